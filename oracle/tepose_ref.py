@@ -1,0 +1,281 @@
+"""CPU ORACLE for the TePose per-window inference hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+`cpu_baseline` leg and __graft_entry__.smoke() may import it; the product path
+(tepose_amd/) never does and fails loudly when the HIP extension is missing.
+
+It restates, in plain torch-CPU tensor ops (any float dtype; float64 gives the
+high-precision truth), the algorithm of the reference's `TePose.forward` in
+eval mode.  Citations are relative to /root/reference:
+
+  encoder      lib/models/tepose.py:44-87   (torch.nn.GRU gate math, gates r,z,n)
+  regressor    lib/models/spin.py:240-291
+  rot6d -> R   lib/utils/geometry.py:330-344
+  SMPL wrapper lib/models/smpl.py:61-84
+  projection   lib/models/spin.py:307-351
+  R -> aa      lib/utils/geometry.py:68-233
+
+PARITY PINNING.  Everything except LBS is pinned against the reference's own
+classes run in the build container (tests/golden/make_golden.py imports
+/root/reference with stub modules and writes tests/golden/*.npz; the `-m "not
+gpu"` tests check this file against those vectors).  The LBS arithmetic itself
+lives in the third-party package `smplx` (requirements.txt:7 pins 0.1.13; the
+code imports `SMPLOutput`, so a later 0.1.2x was really used), which is neither
+vendored in the reference nor installed here and whose licence-gated model files
+are absent: for `lbs()` below **parity is unpinned** -- it restates the published
+SMPL / smplx.lbs algorithm (blend shapes, joint regression, pose blend shapes,
+rigid transform chain, linear blend skinning) and is checked by
+invariants only (identity pose, rigid global rotation, affine consistency).
+"""
+import torch
+import torch.nn.functional as F
+
+# ---- SMPL joint tables (values as in reference lib/models/smpl.py:14-58) ------------
+# 49 output joints = indices into [24 LBS joints | 21 vertex-picked | 9 regressed].
+JOINT_MAP_49 = [24, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 25, 26, 27, 28, 29, 30, 31,
+                32, 33, 34, 8, 5, 45, 46, 4, 7, 21, 19, 17, 16, 18, 20, 47, 48, 49, 50, 51, 52,
+                53, 24, 26, 25, 28, 27]
+H36M_TO_J14 = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10]
+# smplx VertexJointSelector for SMPL (face, feet, finger-tip vertices)
+EXTRA_VERTEX_IDS = [332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
+                    2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133]
+
+
+def _t(a, dtype):
+    return a.to(dtype) if torch.is_tensor(a) else torch.as_tensor(a, dtype=dtype)
+
+
+# ---- encoder --------------------------------------------------------------------------
+def gru_cell(gi, h, w_hh, b_hh):
+    """One GRU step given gi = x W_ih^T + b_ih.  torch.nn.GRU semantics, gate rows
+    [r; z; n] (call sites lib/models/tepose.py:53-64)."""
+    H = h.shape[1]
+    gh = h @ w_hh.t() + b_hh
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h
+
+
+def _scan(seq, sd, prefix, steps=None):
+    """Run one GRU direction over seq[T,B,K] in the given order; returns [steps,B,H]."""
+    w_ih, w_hh = sd[prefix.replace('@', 'weight_ih')], sd[prefix.replace('@', 'weight_hh')]
+    b_ih, b_hh = sd[prefix.replace('@', 'bias_ih')], sd[prefix.replace('@', 'bias_hh')]
+    T, B = seq.shape[:2]
+    h = seq.new_zeros(B, w_hh.shape[1])
+    out = []
+    for t in range(T if steps is None else steps):
+        h = gru_cell(seq[t] @ w_ih.t() + b_ih, h, w_hh, b_hh)
+        out.append(h)
+    return torch.stack(out)
+
+
+def encoder_fwd(sd, x, n_layers, is_train=False):
+    """TemporalEncoder.forward (lib/models/tepose.py:71-87), computing only the
+    cell steps whose results are consumed.  sd: dict of tensors
+    keyed like the reference state dict without the 'encoder.' prefix."""
+    xs = x.transpose(0, 1)                              # [T,B,F]  (tepose.py:73)
+    seq = xs
+    for l in range(n_layers):
+        seq = _scan(seq, sd, 'gru_fwd.@_l%d' % l)
+    y_last = seq[-1]                                    # y[-1]    (tepose.py:79)
+    seq = xs.flip(0)                                    # torch.flip(x,[1]) (tepose.py:75)
+    for l in range(n_layers):
+        top = l == n_layers - 1
+        f = _scan(seq, sd, 'gru_rec.@_l%d' % l, steps=1 if top else None)
+        b = _scan(seq.flip(0), sd, 'gru_rec.@_l%d_reverse' % l).flip(0)
+        if top:
+            y_rec0 = torch.cat([f[0], b[0]], dim=1)     # y_rec[0] (tepose.py:80)
+        else:
+            seq = torch.cat([f, b], dim=2)
+    y_fwd = F.relu(y_last) @ sd['linear_fwd.weight'].t() + sd['linear_fwd.bias']
+    y_rec = F.relu(y_rec0) @ sd['linear_rec.weight'].t() + sd['linear_rec.bias']
+    if is_train:
+        return torch.stack([y_fwd, y_rec], dim=1)
+    return (y_fwd + y_rec) / 2
+
+
+def encoder_fwd_nn_gru(sd, x, n_layers, hidden):
+    """Same function through torch.nn.GRU modules exactly as the reference builds
+    them (all T steps of every direction) -- the op sequence the reference runs
+    on CPU; used as the timed cpu_baseline and as a cross-check of encoder_fwd."""
+    gf = torch.nn.GRU(x.shape[2], hidden, num_layers=n_layers, bidirectional=False)
+    gr = torch.nn.GRU(x.shape[2], hidden, num_layers=n_layers, bidirectional=True)
+    gf.load_state_dict({k[8:]: v for k, v in sd.items() if k.startswith('gru_fwd.')})
+    gr.load_state_dict({k[8:]: v for k, v in sd.items() if k.startswith('gru_rec.')})
+    gf, gr = gf.to(x.dtype), gr.to(x.dtype)
+    with torch.no_grad():
+        y, _ = gf(x.permute(1, 0, 2))
+        y_rec, _ = gr(torch.flip(x, dims=[1]).permute(1, 0, 2))
+        y_fwd = F.linear(F.relu(y[-1]), sd['linear_fwd.weight'], sd['linear_fwd.bias'])
+        y_r = F.linear(F.relu(y_rec[0]), sd['linear_rec.weight'], sd['linear_rec.bias'])
+    return (y_fwd + y_r) / 2
+
+
+# ---- regressor FC loop ------------------------------------------------------------------
+def regressor_iterations(sd, feat, n_iter=3):
+    """Regressor.forward lines spin.py:243-261 (dropout = identity in eval)."""
+    B = feat.shape[0]
+    pose = sd['init_pose'].expand(B, -1)
+    shape = sd['init_shape'].expand(B, -1)
+    cam = sd['init_cam'].expand(B, -1)
+    for _ in range(n_iter):
+        xc = torch.cat([feat, pose, shape, cam], 1)
+        xc = xc @ sd['fc1.weight'].t() + sd['fc1.bias']
+        xc = xc @ sd['fc2.weight'].t() + sd['fc2.bias']
+        pose = xc @ sd['decpose.weight'].t() + sd['decpose.bias'] + pose
+        shape = xc @ sd['decshape.weight'].t() + sd['decshape.bias'] + shape
+        cam = xc @ sd['deccam.weight'].t() + sd['deccam.bias'] + cam
+    return pose, shape, cam
+
+
+# ---- geometry ---------------------------------------------------------------------------
+def rot6d_to_rotmat(x):
+    """geometry.py:330-344.  Interleaved 6D layout: a1 = x[0::2], a2 = x[1::2]."""
+    x = x.reshape(-1, 3, 2)
+    a1, a2 = x[:, :, 0], x[:, :, 1]
+    b1 = a1 / a1.norm(dim=1, keepdim=True).clamp_min(1e-6)
+    u = a2 - (b1 * a2).sum(dim=1, keepdim=True) * b1
+    b2 = u / u.norm(dim=1, keepdim=True).clamp_min(1e-6)
+    b3 = torch.cross(b1, b2, dim=1)
+    return torch.stack([b1, b2, b3], dim=-1)
+
+
+def rotmat_to_angle_axis(R):
+    """geometry.py:68-233 on [N,3,3]: 4-branch quaternion of M = R^T, then
+    quaternion -> axis-angle with atan2; NaN -> 0."""
+    M = R.transpose(1, 2)
+    m00, m01, m02 = M[:, 0, 0], M[:, 0, 1], M[:, 0, 2]
+    m10, m11, m12 = M[:, 1, 0], M[:, 1, 1], M[:, 1, 2]
+    m20, m21, m22 = M[:, 2, 0], M[:, 2, 1], M[:, 2, 2]
+    d2 = m22 < 1e-6
+    d01 = m00 > m11
+    d0n1 = m00 < -m11
+    t0 = 1 + m00 - m11 - m22
+    q0 = torch.stack([m12 - m21, t0, m01 + m10, m20 + m02], -1)
+    t1 = 1 - m00 + m11 - m22
+    q1 = torch.stack([m20 - m02, m01 + m10, t1, m12 + m21], -1)
+    t2 = 1 - m00 - m11 + m22
+    q2 = torch.stack([m01 - m10, m20 + m02, m12 + m21, t2], -1)
+    t3 = 1 + m00 + m11 + m22
+    q3 = torch.stack([t3, m12 - m21, m20 - m02, m01 - m10], -1)
+    c0 = (d2 & d01).to(R.dtype)[:, None]
+    c1 = (d2 & ~d01).to(R.dtype)[:, None]
+    c2 = (~d2 & d0n1).to(R.dtype)[:, None]
+    c3 = (~d2 & ~d0n1).to(R.dtype)[:, None]
+    q = q0 * c0 + q1 * c1 + q2 * c2 + q3 * c3
+    q = q / torch.sqrt(t0[:, None] * c0 + t1[:, None] * c1 + t2[:, None] * c2 + t3[:, None] * c3)
+    q = q * 0.5
+    w, xyz = q[:, 0], q[:, 1:]
+    s2 = (xyz * xyz).sum(-1)
+    s = torch.sqrt(s2)
+    two_theta = 2.0 * torch.where(w < 0, torch.atan2(-s, -w), torch.atan2(s, w))
+    k = torch.where(s2 > 0, two_theta / s, torch.full_like(s, 2.0))
+    aa = xyz * k[:, None]
+    return torch.where(torch.isnan(aa), torch.zeros_like(aa), aa)
+
+
+def batch_rodrigues(aa):
+    """smplx.lbs.batch_rodrigues [published algorithm; parity unpinned]:
+    angle = ||aa + 1e-8||, R = I + sin K + (1-cos) K^2."""
+    angle = torch.norm(aa + 1e-8, dim=1, keepdim=True)
+    d = aa / angle
+    c, s = torch.cos(angle)[:, :, None], torch.sin(angle)[:, :, None]
+    rx, ry, rz = d[:, 0], d[:, 1], d[:, 2]
+    z = torch.zeros_like(rx)
+    K = torch.stack([z, -rz, ry, rz, z, -rx, -ry, rx, z], dim=1).view(-1, 3, 3)
+    eye = torch.eye(3, dtype=aa.dtype)[None]
+    return eye + s * K + (1 - c) * (K @ K)
+
+
+def projection(joints, cam):
+    """spin.py:307-351 with R = I, centre = 0, f = 5000, then / (224/2)."""
+    t = torch.stack([cam[:, 1], cam[:, 2], 2 * 5000. / (224. * cam[:, 0] + 1e-9)], dim=-1)
+    p = joints + t[:, None]
+    p = p / p[:, :, -1:]
+    return (5000. * p[:, :, :2]) / (224. / 2.)
+
+
+# ---- SMPL -------------------------------------------------------------------------------
+def lbs(smpl, betas, rot_mats):
+    """smplx.lbs.lbs with pose2rot=False [published algorithm; PARITY UNPINNED, see
+    module docstring].  smpl: dict of tensors (v_template[V,3], shapedirs[V,3,10],
+    posedirs[207,3V], J_regressor[24,V], lbs_weights[V,24], parents[24]).
+    Returns verts[B,V,3], posed joints[B,24,3]."""
+    B = betas.shape[0]
+    dt = betas.dtype
+    v_shaped = smpl['v_template'] + torch.einsum('bl,mkl->bmk', betas, smpl['shapedirs'])
+    J = torch.einsum('bik,ji->bjk', v_shaped, smpl['J_regressor'])
+    eye = torch.eye(3, dtype=dt)
+    pose_feature = (rot_mats[:, 1:] - eye).reshape(B, -1)
+    v_posed = v_shaped + (pose_feature @ smpl['posedirs']).view(B, -1, 3)
+    parents = [int(p) for p in smpl['parents']]
+    rel = J.clone()
+    rel[:, 1:] = J[:, 1:] - J[:, parents[1:]]
+    Tm = torch.zeros(B, 24, 4, 4, dtype=dt)
+    Tm[:, :, :3, :3] = rot_mats
+    Tm[:, :, :3, 3] = rel
+    Tm[:, :, 3, 3] = 1
+    chain = [Tm[:, 0]]
+    for i in range(1, 24):
+        chain.append(chain[parents[i]] @ Tm[:, i])
+    G = torch.stack(chain, dim=1)
+    posed = G[:, :, :3, 3]
+    A = G.clone()
+    A[:, :, :3, 3] = G[:, :, :3, 3] - torch.einsum('bjik,bjk->bji', G[:, :, :3, :3], J)
+    Tv = torch.einsum('vj,bjik->bvik', smpl['lbs_weights'], A)
+    verts = torch.einsum('bvik,bvk->bvi', Tv[:, :, :3, :3], v_posed) + Tv[:, :, :3, 3]
+    return verts, posed
+
+
+def smpl_joints49(smpl, verts, posed):
+    """smplx vertex joint selector (+21) then wrapper lib/models/smpl.py:72-84."""
+    j45 = torch.cat([posed, verts[:, EXTRA_VERTEX_IDS]], dim=1)
+    extra = torch.einsum('bik,ji->bjk', verts, smpl['J_regressor_extra'])
+    return torch.cat([j45, extra], dim=1)[:, JOINT_MAP_49]
+
+
+def regressor_fwd(sd, smpl, feat, J_regressor=None, n_iter=3):
+    """Regressor.forward (spin.py:240-291) -> dict like one element of its list."""
+    B = feat.shape[0]
+    pose6d, shape, cam = regressor_iterations(sd, feat, n_iter)
+    R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
+    verts, posed = lbs(smpl, shape, R)
+    joints = smpl_joints49(smpl, verts, posed)
+    if J_regressor is not None:
+        joints = torch.einsum('bik,ji->bjk', verts, J_regressor)[:, H36M_TO_J14]
+    kp2d = projection(joints, cam)
+    aa = rotmat_to_angle_axis(R.reshape(-1, 3, 3)).reshape(-1, 72)
+    return {'theta': torch.cat([cam, aa, shape], dim=1), 'verts': verts, 'kp_2d': kp2d,
+            'kp_3d': joints, 'rotmat': R, 'pose6d': pose6d}
+
+
+def split_state_dict(state, dtype=torch.float32):
+    """Full reference-keyed state dict -> (encoder dict, regressor dict) of tensors."""
+    enc = {k[len('encoder.'):]: _t(v, dtype) for k, v in state.items() if k.startswith('encoder.')}
+    reg = {k[len('regressor.'):]: _t(v, dtype) for k, v in state.items()
+           if k.startswith('regressor.') and not k.startswith('regressor.smpl.')}
+    return enc, reg
+
+
+def smpl_tensors(smpl_np, dtype=torch.float32):
+    out = {k: _t(v, dtype) for k, v in smpl_np.items() if k != 'parents'}
+    out['parents'] = [int(p) for p in smpl_np['parents']]
+    return out
+
+
+def tepose_fwd(state, smpl_np, x, n_layers, J_regressor=None, dtype=torch.float32, nn_gru=False):
+    """TePose.forward, eval mode (lib/models/tepose.py:121-136).  Returns the dict of
+    the single list element plus 'feature' (encoder output) for module-level tests."""
+    enc, reg = split_state_dict(state, dtype)
+    smpl = smpl_tensors(smpl_np, dtype)
+    x = _t(x, dtype)
+    with torch.no_grad():
+        if nn_gru:
+            feat = encoder_fwd_nn_gru(enc, x, n_layers, enc['gru_fwd.weight_hh_l0'].shape[1])
+        else:
+            feat = encoder_fwd(enc, x, n_layers)
+        out = regressor_fwd(reg, smpl, feat,
+                            None if J_regressor is None else _t(J_regressor, dtype))
+    out['feature'] = feat
+    return out

@@ -1,0 +1,208 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes.
+
+Run only in the build container (needs /root/reference; never on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference (pure Python) cannot be imported as-is here: `yacs`, `torchvision`
+and `smplx` are not installed and the licence-gated data files are absent
+(SURVEY.md 8c).  This script injects stub modules for those three imports and
+patches `np.load` for the two data files read at construction time, then runs the
+real `lib.models.tepose.TePose`, `lib.models.spin.Regressor`,
+`lib.utils.geometry.*` from /root/reference on deterministic synthetic weights
+(tepose_amd.synth, regenerable anywhere) and stores the outputs.
+
+The `smplx.SMPL` stub is the oracle's own LBS (oracle.tepose_ref.lbs): these
+vectors therefore pin the encoder, FC loop, rot6d, the SMPL wrapper's joint
+logic, the J_regressor path, projection and R->axis-angle against reference
+code; LBS itself stays unpinned (see oracle/tepose_ref.py header).
+
+Fixtures hold inputs' seeds and expected outputs only -- no reference source.
+"""
+import os
+import sys
+import types
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+
+from tepose_amd import synth  # noqa: E402
+from oracle import tepose_ref as O  # noqa: E402
+
+SMPL_NP = synth.synthetic_smpl(0)
+MEAN = synth.synthetic_mean_params(0)
+
+
+class _StubSMPL(nn.Module):
+    """Stand-in for smplx.SMPL: oracle LBS over the synthetic tables; returns the 45
+    joints smplx would (24 posed + 21 vertex-picked)."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        self.t = O.smpl_tensors(SMPL_NP)
+
+    def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=False, **kw):
+        assert pose2rot is False
+        R = torch.cat([global_orient, body_pose], dim=1)
+        dt = R.dtype
+        t = {k: (v.to(dt) if torch.is_tensor(v) else v) for k, v in self.t.items()}
+        verts, posed = O.lbs(t, betas, R)
+        joints = torch.cat([posed, verts[:, O.EXTRA_VERTEX_IDS]], dim=1)
+        return _Out(vertices=verts, global_orient=global_orient, body_pose=body_pose,
+                    joints=joints, betas=betas, full_pose=R)
+
+
+_Out = namedtuple('SMPLOutput', 'vertices global_orient body_pose joints betas full_pose')
+
+
+def install_stubs():
+    sys.path.insert(0, REF)
+    yc = types.ModuleType('yacs.config')
+
+    class CN(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def clone(self):
+            import copy
+            return copy.deepcopy(self)
+
+    yc.CfgNode = CN
+    y = types.ModuleType('yacs')
+    y.config = yc
+    sys.modules.update({'yacs': y, 'yacs.config': yc})
+    tv, tvm, tvr = (types.ModuleType(n) for n in
+                    ('torchvision', 'torchvision.models', 'torchvision.models.resnet'))
+    tv.models = tvm
+    tvm.resnet = tvr
+    sys.modules.update({'torchvision': tv, 'torchvision.models': tvm, 'torchvision.models.resnet': tvr})
+    sx, sxb, sxl = (types.ModuleType(n) for n in ('smplx', 'smplx.body_models', 'smplx.lbs'))
+    sx.SMPL = _StubSMPL
+    sxb.SMPLOutput = _Out
+    sxl.vertices2joints = lambda J, v: torch.einsum('bik,ji->bjk', [v, J])
+    sys.modules.update({'smplx': sx, 'smplx.body_models': sxb, 'smplx.lbs': sxl})
+    _np_load = np.load
+
+    def fake_load(p, *a, **k):
+        s = str(p)
+        if s.endswith('J_regressor_extra.npy'):
+            return SMPL_NP['J_regressor_extra']
+        if s.endswith('smpl_mean_params.npz'):
+            return MEAN
+        return _np_load(p, *a, **k)
+
+    np.load = fake_load
+
+
+def verts_digest(v):
+    """[B,6890,3] -> strided subsample + per-person checksums (keeps fixtures small)."""
+    v = np.asarray(v, dtype=np.float64)
+    return {'verts_sub': v[:, ::53].astype(np.float32),
+            'verts_sum': v.sum(axis=1).astype(np.float64),
+            'verts_l2': np.sqrt((v * v).sum(axis=(1, 2))).astype(np.float64)}
+
+
+def run_case(T_mod, name, L, H, B, T, use_jreg, seed_w=0, seed_x=1234):
+    model = T_mod.TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='').eval()
+    sd_np = synth.synthetic_state_dict(L, H, seed_w)
+    sd = model.state_dict()
+    for k in sd:
+        if k in sd_np:
+            assert tuple(sd[k].shape) == sd_np[k].shape, (k, sd[k].shape, sd_np[k].shape)
+            sd[k] = torch.from_numpy(sd_np[k])
+    missing = [k for k in sd_np if k not in sd]
+    assert not missing, missing
+    model.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synth.synthetic_windows(B, T, seed_x))
+    J = torch.from_numpy(SMPL_NP['J_regressor_h36m']) if use_jreg else None
+    with torch.no_grad():
+        feat = model.encoder(x)
+        out = model(x, J_regressor=J)[0]
+        feat_tr = model.encoder(x, is_train=True)
+    d = {'meta': np.array([L, H, B, T, int(use_jreg), seed_w, seed_x], dtype=np.int64),
+         'feature': feat.numpy(), 'feature_train': feat_tr.numpy(),
+         'theta': out['theta'].numpy(), 'kp_2d': out['kp_2d'].numpy(),
+         'kp_3d': out['kp_3d'].numpy(), 'rotmat': out['rotmat'].numpy()}
+    d.update(verts_digest(out['verts'].numpy()))
+    # regressor internals through the reference module on the same feature
+    with torch.no_grad():
+        reg = model.regressor
+        pose, shape, cam = reg.init_pose.expand(B, -1), reg.init_shape.expand(B, -1), reg.init_cam.expand(B, -1)
+        for _ in range(3):
+            xc = torch.cat([feat, pose, shape, cam], 1)
+            xc = reg.fc2(reg.fc1(xc))
+            pose, shape, cam = reg.decpose(xc) + pose, reg.decshape(xc) + shape, reg.deccam(xc) + cam
+    d['pose6d'] = pose.numpy()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **d)
+    print('wrote', name, {k: v.shape for k, v in d.items()})
+
+
+def geometry_cases(G):
+    """Edge vectors for R->aa (each quaternion branch, angle 0, angles near pi about
+    each axis), rot6d->R (incl. degenerate input) and projection."""
+    rs = []
+
+    def rod(axis, ang):
+        a = np.asarray(axis, dtype=np.float64)
+        a = a / np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+    rs.append(np.eye(3))
+    for ax in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, -2, 3], [-1, 0.2, 0.1]):
+        for ang in (1e-4, 0.3, 1.5, 2.2, 3.0, np.pi - 1e-3, np.pi, -2.5):
+            rs.append(rod(ax, ang))
+    rng = np.random.RandomState(7)
+    for _ in range(200):
+        rs.append(rod(rng.randn(3), rng.uniform(0, np.pi)))
+    R = torch.from_numpy(np.stack(rs).astype(np.float32))
+    aa = G.rotation_matrix_to_angle_axis(R.clone())
+    x6 = torch.from_numpy(synth.normal('geom/6d', (64, 144)))
+    x6[0, :6] = 0.0                       # degenerate: zero a1 and a2
+    x6[1, :6] = torch.tensor([1., 2., 0., 0., 0., 0.])   # a2 parallel to a1
+    R6 = G.rot6d_to_rotmat(x6.clone())
+    np.savez_compressed(os.path.join(HERE, 'geometry.npz'), R=R.numpy(), aa=aa.numpy(),
+                        x6=x6.numpy(), R6=R6.numpy())
+    print('wrote geometry', R.shape, aa.shape, R6.shape)
+
+
+def main():
+    install_stubs()
+    import lib.models.tepose as T_mod
+    import lib.models.smpl as S_mod
+    import lib.models.spin as P_mod
+    import lib.utils.geometry as G
+    # table parity: the oracle's literal tables vs the reference's
+    assert [S_mod.JOINT_MAP[n] for n in S_mod.JOINT_NAMES] == O.JOINT_MAP_49
+    assert S_mod.H36M_TO_J14 == O.H36M_TO_J14
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    run_case(T_mod, 'tepose_L2H1024_B2T6_j14', 2, 1024, 2, 6, True)
+    run_case(T_mod, 'tepose_L2H1024_B2T6_j49', 2, 1024, 2, 6, False)
+    run_case(T_mod, 'tepose_L2H1024_B2T16_j14', 2, 1024, 2, 16, True)
+    run_case(T_mod, 'tepose_L2H1024_B1T32_j14', 2, 1024, 1, 32, True)
+    run_case(T_mod, 'tepose_L1H128_B3T5_j49', 1, 128, 3, 5, False, seed_w=3, seed_x=77)
+    run_case(T_mod, 'tepose_L3H64_B2T4_j14', 3, 64, 2, 4, True, seed_w=4, seed_x=78)
+    geometry_cases(G)
+    # projection vector
+    j = torch.from_numpy(synth.normal('geom/j', (4, 14, 3), std=0.5))
+    cam = torch.from_numpy(synth.normal('geom/cam', (4, 3), std=0.1)) + torch.tensor([0.9, 0., 0.])
+    np.savez_compressed(os.path.join(HERE, 'projection.npz'), joints=j.numpy(), cam=cam.numpy(),
+                        kp_2d=P_mod.projection(j, cam).numpy())
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,125 @@
+"""CPU: the oracle (oracle/tepose_ref.py) against the committed golden vectors that
+tests/golden/make_golden.py produced by running the reference's own classes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tepose_ref as O
+from tepose_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'tepose_*.npz')))
+
+
+@pytest.fixture(scope='module')
+def smpl_np():
+    return synth.synthetic_smpl(0)
+
+
+def _run(case, smpl_np, dtype=torch.float32, nn_gru=False):
+    g = np.load(os.path.join(GOLDEN, case + '.npz'))
+    L, H, B, T, use_j, seed_w, seed_x = [int(v) for v in g['meta']]
+    state = synth.synthetic_state_dict(L, H, seed_w)
+    x = synth.synthetic_windows(B, T, seed_x)
+    J = smpl_np['J_regressor_h36m'] if use_j else None
+    out = O.tepose_fwd(state, smpl_np, x, L, J_regressor=J, dtype=dtype, nn_gru=nn_gru)
+    return g, {k: v.double().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_matches_reference_golden(case, smpl_np):
+    g, o = _run(case, smpl_np)
+    # fp32 reference vs fp32 restatement: differences are summation-order noise only
+    assert np.abs(o['feature'] - g['feature']).max() < 2e-5
+    assert np.abs(o['pose6d'] - g['pose6d']).max() < 2e-5
+    assert np.abs(o['rotmat'] - g['rotmat']).max() < 2e-5
+    assert np.abs(o['theta'] - g['theta']).max() < 1e-4
+    assert np.abs(o['kp_3d'] - g['kp_3d']).max() < 2e-5
+    assert np.abs(o['kp_2d'] - g['kp_2d']).max() < 1e-4
+    assert np.abs(o['verts'][:, ::53] - g['verts_sub']).max() < 2e-5
+    assert np.abs(o['verts'].sum(1) - g['verts_sum']).max() < 5e-3
+
+
+@pytest.mark.parametrize('case', ['tepose_L2H1024_B2T6_j14', 'tepose_L1H128_B3T5_j49'])
+def test_oracle_fp64_bounds_reference_noise(case, smpl_np):
+    """The fp64 oracle is the truth both fp32 paths scatter around."""
+    g, o = _run(case, smpl_np, dtype=torch.float64)
+    assert np.abs(o['feature'] - g['feature']).max() < 2e-5
+    assert np.abs(o['verts'][:, ::53] - g['verts_sub']).max() < 2e-5
+    assert np.abs(o['theta'] - g['theta']).max() < 1e-4
+
+
+def test_minimal_cell_schedule_equals_nn_gru(smpl_np):
+    """encoder_fwd (5T+1 consumed cell steps) == torch.nn.GRU op sequence."""
+    state = synth.synthetic_state_dict(2, 128, 5)
+    enc, _ = O.split_state_dict(state, torch.float64)
+    x = torch.from_numpy(synth.synthetic_windows(3, 7, 9)).double()
+    a = O.encoder_fwd(enc, x, 2)
+    b = O.encoder_fwd_nn_gru(enc, x, 2, 128)
+    assert (a - b).abs().max() < 1e-12
+
+
+def test_encoder_train_mode_golden(smpl_np):
+    g = np.load(os.path.join(GOLDEN, 'tepose_L2H1024_B2T6_j14.npz'))
+    state = synth.synthetic_state_dict(2, 1024, 0)
+    enc, _ = O.split_state_dict(state)
+    x = torch.from_numpy(synth.synthetic_windows(2, 6, 1234))
+    with torch.no_grad():
+        f = O.encoder_fwd(enc, x, 2, is_train=True)
+    assert np.abs(f.numpy() - g['feature_train']).max() < 2e-5
+
+
+def test_geometry_golden():
+    g = np.load(os.path.join(GOLDEN, 'geometry.npz'))
+    aa = O.rotmat_to_angle_axis(torch.from_numpy(g['R'])).numpy()
+    # identical op sequence -> tight; near-pi rows are ill-conditioned but deterministic
+    assert np.abs(aa - g['aa']).max() < 1e-5
+    R6 = O.rot6d_to_rotmat(torch.from_numpy(g['x6'])).numpy()
+    assert np.abs(R6 - g['R6']).max() < 1e-6
+    p = np.load(os.path.join(GOLDEN, 'projection.npz'))
+    kp = O.projection(torch.from_numpy(p['joints']), torch.from_numpy(p['cam'])).numpy()
+    assert np.abs(kp - p['kp_2d']).max() < 1e-5
+
+
+# ---- LBS invariants (parity unpinned vs smplx; see oracle header) -------------------------
+def _rand_rot(n, seed):
+    a = torch.from_numpy(synth.normal('rot%d' % seed, (n, 3), std=0.8)).double()
+    return O.batch_rodrigues(a)
+
+
+def test_lbs_identity_pose_gives_shaped_template(smpl_np):
+    s = O.smpl_tensors(smpl_np, torch.float64)
+    betas = torch.from_numpy(synth.normal('b', (2, 10), std=0.5)).double()
+    R = torch.eye(3, dtype=torch.float64).expand(2, 24, 3, 3).contiguous()
+    v, j = O.lbs(s, betas, R)
+    v_shaped = s['v_template'] + torch.einsum('bl,mkl->bmk', betas, s['shapedirs'])
+    # float32 skin-weight rows sum to 1 only to ~6e-8, so T_v is I to that accuracy
+    assert (v - v_shaped).abs().max() < 5e-7
+    assert (j - torch.einsum('bik,ji->bjk', v_shaped, s['J_regressor'])).abs().max() < 1e-12
+
+
+def test_lbs_global_rotation_is_rigid_about_root(smpl_np):
+    s = O.smpl_tensors(smpl_np, torch.float64)
+    betas = torch.from_numpy(synth.normal('b2', (1, 10), std=0.5)).double()
+    R = _rand_rot(24, 1).view(1, 24, 3, 3)
+    v0, j0 = O.lbs(s, betas, R)
+    Q = _rand_rot(1, 2)[0]
+    R2 = R.clone()
+    R2[:, 0] = Q @ R[:, 0]
+    v1, j1 = O.lbs(s, betas, R2)
+    root = j0[:, 0:1]
+    assert (j1[:, 0] - j0[:, 0]).abs().max() < 1e-12          # root joint fixed
+    assert ((v0 - root) @ Q.t() + root - v1).abs().max() < 1e-7   # sum_j W[v,j] = 1 +- 6e-8
+    assert ((j0 - root) @ Q.t() + root - j1).abs().max() < 1e-10
+
+
+def test_batch_rodrigues_is_rotation():
+    R = _rand_rot(50, 3)
+    assert (R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-12
+    assert (torch.linalg.det(R) - 1).abs().max() < 1e-12
+    aa = torch.from_numpy(synth.normal('rot3', (50, 3), std=0.8)).double()
+    back = O.rotmat_to_angle_axis(R)
+    assert (back - aa).abs().max() < 1e-6
