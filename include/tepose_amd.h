@@ -1,0 +1,134 @@
+/* tepose_amd.h -- C ABI of libtepose_hip.so: the MI355X (gfx950) implementation of the
+ * TePose per-window inference hot path.
+ *
+ * The reference (ostadabbas/TePose) is pure Python/PyTorch and has no FFI layer; its
+ * boundary for this path is the Python module API of lib/models.  The
+ * entry points below are what the Python drop-in (tepose_amd/tepose.py, spin.py, smpl.py)
+ * binds through ctypes; each one names the reference code it replaces (paths relative to
+ * the reference repo root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t, or a negative
+ *     TEPOSE_E_* argument error; nothing throws, aborts or synchronises the device;
+ *   - all `const float*` / `float*` arguments are DEVICE pointers owned by the caller
+ *     (fp32, contiguous unless a stride is given); the library never frees them and keeps
+ *     none beyond the call, except the packed-weight blob registered in a model handle;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - a handle is host memory only; calls on one handle are re-entrant across streams as
+ *     long as each call gets its own workspace.
+ */
+#ifndef TEPOSE_AMD_H
+#define TEPOSE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEPOSE_ABI_VERSION 1
+
+#define TEPOSE_E_ARG (-1)       /* null pointer / non-positive size / bad enum           */
+#define TEPOSE_E_SHAPE (-2)     /* dimension not supported (see each function)           */
+#define TEPOSE_E_WORKSPACE (-3) /* workspace smaller than tepose_*_workspace_bytes()     */
+#define TEPOSE_E_STATE (-4)     /* handle not packed yet                                 */
+
+#define TEPOSE_FEAT 2048        /* ResNet feature width (lib/models/tepose.py:68)         */
+#define TEPOSE_THETA 85         /* cam3 + pose72 + shape10 (lib/models/spin.py:285)       */
+#define TEPOSE_INPUT 2133       /* GRU input_size (lib/models/tepose.py:54,60)            */
+#define TEPOSE_NVERT 6890
+#define TEPOSE_NJOINT 24
+
+typedef struct tepose_model tepose_model; /* opaque */
+
+int tepose_version(void);
+const char* tepose_error_string(int code);
+
+/* ---- model handle ------------------------------------------------------------------
+ * Replaces TePose.__init__ / TemporalEncoder.__init__ / Regressor.__init__
+ * (lib/models/tepose.py:44-69,90-118; lib/models/spin.py:209-238).
+ * n_layers >= 1, hidden >= 1 (padded internally to a multiple of 64).               */
+int tepose_create(int n_layers, int hidden, tepose_model** out);
+void tepose_destroy(tepose_model* m);
+
+/* Bytes of the single device blob that holds every packed constant of the model
+ * (encoder + regressor + SMPL tables).  The caller allocates it; it is what gets
+ * broadcast to the other ranks of a node.                                            */
+size_t tepose_packed_bytes(const tepose_model* m);
+int tepose_set_blob(tepose_model* m, void* blob, size_t bytes);
+
+/* Pack encoder weights.  `w` = HOST array of DEVICE pointers in the reference's
+ * state-dict order, n_w = 8*L + 16*L... precisely:
+ *   for l in 0..L-1:  gru_fwd.{weight_ih,weight_hh,bias_ih,bias_hh}_l{l}
+ *   for l in 0..L-1, sfx in ("", "_reverse"): gru_rec.{weight_ih,weight_hh,bias_ih,bias_hh}_l{l}{sfx}
+ *   linear_fwd.weight, linear_fwd.bias, linear_rec.weight, linear_rec.bias
+ * i.e. n_w = 12*L + 4.  Shapes as torch.nn.GRU / nn.Linear make them
+ * (lib/models/tepose.py:53-69).                                                      */
+int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* stream);
+
+/* Pack regressor weights: w = { fc1.weight[1024,2205], fc1.bias, fc2.weight[1024,1024],
+ * fc2.bias, decpose.weight[144,1024], decpose.bias, decshape.weight[10,1024],
+ * decshape.bias, deccam.weight[3,1024], deccam.bias, init_pose[144], init_shape[10],
+ * init_cam[3] }  (lib/models/spin.py:215-238), n_w = 13.                             */
+int tepose_pack_regressor(tepose_model* m, const float* const* w, int n_w, void* stream);
+
+/* Pack SMPL tables (the buffers smplx.SMPL registers + lib/models/smpl.py:67-68):
+ * v_template[6890,3], shapedirs[6890,3,10], posedirs[207,20670], J_regressor[24,6890],
+ * lbs_weights[6890,24], J_regressor_extra[9,6890]; `parents` is a HOST int32[24].
+ * Re-callable: evaluate.py:130-135 swaps model.regressor.smpl per gender.            */
+int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shapedirs,
+                     const float* posedirs, const float* J_regressor, const float* lbs_weights,
+                     const float* J_regressor_extra, const int32_t* parents_host, void* stream);
+
+/* Optional evaluation joint regressor (J_regressor_h36m[17,6890], evaluate.py:109,
+ * lib/models/spin.py:275-278).  Packed into a caller-provided device buffer of
+ * tepose_jreg_packed_bytes() so several regressors can coexist.                       */
+size_t tepose_jreg_packed_bytes(void);
+int tepose_pack_jreg(const float* J_regressor_17x6890, void* packed, void* stream);
+
+/* ---- forward ------------------------------------------------------------------------ */
+size_t tepose_workspace_bytes(const tepose_model* m, int B, int T);
+
+/* TemporalEncoder.forward (lib/models/tepose.py:71-87).
+ * x[B,T,2133] -> feat: eval mode [B,2048] = (y_fwd + y_rec)/2 ; is_train != 0 writes
+ * [B,2,2048] = stack(y_fwd, y_rec).                                                  */
+int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train,
+                       float* feat, void* workspace, size_t ws_bytes, void* stream);
+
+/* Regressor.forward (lib/models/spin.py:240-291) incl. rot6d_to_rotmat
+ * (lib/utils/geometry.py:330-344), SMPL wrapper (lib/models/smpl.py:72-84 over
+ * smplx.lbs), projection (spin.py:307-351), rotation_matrix_to_angle_axis
+ * (geometry.py:68-233).  feat[N,2048] -> theta[N,85], verts[N,6890,3], kp_3d[N,J,3],
+ * kp_2d[N,J,2], rotmat[N,24,3,3]; J = 14 when jreg_packed != NULL (H36M_TO_J14 path),
+ * else 49.  n_iter = 3 in the reference.                                             */
+int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter,
+                         const void* jreg_packed, float* theta, float* verts, float* kp_3d,
+                         float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
+                         void* stream);
+
+/* TePose.forward, eval mode (lib/models/tepose.py:121-136) = the two calls above.     */
+int tepose_forward(const tepose_model* m, const float* x, int B, int T, const void* jreg_packed,
+                   float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
+                   void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- building blocks exported for tests and bench.py --------------------------------- */
+/* C[M,N] = (relu_a ? relu(A) : A)[M,K] * W[N,K]^T (+ bias[N]) with the library's own
+ * fp32-MFMA kernel.  A rows must be 16-byte aligned (lda % 4 == 0); W is packed on the
+ * fly into `workspace` (>= tepose_gemm_workspace_bytes(N,K)).                          */
+size_t tepose_gemm_workspace_bytes(int N, int K);
+int tepose_gemm_f32(const float* A, long lda, const float* W, long ldw, const float* bias,
+                    float* C, long ldc, int M, int N, int K, int relu_a, void* workspace,
+                    size_t ws_bytes, void* stream);
+
+/* Per-launch timing of the dominant kernel (the layer-0 input-projection GEMM) with
+ * hipEvents on the launch stream: enable, run forwards, then read back.  Reading
+ * synchronises on the recorded events only.  Used by bench.py for the `roofline`
+ * object; off by default.                                                            */
+int tepose_profile_enable(tepose_model* m, int on);
+int tepose_profile_read(tepose_model* m, double* total_ms, int* n_launches, double* flops_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEPOSE_AMD_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libtepose_hip.so (C ABI in include/tepose_amd.h).
+
+There is no CPU or PyTorch fallback: if the shared library is missing the import
+fails with instructions, and every non-zero return code raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtepose_hip.so')
+
+# every symbol include/tepose_amd.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    'tepose_version', 'tepose_error_string', 'tepose_create', 'tepose_destroy',
+    'tepose_packed_bytes', 'tepose_set_blob', 'tepose_pack_encoder', 'tepose_pack_regressor',
+    'tepose_pack_smpl', 'tepose_jreg_packed_bytes', 'tepose_pack_jreg', 'tepose_workspace_bytes',
+    'tepose_encoder_fwd', 'tepose_regressor_fwd', 'tepose_forward', 'tepose_gemm_workspace_bytes',
+    'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read',
+]
+
+_lib = None
+
+
+class TeposeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            'tepose_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no fallback path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    fp = c_void_p  # device pointers travel as integers
+    lib.tepose_version.restype = c_int
+    lib.tepose_error_string.restype = c_char_p
+    lib.tepose_error_string.argtypes = [c_int]
+    lib.tepose_create.argtypes = [c_int, c_int, POINTER(c_void_p)]
+    lib.tepose_destroy.argtypes = [c_void_p]
+    lib.tepose_destroy.restype = None
+    lib.tepose_packed_bytes.argtypes = [c_void_p]
+    lib.tepose_packed_bytes.restype = c_size_t
+    lib.tepose_set_blob.argtypes = [c_void_p, fp, c_size_t]
+    lib.tepose_pack_encoder.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
+    lib.tepose_pack_regressor.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
+    lib.tepose_pack_smpl.argtypes = [c_void_p, fp, fp, fp, fp, fp, fp, POINTER(c_int32), c_void_p]
+    lib.tepose_jreg_packed_bytes.restype = c_size_t
+    lib.tepose_pack_jreg.argtypes = [fp, fp, c_void_p]
+    lib.tepose_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.tepose_workspace_bytes.restype = c_size_t
+    lib.tepose_encoder_fwd.argtypes = [c_void_p, fp, c_int, c_int, c_int, fp, fp, c_size_t, c_void_p]
+    lib.tepose_regressor_fwd.argtypes = [c_void_p, fp, c_int, c_int, fp, fp, fp, fp, fp, fp, fp,
+                                         c_size_t, c_void_p]
+    lib.tepose_forward.argtypes = [c_void_p, fp, c_int, c_int, fp, fp, fp, fp, fp, fp, fp, c_size_t,
+                                   c_void_p]
+    lib.tepose_gemm_workspace_bytes.argtypes = [c_int, c_int]
+    lib.tepose_gemm_workspace_bytes.restype = c_size_t
+    lib.tepose_gemm_f32.argtypes = [fp, c_long, fp, c_long, fp, fp, c_long, c_int, c_int, c_int, c_int,
+                                    fp, c_size_t, c_void_p]
+    lib.tepose_profile_enable.argtypes = [c_void_p, c_int]
+    lib.tepose_profile_read.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is c_int and name != 'tepose_version':
+            pass
+    if lib.tepose_version() != 1:
+        raise ImportError('tepose_amd: ABI version mismatch (%d)' % lib.tepose_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tepose_error_string(rc)
+        raise TeposeError('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', rc))
+
+
+def ptr_array(ptrs):
+    arr = (c_void_p * len(ptrs))(*ptrs)
+    return arr

@@ -1,0 +1,588 @@
+// C ABI of libtepose_hip.so (include/tepose_amd.h): model handle, weight packing, and the
+// launch sequence of the TePose forward.  Host code only; every kernel lives in gemm.hip,
+// misc.hip, smpl.hip.  Nothing here allocates device memory or synchronises the device.
+#include "../../include/tepose_amd.h"
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+using namespace tepose;
+
+namespace {
+
+struct DirW {                     // one GRU layer/direction inside the blob (float offsets)
+  size_t wih = 0, bih = 0;        // input projection (layer-0 ones live in the stacked block)
+  size_t whh = 0, bhh = 0;
+};
+
+struct SmplOff {
+  size_t J0, JS, blendW, lbsW, parents, depth, xr_ptr, xr_idx, xr_val;
+};
+
+}  // namespace
+
+struct tepose_model {
+  int L = 0, H = 0, Hp = 0;
+  float* blob = nullptr;
+  size_t blob_floats = 0;
+  bool enc_packed = false, reg_packed = false, smpl_packed = false;
+  // encoder offsets
+  size_t wih0 = 0, bih0 = 0;                    // stacked [9Hp][2144]: fwd | rec_reverse | rec
+  std::vector<DirW> fwd, rec_f, rec_r;          // per layer
+  size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
+  // regressor offsets
+  size_t w1a = 0, b1 = 0, w1b = 0, w2 = 0, b2 = 0, wdec = 0, bdec = 0, init = 0;
+  SmplOff smpl{};
+  int maxdepth = 0;
+  // profiling of the dominant kernel (layer-0 input-projection GEMM)
+  bool prof = false;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  double prof_flops = 0.0;
+};
+
+namespace {
+
+constexpr size_t kAlignF = 64;   // 256-byte sections
+
+size_t take(size_t& cur, size_t n) {
+  const size_t o = cur;
+  cur = align_up(cur + n, kAlignF);
+  return o;
+}
+
+void layout(tepose_model* m) {
+  const size_t Hp = m->Hp, L = m->L;
+  size_t cur = 0;
+  m->wih0 = take(cur, (size_t)round_up(9 * (int)Hp, 128) * kInputP);
+  m->bih0 = take(cur, 9 * Hp);
+  m->fwd.assign(L, DirW());
+  m->rec_f.assign(L, DirW());
+  m->rec_r.assign(L, DirW());
+  for (size_t l = 0; l < L; ++l) {
+    const size_t n128 = round_up(3 * (int)Hp, 128);
+    if (l > 0) {
+      m->fwd[l].wih = take(cur, n128 * Hp);
+      m->fwd[l].bih = take(cur, 3 * Hp);
+      m->rec_f[l].wih = take(cur, n128 * 2 * Hp);
+      m->rec_f[l].bih = take(cur, 3 * Hp);
+      m->rec_r[l].wih = take(cur, n128 * 2 * Hp);
+      m->rec_r[l].bih = take(cur, 3 * Hp);
+    }
+    for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) {
+      d->whh = take(cur, 3 * Hp * Hp);
+      d->bhh = take(cur, 3 * Hp);
+    }
+  }
+  m->wlf = take(cur, (size_t)kFeat * Hp);
+  m->blf = take(cur, kFeat);
+  m->wlr = take(cur, (size_t)kFeat * 2 * Hp);
+  m->blr = take(cur, kFeat);
+  m->w1a = take(cur, 1024 * (size_t)kFeat);
+  m->b1 = take(cur, 1024);
+  m->w1b = take(cur, 1024 * (size_t)kState);
+  m->w2 = take(cur, 1024 * 1024);
+  m->b2 = take(cur, 1024);
+  m->wdec = take(cur, 256 * 1024);
+  m->bdec = take(cur, kState);
+  m->init = take(cur, kState);
+  m->smpl.J0 = take(cur, 72);
+  m->smpl.JS = take(cur, 720);
+  m->smpl.blendW = take(cur, (size_t)kBlendN * kBlendK);
+  m->smpl.lbsW = take(cur, (size_t)kNV * kNJ);
+  m->smpl.parents = take(cur, 32);
+  m->smpl.depth = take(cur, 32);
+  m->smpl.xr_ptr = take(cur, 16);
+  m->smpl.xr_idx = take(cur, (size_t)9 * kNV);
+  m->smpl.xr_val = take(cur, (size_t)9 * kNV);
+  m->blob_floats = cur;
+}
+
+#define CK(expr)                      \
+  do {                                \
+    hipError_t e__ = (expr);          \
+    if (e__ != hipSuccess) return (int)e__; \
+  } while (0)
+
+int pack(const float* src, long ld, int N, int K, float* dst, int Np, int Kp, int rowmap, int colmap,
+         int H, int Hp, hipStream_t s) {
+  PackArgs a{src, ld, N, K, dst, Np, Kp, rowmap, colmap, H, Hp};
+  return (int)launch_pack(a, s);
+}
+
+struct Carver {
+  char* base; size_t cur = 0, cap;
+  Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+  float* f(size_t n) {
+    const size_t o = cur;
+    cur = align_up(cur + n * sizeof(float), 256);
+    return base ? (float*)(base + o) : nullptr;
+  }
+};
+
+// Buffers of one encoder forward (shared between sizing and execution).
+struct EncWs {
+  float *xp, *g0, *g0c, *gf, *grr, *grf, *sf[2], *sr[2], *pf[2], *pr[2], *ytop, *y1;
+};
+
+void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
+  const size_t Hp = m->Hp, BT = (size_t)B * T;
+  const int L = m->L;
+  w.xp = c.f(BT * kInputP);
+  w.g0 = c.f(BT * (L >= 2 ? 9 : 6) * Hp);
+  w.g0c = c.f(L >= 2 ? 0 : (size_t)B * 3 * Hp);
+  w.gf = c.f(L >= 2 ? BT * 3 * Hp : 0);
+  w.grr = c.f(L >= 2 ? BT * 3 * Hp : 0);
+  w.grf = c.f(L >= 3 ? BT * 3 * Hp : (L == 2 ? (size_t)B * 3 * Hp : 0));
+  for (int i = 0; i < 2; ++i) {
+    const bool need = (i == 0 && L >= 2) || (i == 1 && L >= 3);
+    w.sf[i] = c.f(need ? BT * Hp : 0);
+    w.sr[i] = c.f(need ? BT * 2 * Hp : 0);
+    w.pf[i] = c.f((size_t)B * Hp);
+    w.pr[i] = c.f((size_t)B * Hp);
+  }
+  w.ytop = c.f((size_t)B * 2 * Hp);
+  w.y1 = c.f((size_t)B * kFeat);
+}
+
+struct RegWs {
+  float *base, *h1, *h2, *xs, *pf, *amat, *posed, *vposed;
+};
+
+void carve_regressor(int N, Carver& c, RegWs& w) {
+  w.base = c.f((size_t)N * 1024);
+  w.h1 = c.f((size_t)N * 1024);
+  w.h2 = c.f((size_t)N * 1024);
+  w.xs = c.f((size_t)N * kState);
+  w.pf = c.f((size_t)N * kBlendK);
+  w.amat = c.f((size_t)N * kNJ * 12);
+  w.posed = c.f((size_t)N * kNJ * 3);
+  w.vposed = c.f((size_t)N * kVertLd);
+}
+
+GemmArgs gemm(const float* A, long lda, const float* W, int Kp, float* C, long ldc, const float* bias,
+              int M, int N) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.Kp = Kp; g.C = C; g.ldc = ldc; g.bias = bias;
+  g.addend = nullptr; g.ldadd = 0; g.scale = 1.f; g.M = M; g.N = N; g.relu_a = 0;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tepose_version(void) { return TEPOSE_ABI_VERSION; }
+
+const char* tepose_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case TEPOSE_E_ARG: return "tepose: bad argument";
+    case TEPOSE_E_SHAPE: return "tepose: unsupported shape";
+    case TEPOSE_E_WORKSPACE: return "tepose: workspace too small";
+    case TEPOSE_E_STATE: return "tepose: model not packed";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "tepose: unknown error";
+  }
+}
+
+int tepose_create(int n_layers, int hidden, tepose_model** out) {
+  if (!out || n_layers < 1 || hidden < 1) return TEPOSE_E_ARG;
+  if (n_layers > 8 || hidden > 8192) return TEPOSE_E_SHAPE;
+  tepose_model* m = new (std::nothrow) tepose_model();
+  if (!m) return TEPOSE_E_ARG;
+  m->L = n_layers; m->H = hidden; m->Hp = round_up(hidden, 64);
+  layout(m);
+  *out = m;
+  return 0;
+}
+
+void tepose_destroy(tepose_model* m) {
+  if (!m) return;
+  for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+  delete m;
+}
+
+size_t tepose_packed_bytes(const tepose_model* m) { return m ? m->blob_floats * sizeof(float) : 0; }
+
+int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
+  if (!m || !blob) return TEPOSE_E_ARG;
+  if (bytes < m->blob_floats * sizeof(float)) return TEPOSE_E_WORKSPACE;
+  m->blob = (float*)blob;
+  return 0;
+}
+
+int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* stream) {
+  if (!m || !w) return TEPOSE_E_ARG;
+  if (!m->blob) return TEPOSE_E_STATE;
+  const int L = m->L, H = m->H, Hp = m->Hp;
+  if (n_w != 12 * L + 4) return TEPOSE_E_ARG;
+  for (int i = 0; i < n_w; ++i)
+    if (!w[i]) return TEPOSE_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* B = m->blob;
+  // zero the stacked layer-0 block first (rows beyond 9Hp up to the 128 multiple)
+  CK(launch_fill(B + m->wih0, (size_t)round_up(9 * Hp, 128) * kInputP, 0.f, s));
+  auto fwd_w = [&](int l, int k) { return w[4 * l + k]; };                       // ih, hh, bih, bhh
+  auto rec_w = [&](int l, int rev, int k) { return w[4 * L + 8 * l + 4 * rev + k]; };
+  const int n128 = round_up(3 * Hp, 128);
+  // layer 0 input projections, stacked [fwd | rec_reverse | rec]
+  const float* l0[3] = {fwd_w(0, 0), rec_w(0, 1, 0), rec_w(0, 0, 0)};
+  const float* l0b[3] = {fwd_w(0, 2), rec_w(0, 1, 2), rec_w(0, 0, 2)};
+  for (int d = 0; d < 3; ++d) {
+    CK((hipError_t)pack(l0[d], kInput, 3 * H, kInput, B + m->wih0 + (size_t)d * 3 * Hp * kInputP, 3 * Hp,
+                        kInputP, ROW_GATES, COL_PLAIN, H, Hp, s));
+    CK((hipError_t)pack(l0b[d], 1, 3 * H, 1, B + m->bih0 + (size_t)d * 3 * Hp, 3 * Hp, 1, ROW_GATES,
+                        COL_PLAIN, H, Hp, s));
+  }
+  for (int l = 0; l < L; ++l) {
+    struct { DirW* d; const float *ih, *hh, *bih, *bhh; bool split; } dirs[3] = {
+        {&m->fwd[l], fwd_w(l, 0), fwd_w(l, 1), fwd_w(l, 2), fwd_w(l, 3), false},
+        {&m->rec_f[l], rec_w(l, 0, 0), rec_w(l, 0, 1), rec_w(l, 0, 2), rec_w(l, 0, 3), true},
+        {&m->rec_r[l], rec_w(l, 1, 0), rec_w(l, 1, 1), rec_w(l, 1, 2), rec_w(l, 1, 3), true}};
+    for (auto& d : dirs) {
+      if (l > 0) {
+        const int K = d.split ? 2 * H : H, Kp = d.split ? 2 * Hp : Hp;
+        CK((hipError_t)pack(d.ih, K, 3 * H, K, B + d.d->wih, n128, Kp, ROW_GATES,
+                            d.split ? COL_SPLIT2 : COL_PLAIN, H, Hp, s));
+        CK((hipError_t)pack(d.bih, 1, 3 * H, 1, B + d.d->bih, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+      }
+      CK((hipError_t)pack(d.hh, H, 3 * H, H, B + d.d->whh, 3 * Hp, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
+      CK((hipError_t)pack(d.bhh, 1, 3 * H, 1, B + d.d->bhh, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+    }
+  }
+  const float* const* t = w + 12 * L;
+  CK((hipError_t)pack(t[0], H, kFeat, H, B + m->wlf, kFeat, Hp, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  CK((hipError_t)pack(t[1], 1, kFeat, 1, B + m->blf, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  CK((hipError_t)pack(t[2], 2 * H, kFeat, 2 * H, B + m->wlr, kFeat, 2 * Hp, ROW_PLAIN, COL_SPLIT2, H, Hp, s));
+  CK((hipError_t)pack(t[3], 1, kFeat, 1, B + m->blr, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  m->enc_packed = true;
+  return 0;
+}
+
+int tepose_pack_regressor(tepose_model* m, const float* const* w, int n_w, void* stream) {
+  if (!m || !w || n_w != 13) return TEPOSE_E_ARG;
+  if (!m->blob) return TEPOSE_E_STATE;
+  for (int i = 0; i < n_w; ++i)
+    if (!w[i]) return TEPOSE_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* B = m->blob;
+  const int ld1 = kFeat + kNPose + 13;   // 2205
+  CK((hipError_t)pack(w[0], ld1, 1024, kFeat, B + m->w1a, 1024, kFeat, 0, 0, 0, 1, s));
+  CK((hipError_t)pack(w[1], 1, 1024, 1, B + m->b1, 1024, 1, 0, 0, 0, 1, s));
+  CK((hipError_t)pack(w[0] + kFeat, ld1, 1024, 157, B + m->w1b, 1024, kState, 0, 0, 0, 1, s));
+  CK((hipError_t)pack(w[2], 1024, 1024, 1024, B + m->w2, 1024, 1024, 0, 0, 0, 1, s));
+  CK((hipError_t)pack(w[3], 1, 1024, 1, B + m->b2, 1024, 1, 0, 0, 0, 1, s));
+  // decoders stacked: rows 0..143 decpose, 144..153 decshape, 154..156 deccam, rest zero
+  CK(launch_fill(B + m->wdec, 256 * 1024, 0.f, s));
+  CK(launch_fill(B + m->bdec, kState, 0.f, s));
+  CK(launch_fill(B + m->init, kState, 0.f, s));
+  const int rows[3] = {kNPose, 10, 3}, off[3] = {0, kNPose, kNPose + 10};
+  for (int i = 0; i < 3; ++i) {
+    CK((hipError_t)pack(w[4 + 2 * i], 1024, rows[i], 1024, B + m->wdec + (size_t)off[i] * 1024, rows[i], 1024,
+                        0, 0, 0, 1, s));
+    CK((hipError_t)pack(w[5 + 2 * i], 1, rows[i], 1, B + m->bdec + off[i], rows[i], 1, 0, 0, 0, 1, s));
+    CK((hipError_t)pack(w[10 + i], 1, rows[i], 1, B + m->init + off[i], rows[i], 1, 0, 0, 0, 1, s));
+  }
+  m->reg_packed = true;
+  return 0;
+}
+
+int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shapedirs,
+                     const float* posedirs, const float* J_regressor, const float* lbs_weights,
+                     const float* J_regressor_extra, const int32_t* parents_host, void* stream) {
+  if (!m || !v_template || !shapedirs || !posedirs || !J_regressor || !lbs_weights ||
+      !J_regressor_extra || !parents_host)
+    return TEPOSE_E_ARG;
+  if (!m->blob) return TEPOSE_E_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  float* B = m->blob;
+  int par[kNJ], dep[kNJ], maxd = 0;
+  for (int j = 0; j < kNJ; ++j) {
+    par[j] = parents_host[j];
+    if (j == 0) { dep[j] = 0; par[j] = -1; continue; }
+    if (par[j] < 0 || par[j] >= j) return TEPOSE_E_ARG;   // parents must precede children
+    dep[j] = dep[par[j]] + 1;
+    if (dep[j] > maxd) maxd = dep[j];
+  }
+  m->maxdepth = maxd;
+  CK(hipMemcpyAsync(B + m->smpl.parents, par, sizeof(par), hipMemcpyHostToDevice, s));
+  CK(hipMemcpyAsync(B + m->smpl.depth, dep, sizeof(dep), hipMemcpyHostToDevice, s));
+  CK(hipStreamSynchronize(s));   // par/dep are stack arrays (pack time only, never on the forward path)
+  CK(launch_smpl_consts(v_template, shapedirs, posedirs, J_regressor, B + m->smpl.J0, B + m->smpl.JS,
+                        B + m->smpl.blendW, s));
+  CK((hipError_t)pack(lbs_weights, kNJ, kNV, kNJ, B + m->smpl.lbsW, kNV, kNJ, 0, 0, 0, 1, s));
+  CK(launch_csr_build(J_regressor_extra, 9, kNV, (int*)(B + m->smpl.xr_ptr), (int*)(B + m->smpl.xr_idx),
+                      B + m->smpl.xr_val, 9 * kNV, s));
+  m->smpl_packed = true;
+  return 0;
+}
+
+size_t tepose_jreg_packed_bytes(void) { return (32 + (size_t)17 * kNV * 2) * 4; }
+
+int tepose_pack_jreg(const float* J, void* packed, void* stream) {
+  if (!J || !packed) return TEPOSE_E_ARG;
+  int* p = (int*)packed;
+  CK(launch_csr_build(J, 17, kNV, p, p + 32, (float*)(p + 32 + 17 * kNV), 17 * kNV, (hipStream_t)stream));
+  return 0;
+}
+
+size_t tepose_workspace_bytes(const tepose_model* m, int B, int T) {
+  if (!m || B < 1 || T < 1) return 0;
+  Carver c(nullptr, 0);
+  EncWs e;
+  carve_encoder(m, B, T, c, e);
+  RegWs r;
+  c.f((size_t)B * 2 * kFeat);          // feature buffer of tepose_forward
+  carve_regressor(2 * B, c, r);        // is_train regresses 2 rows per window
+  return c.cur + 256;
+}
+
+int tepose_profile_enable(tepose_model* m, int on) {
+  if (!m) return TEPOSE_E_ARG;
+  m->prof = on != 0;
+  m->ev_used = 0;
+  m->prof_flops = 0.0;
+  return 0;
+}
+
+int tepose_profile_read(tepose_model* m, double* total_ms, int* n_launches, double* flops_per_launch) {
+  if (!m || !total_ms || !n_launches || !flops_per_launch) return TEPOSE_E_ARG;
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
+    CK(hipEventSynchronize(m->ev[i + 1]));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *n_launches = (int)(m->ev_used / 2);
+  *flops_per_launch = m->prof_flops;
+  m->ev_used = 0;
+  return 0;
+}
+
+int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
+                       void* workspace, size_t ws_bytes, void* stream) {
+  if (!m || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
+  if (!m->enc_packed) return TEPOSE_E_STATE;
+  if ((size_t)B * T > (1u << 30) / 4) return TEPOSE_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(workspace, ws_bytes);
+  EncWs w;
+  carve_encoder(m, B, T, c, w);
+  if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
+  const int L = m->L, Hp = m->Hp;
+  const float* Bl = m->blob;
+  const long BT = (long)B * T;
+  const int H3 = 3 * Hp;
+
+  CK(launch_pad_input(x, w.xp, BT, s));
+  // ---- layer-0 input projections: one GEMM for every direction that runs all T steps --------
+  const int ld0 = (L >= 2 ? 9 : 6) * Hp;
+  {
+    GemmArgs g = gemm(w.xp, kInputP, Bl + m->wih0, kInputP, w.g0, ld0, Bl + m->bih0, (int)BT, ld0);
+    tepose_model* mm = const_cast<tepose_model*>(m);
+    if (m->prof) {
+      if (mm->ev.size() < mm->ev_used + 2) {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+        mm->ev.push_back(a);
+        mm->ev.push_back(b);
+      }
+      CK(hipEventRecord(mm->ev[mm->ev_used], s));
+    }
+    CK(launch_gemm(g, s));
+    if (m->prof) {
+      CK(hipEventRecord(mm->ev[mm->ev_used + 1], s));
+      mm->ev_used += 2;
+      mm->prof_flops = 2.0 * (double)BT * (double)(L >= 2 ? 9 : 6) * m->H * kInput;
+    }
+  }
+  if (L == 1) {  // rec.l0 forward direction: only flipped index 0 (= frame T-1) is consumed
+    GemmArgs g = gemm(w.xp + (long)(T - 1) * kInputP, (long)T * kInputP, Bl + m->wih0 + (size_t)6 * Hp * kInputP,
+                      kInputP, w.g0c, H3, Bl + m->bih0 + 6 * Hp, B, H3);
+    CK(launch_gemm(g, s));
+  }
+
+  for (int l = 0; l < L; ++l) {
+    const bool top = l == L - 1;
+    float* sf = w.sf[l & 1];
+    float* sr = w.sr[l & 1];
+    const float *gf, *grr, *grf;     // gate pre-activation sources of this layer
+    long ldg, stepg_f, stepg_r;      // row stride; per-step offsets are computed below
+    if (l == 0) {
+      gf = w.g0; grr = w.g0 + H3; grf = L >= 2 ? w.g0 + 2 * H3 : w.g0c;
+      ldg = (long)T * ld0;
+    } else {
+      const float* inf = w.sf[(l - 1) & 1];
+      const float* inr = w.sr[(l - 1) & 1];
+      GemmArgs g1 = gemm(inf, Hp, Bl + m->fwd[l].wih, Hp, w.gf, H3, Bl + m->fwd[l].bih, (int)BT, H3);
+      CK(launch_gemm(g1, s));
+      GemmArgs g2 = gemm(inr, 2 * Hp, Bl + m->rec_r[l].wih, 2 * Hp, w.grr, H3, Bl + m->rec_r[l].bih, (int)BT, H3);
+      CK(launch_gemm(g2, s));
+      GemmArgs g3 = gemm(inr, 2 * Hp, Bl + m->rec_f[l].wih, 2 * Hp, w.grf, H3, Bl + m->rec_f[l].bih,
+                         top ? B : (int)BT, H3);
+      CK(launch_gemm(g3, s));
+      gf = w.gf; grr = w.grr; grf = w.grf;
+      ldg = H3;
+    }
+    (void)stepg_f; (void)stepg_r;
+    // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
+    auto goff = [&](int q) -> long { return l == 0 ? (long)q * ld0 : (long)q * B * H3; };
+
+    for (int st = 0; st < T; ++st) {
+      GruArgs a{};
+      a.M = B; a.Hp = Hp; a.first = st == 0;
+      int nd = 0;
+      {  // gru_fwd layer l, frame t = st
+        GruDir& d = a.d[nd++];
+        d.Whh = Bl + m->fwd[l].whh; d.bhh = Bl + m->fwd[l].bhh;
+        d.gi = gf + goff(st); d.ldgi = ldg;
+        if (!top) {
+          d.hprev = sf + (long)(st - 1) * B * Hp; d.ldh = Hp;
+          d.hout = sf + (long)st * B * Hp; d.ldo = Hp;
+        } else {
+          d.hprev = w.pf[(st + 1) & 1]; d.ldh = Hp;
+          d.hout = w.pf[st & 1]; d.ldo = Hp;
+        }
+      }
+      {  // gru_rec layer l, reverse direction: flipped index i = T-1-st (frame st for layer 0)
+        GruDir& d = a.d[nd++];
+        const int i = T - 1 - st;
+        d.Whh = Bl + m->rec_r[l].whh; d.bhh = Bl + m->rec_r[l].bhh;
+        d.gi = grr + goff(l == 0 ? st : i); d.ldgi = ldg;
+        if (!top) {
+          d.hprev = sr + (long)(i + 1) * B * 2 * Hp + Hp; d.ldh = 2 * Hp;
+          d.hout = sr + (long)i * B * 2 * Hp + Hp; d.ldo = 2 * Hp;
+        } else {
+          d.hprev = w.pr[(st + 1) & 1]; d.ldh = Hp;
+          if (st == T - 1) { d.hout = w.ytop + Hp; d.ldo = 2 * Hp; }
+          else { d.hout = w.pr[st & 1]; d.ldo = Hp; }
+        }
+      }
+      if (!top) {  // gru_rec layer l, forward direction: flipped index i = st (frame T-1-st)
+        GruDir& d = a.d[nd++];
+        d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
+        d.gi = grf + goff(l == 0 ? T - 1 - st : st); d.ldgi = ldg;
+        d.hprev = sr + (long)(st - 1) * B * 2 * Hp; d.ldh = 2 * Hp;
+        d.hout = sr + (long)st * B * 2 * Hp; d.ldo = 2 * Hp;
+      }
+      a.ndir = nd;
+      CK(launch_gru_step(a, s));
+    }
+    if (top) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
+      GruArgs a{};
+      a.M = B; a.Hp = Hp; a.first = 1; a.ndir = 1;
+      GruDir& d = a.d[0];
+      d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
+      if (l == 0) { d.gi = w.g0c; d.ldgi = H3; }
+      else { d.gi = grf; d.ldgi = H3; }
+      d.hprev = w.ytop; d.ldh = 2 * Hp;
+      d.hout = w.ytop; d.ldo = 2 * Hp;
+      CK(launch_gru_step(a, s));
+    }
+  }
+  // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
+  const float* hlast = w.pf[(T - 1) & 1];
+  if (!is_train) {
+    GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, w.y1, kFeat, Bl + m->blf, B, kFeat);
+    g1.relu_a = 1;
+    CK(launch_gemm(g1, s));
+    GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat, kFeat, Bl + m->blr, B, kFeat);
+    g2.relu_a = 1; g2.addend = w.y1; g2.ldadd = kFeat; g2.scale = 0.5f;
+    CK(launch_gemm(g2, s));
+  } else {
+    GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat);
+    g1.relu_a = 1;
+    CK(launch_gemm(g1, s));
+    GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat + kFeat, 2 * kFeat, Bl + m->blr, B, kFeat);
+    g2.relu_a = 1;
+    CK(launch_gemm(g2, s));
+  }
+  return 0;
+}
+
+int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter, const void* jreg_packed,
+                         float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
+                         void* workspace, size_t ws_bytes, void* stream) {
+  if (!m || !feat || !theta || !verts || !kp_3d || !kp_2d || !rotmat || !workspace || N < 1 || n_iter < 0)
+    return TEPOSE_E_ARG;
+  if (!m->reg_packed || !m->smpl_packed) return TEPOSE_E_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(workspace, ws_bytes);
+  RegWs w;
+  carve_regressor(N, c, w);
+  if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
+  const float* Bl = m->blob;
+  // xc = cat[x, pose, shape, cam]; fc1(xc) = x W1a^T + b1 (iteration-invariant) + state W1b^T
+  GemmArgs gb = gemm(feat, kFeat, Bl + m->w1a, kFeat, w.base, 1024, Bl + m->b1, N, 1024);
+  CK(launch_gemm(gb, s));
+  CK(launch_init_state(Bl + m->init, w.xs, N, s));
+  for (int it = 0; it < n_iter; ++it) {
+    GemmArgs g1 = gemm(w.xs, kState, Bl + m->w1b, kState, w.h1, 1024, nullptr, N, 1024);
+    g1.addend = w.base; g1.ldadd = 1024;
+    CK(launch_gemm(g1, s));
+    GemmArgs g2 = gemm(w.h1, 1024, Bl + m->w2, 1024, w.h2, 1024, Bl + m->b2, N, 1024);
+    CK(launch_gemm(g2, s));
+    GemmArgs g3 = gemm(w.h2, 1024, Bl + m->wdec, 1024, w.xs, kState, Bl + m->bdec, N, kState);
+    g3.addend = w.xs; g3.ldadd = kState;
+    CK(launch_gemm(g3, s));
+  }
+  SmplConsts sc{};
+  sc.J0 = Bl + m->smpl.J0; sc.JS = Bl + m->smpl.JS; sc.blendW = Bl + m->smpl.blendW;
+  sc.lbsW = Bl + m->smpl.lbsW; sc.parents = (const int*)(Bl + m->smpl.parents);
+  sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
+  sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
+  sc.xr_val = Bl + m->smpl.xr_val;
+  CK(launch_smpl_prep(sc, w.xs, N, w.pf, w.amat, w.posed, rotmat, theta, s));
+  // v_posed = v_template + shapedirs beta + posedirs^T pose_feature as one GEMM, K = 224
+  GemmArgs gv = gemm(w.pf, kBlendK, sc.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
+  CK(launch_gemm(gv, s));
+  CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
+  JregPacked jr{};
+  if (jreg_packed) {
+    const int* p = (const int*)jreg_packed;
+    jr.ptr = p; jr.idx = p + 32; jr.val = (const float*)(p + 32 + 17 * kNV);
+  }
+  CK(launch_smpl_joints(sc, jreg_packed ? &jr : nullptr, verts, w.posed, w.xs, N, kp_3d, kp_2d, s));
+  return 0;
+}
+
+int tepose_forward(const tepose_model* m, const float* x, int B, int T, const void* jreg_packed, float* theta,
+                   float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
+                   void* stream) {
+  if (!m || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
+  if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
+  // [feature | shared scratch]: the encoder's scratch is dead once `feat` exists
+  float* feat = (float*)workspace;
+  char* rest = (char*)workspace + align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
+  const size_t rest_bytes = ws_bytes - (size_t)(rest - (char*)workspace);
+  int rc = tepose_encoder_fwd(m, x, B, T, 0, feat, rest, rest_bytes, stream);
+  if (rc) return rc;
+  return tepose_regressor_fwd(m, feat, B, 3, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest, rest_bytes,
+                              stream);
+}
+
+size_t tepose_gemm_workspace_bytes(int N, int K) {
+  if (N < 1 || K < 1) return 0;
+  return (size_t)round_up(N, 128) * round_up(K, 32) * sizeof(float) + 256;
+}
+
+int tepose_gemm_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
+                    int M, int N, int K, int relu_a, void* workspace, size_t ws_bytes, void* stream) {
+  if (!A || !W || !C || !workspace || M < 1 || N < 1 || K < 1) return TEPOSE_E_ARG;
+  if (lda % 4 != 0 || ((uintptr_t)A & 15) != 0 || K % 32 != 0) return TEPOSE_E_SHAPE;
+  if (ws_bytes < tepose_gemm_workspace_bytes(N, K)) return TEPOSE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* wp = (float*)workspace;
+  CK((hipError_t)pack(W, ldw, N, K, wp, round_up(N, 128), K, 0, 0, 0, 1, s));
+  GemmArgs g = gemm(A, lda, wp, K, C, ldc, bias, M, N);
+  g.relu_a = relu_a;
+  CK(launch_gemm(g, s));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Internal declarations shared by the HIP translation units of libtepose_hip.so.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, fp32-input MFMA, LDS-DMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tepose {
+
+constexpr int kFeat = 2048;
+constexpr int kTheta = 85;
+constexpr int kInput = 2133;
+constexpr int kInputP = 2144;   // 2133 padded to a multiple of the GEMM K-tile (32)
+constexpr int kNV = 6890;
+constexpr int kNJ = 24;
+constexpr int kNPose = 144;
+constexpr int kState = 160;     // regressor state row: pose6d(144) | shape(10) | cam(3) | pad(3)
+constexpr int kBlendK = 224;    // [1 | betas(10) | pose_feature(207) | pad(6)]
+constexpr int kBlendN = 20736;  // 3*6890 = 20670 padded to a multiple of 128
+constexpr int kVertLd = 20672;  // row stride of the v_posed scratch (>= 20670, multiple of 4)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C[M,N] = epi( A[M,Kp] * W[Np,Kp]^T ), fp32 operands, fp32 MFMA accumulate.
+struct GemmArgs {
+  const float* A; long lda;      // rows 16-byte aligned, K zero-padded to Kp by the producer
+  const float* W; int Kp;        // packed [Np][Kp], Np multiple of 128, Kp multiple of 32
+  float* C; long ldc;
+  const float* bias;             // [N] or nullptr
+  const float* addend; long ldadd;  // [M,N] or nullptr
+  float scale;                   // applied last
+  int M, N;
+  int relu_a;                    // apply max(0,.) to A on the fly
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// One GRU cell step for up to 3 independent directions in one launch:
+//   gh = hprev * Whh^T ; r,z,n gate math ; hout = (1-z)*n + z*hprev      (torch.nn.GRU)
+struct GruDir {
+  const float* hprev; long ldh;  // [M][Hp]; ignored when first
+  const float* Whh;              // packed, gate-interleaved tiles (see pack_whh_kernel)
+  const float* bhh;              // [3*Hp], natural order g*Hp + j
+  const float* gi; long ldgi;    // gi[row*ldgi + g*Hp + j] = x W_ih^T + b_ih
+  float* hout; long ldo;
+};
+struct GruArgs {
+  GruDir d[3];
+  int ndir;
+  int M, Hp;
+  int first;                     // h_{-1} = 0: skip the matmul
+};
+hipError_t launch_gru_step(const GruArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- misc.hip
+// dst[np][kp] (row-major [Np][Kp]) = src[rowmap(np)][colmap(kp)] or 0.
+enum RowMap { ROW_PLAIN = 0, ROW_GATES = 1, ROW_GATES_TILED = 2 };
+enum ColMap { COL_PLAIN = 0, COL_SPLIT2 = 1 };
+struct PackArgs {
+  const float* src; long ld_src; int N, K;   // logical source [N][K] (col offset folded into src)
+  float* dst; int Np, Kp;
+  int rowmap, colmap;
+  int H, Hp;                                  // for the gate / split maps
+};
+hipError_t launch_pack(const PackArgs& a, hipStream_t s);
+hipError_t launch_pad_input(const float* x, float* xp, long rows, hipStream_t s);
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s);
+
+// ---------------------------------------------------------------- smpl.hip
+struct SmplConsts {              // device pointers into the packed blob
+  const float* J0;               // [24][3]      J_regressor * v_template
+  const float* JS;               // [24][3][10]  J_regressor * shapedirs
+  const float* blendW;           // [kBlendN][kBlendK]  rows (v,c): [v_template | shapedirs | posedirs^T]
+  const float* lbsW;             // [6890][24]
+  const int* parents;            // [24]
+  const int* depth;              // [24]
+  int maxdepth;                  // deepest level of the tree (host-computed)
+  const int* xr_ptr;             // CSR of J_regressor_extra: [10]
+  const int* xr_idx;             // [nnz]
+  const float* xr_val;
+};
+struct JregPacked {              // CSR of the optional 17-row evaluation regressor
+  const int* ptr; const int* idx; const float* val;
+};
+hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
+                            float* posed, float* rotmat, float* theta, hipStream_t s);
+hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
+                            float* verts, hipStream_t s);
+hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const float* verts,
+                              const float* posed, const float* xs, int N, float* kp3d,
+                              float* kp2d, hipStream_t s);
+// CSR build (device): counts then fill, rows x cols dense -> ptr/idx/val
+hipError_t launch_csr_build(const float* dense, int rows, int cols, int* ptr, int* idx, float* val,
+                            int cap, hipStream_t s);
+hipError_t launch_smpl_consts(const float* v_template, const float* shapedirs, const float* posedirs,
+                              const float* J_regressor, float* J0, float* JS, float* blendW,
+                              hipStream_t s);
+
+}  // namespace tepose

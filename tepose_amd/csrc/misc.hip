@@ -1,0 +1,100 @@
+// Weight packing, input padding and small fills.  All HBM-bound element-wise kernels:
+// one dword per lane, consecutive lanes on consecutive addresses, grid-stride loops.
+#include "common.h"
+
+namespace tepose {
+
+// dst[np][kp] = src[rowmap(np)][colmap(kp)] or 0 (see RowMap / ColMap in common.h).
+//   ROW_GATES        np = g*Hp + j                      -> source row g*H + j
+//   ROW_GATES_TILED  np = jt*192 + wn*96 + g*32 + jj    -> j = jt*64 + wn*32 + jj, row g*H + j
+//                    (the order gru_step_kernel's waves consume W_hh in)
+//   COL_SPLIT2       kp < Hp -> k = kp ; else k = H + (kp - Hp)   (bi-GRU concat input)
+__global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
+  const long total = (long)a.Np * a.Kp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int np = (int)(idx / a.Kp), kp = (int)(idx - (long)np * a.Kp);
+    int n = -1, k = -1;
+    if (a.rowmap == ROW_PLAIN) {
+      if (np < a.N) n = np;
+    } else if (a.rowmap == ROW_GATES) {
+      const int g = np / a.Hp, j = np - g * a.Hp;
+      if (g < 3 && j < a.H) n = g * a.H + j;
+    } else {
+      const int jt = np / 192, rem = np - jt * 192;
+      const int wn = rem / 96, g = (rem % 96) / 32, jj = rem & 31;
+      const int j = jt * 64 + wn * 32 + jj;
+      if (j < a.H) n = g * a.H + j;
+    }
+    if (a.colmap == COL_PLAIN) {
+      if (kp < a.K) k = kp;
+    } else {
+      if (kp < a.Hp) {
+        if (kp < a.H) k = kp;
+      } else if (kp - a.Hp < a.H) {
+        k = a.H + (kp - a.Hp);
+      }
+    }
+    a.dst[idx] = (n >= 0 && k >= 0) ? a.src[(long)n * a.ld_src + k] : 0.f;
+  }
+}
+
+hipError_t launch_pack(const PackArgs& a, hipStream_t s) {
+  const long total = (long)a.Np * a.Kp;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// x[rows][2133] (rows only 4-byte aligned) -> xp[rows][2144], pad columns zero, so the
+// GEMM's 16-byte LDS-DMA can read it.
+__global__ void __launch_bounds__(256) pad_input_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ xp, long rows) {
+  const long total = rows * kInputP;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / kInputP;
+    const int k = (int)(idx - row * kInputP);
+    xp[idx] = k < kInput ? x[row * kInput + k] : 0.f;
+  }
+}
+
+hipError_t launch_pad_input(const float* x, float* xp, long rows, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  const long total = rows * kInputP;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pad_input_kernel, dim3(blocks), dim3(256), 0, s, x, xp, rows);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* p, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
+  return hipGetLastError();
+}
+
+// xs[n][0..159] = init160 (init_pose | init_shape | init_cam | 0 0 0), spin.py:243-248
+__global__ void __launch_bounds__(256) init_state_kernel(const float* __restrict__ init160,
+                                                         float* __restrict__ xs, long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x)
+    xs[idx] = init160[idx % kState];
+}
+
+hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s) {
+  const long total = (long)N * kState;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init160, xs, total);
+  return hipGetLastError();
+}
+
+}  // namespace tepose

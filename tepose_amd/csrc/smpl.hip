@@ -1,0 +1,369 @@
+// SMPL forward for N persons: rot6d -> R, R -> axis-angle, 24-joint kinematic chain, pose
+// feature, linear blend skinning, joint regression, projection.
+//
+// Reference: lib/utils/geometry.py:330-344 (rot6d), :68-233 (R -> aa);
+// lib/models/smpl.py:72-84 + smplx.lbs (LBS); lib/models/spin.py:275-280,
+// :307-351 (eval joint regressor, projection).
+//
+// Split (round 1): prep (one wave per person) -> blend-shape GEMM on the MFMA kernel
+// ([N,224] x [224,20670], the only FLOP-heavy part) -> skin (thread per vertex, W row in
+// registers, persons looped, A matrices read through the scalar cache) -> joints (block per
+// person, sparse regressors in CSR).
+#include "common.h"
+
+namespace tepose {
+
+__device__ const int kJointMap49[49] = {24, 12, 17, 19, 21, 16, 18, 20, 0,  2,  5,  8,  1,  4,  7,  25, 26,
+                                        27, 28, 29, 30, 31, 32, 33, 34, 8,  5,  45, 46, 4,  7,  21, 19, 17,
+                                        16, 18, 20, 47, 48, 49, 50, 51, 52, 53, 24, 26, 25, 28, 27};
+__device__ const int kH36mToJ14[14] = {6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10};
+__device__ const int kExtraVerts[21] = {332,  6260, 2800, 4071, 583,  3216, 3226, 3387, 6617, 6624, 6787,
+                                        2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133};
+
+// ------------------------------------------------------------------ pack-time constants
+// J0 = J_regressor * v_template, JS = J_regressor * shapedirs (fp64 accumulate), so the rest
+// joints are J0 + JS * beta instead of a 6890-long reduction per person.
+__global__ void __launch_bounds__(256) smpl_joint_consts_kernel(const float* __restrict__ vt,
+                                                                const float* __restrict__ sd,
+                                                                const float* __restrict__ jr,
+                                                                float* J0, float* JS) {
+  // blockIdx.x = (j*3 + c)*11 + l, l = 0 -> template, l = 1..10 -> shapedir l-1
+  const int l = blockIdx.x % 11, jc = blockIdx.x / 11, c = jc % 3, j = jc / 3;
+  double acc = 0.0;
+  for (int v = threadIdx.x; v < kNV; v += 256) {
+    const double w = jr[(long)j * kNV + v];
+    const double x = l == 0 ? vt[v * 3 + c] : sd[((long)v * 3 + c) * 10 + (l - 1)];
+    acc += w * x;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (l == 0) J0[j * 3 + c] = (float)red[0];
+    else JS[(j * 3 + c) * 10 + (l - 1)] = (float)red[0];
+  }
+}
+
+// blendW[n = 3v+c][k]: k=0 v_template, k=1..10 shapedirs, k=11..217 posedirs[k-11][n]
+__global__ void __launch_bounds__(256) smpl_blendw_kernel(const float* __restrict__ vt,
+                                                          const float* __restrict__ sd,
+                                                          const float* __restrict__ pd, float* bw) {
+  const long total = (long)kBlendN * kBlendK;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int n = (int)(idx / kBlendK), k = (int)(idx % kBlendK);
+    float v = 0.f;
+    if (n < 3 * kNV) {
+      if (k == 0) v = vt[n];
+      else if (k <= 10) v = sd[(long)n * 10 + (k - 1)];
+      else if (k < 218) v = pd[(long)(k - 11) * (3 * kNV) + n];
+    }
+    bw[idx] = v;
+  }
+}
+
+hipError_t launch_smpl_consts(const float* vt, const float* sd, const float* pd, const float* jr,
+                              float* J0, float* JS, float* blendW, hipStream_t s) {
+  hipLaunchKernelGGL(smpl_joint_consts_kernel, dim3(24 * 3 * 11), dim3(256), 0, s, vt, sd, jr, J0, JS);
+  hipLaunchKernelGGL(smpl_blendw_kernel, dim3(4096), dim3(256), 0, s, vt, sd, pd, blendW);
+  return hipGetLastError();
+}
+
+// Dense [rows][cols] -> CSR (ptr[rows+1], idx, val), column order kept.  One block per row.
+__global__ void __launch_bounds__(256) csr_build_kernel(const float* __restrict__ dense, int rows,
+                                                        int cols, int* ptr, int* idx, float* val,
+                                                        int cap) {
+  __shared__ int wsum[4];
+  __shared__ int base_sh;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // offset of this row = non-zeros of all previous rows
+  int cnt = 0;
+  for (long i = tid; i < (long)row * cols; i += 256) cnt += dense[i] != 0.f;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  if (lane == 0) wsum[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) base_sh = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  int base = base_sh;
+  if (tid == 0) ptr[row] = base;
+  for (int c0 = 0; c0 < cols; c0 += 256) {
+    const int c = c0 + tid;
+    const float v = c < cols ? dense[(long)row * cols + c] : 0.f;
+    const bool nz = v != 0.f;
+    const unsigned long long m = __ballot(nz);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base + before;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (nz && off < cap) { idx[off] = c; val[off] = v; }
+    base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  if (row == rows - 1 && tid == 0) ptr[rows] = base;
+}
+
+hipError_t launch_csr_build(const float* dense, int rows, int cols, int* ptr, int* idx, float* val,
+                            int cap, hipStream_t s) {
+  hipLaunchKernelGGL(csr_build_kernel, dim3(rows), dim3(256), 0, s, dense, rows, cols, ptr, idx, val, cap);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ per-person prep
+// geometry.py:191-233 on M = R^T, then :118-157.
+__device__ __forceinline__ void rotmat_to_aa(const float R[3][3], float aa[3]) {
+  const float m00 = R[0][0], m01 = R[1][0], m02 = R[2][0];
+  const float m10 = R[0][1], m11 = R[1][1], m12 = R[2][1];
+  const float m20 = R[0][2], m21 = R[1][2], m22 = R[2][2];
+  const bool d2 = m22 < 1e-6f, d01 = m00 > m11, d0n1 = m00 < -m11;
+  float w, x, y, z, t;
+  if (d2 && d01) {
+    t = 1.f + m00 - m11 - m22; w = m12 - m21; x = t; y = m01 + m10; z = m20 + m02;
+  } else if (d2) {
+    t = 1.f - m00 + m11 - m22; w = m20 - m02; x = m01 + m10; y = t; z = m12 + m21;
+  } else if (d0n1) {
+    t = 1.f - m00 - m11 + m22; w = m01 - m10; x = m20 + m02; y = m12 + m21; z = t;
+  } else {
+    t = 1.f + m00 + m11 + m22; w = t; x = m12 - m21; y = m20 - m02; z = m01 - m10;
+  }
+  const float st = sqrtf(t);
+  w = (w / st) * 0.5f; x = (x / st) * 0.5f; y = (y / st) * 0.5f; z = (z / st) * 0.5f;
+  const float s2 = x * x + y * y + z * z;
+  const float sn = sqrtf(s2);
+  const float two_theta = 2.f * (w < 0.f ? atan2f(-sn, -w) : atan2f(sn, w));
+  const float k = s2 > 0.f ? two_theta / sn : 2.f;
+  aa[0] = x * k; aa[1] = y * k; aa[2] = z * k;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (aa[i] != aa[i]) aa[i] = 0.f;
+}
+
+// One wave per person, lane = joint (24 active).  xs row = [pose6d 144 | betas 10 | cam 3 | 0 0 0].
+__global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth,
+                                                        const float* __restrict__ xs, int N,
+                                                        float* __restrict__ pf, float* __restrict__ Amat,
+                                                        float* __restrict__ posed,
+                                                        float* __restrict__ rotmat,
+                                                        float* __restrict__ theta) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= N) return;                       // wave-uniform
+  const float* x = xs + (long)p * kState;
+  const int j = lane < kNJ ? lane : 0;
+  const bool act = lane < kNJ;
+  // rot6d_to_rotmat: a1 = x[0::2], a2 = x[1::2]
+  const float a1[3] = {x[6 * j + 0], x[6 * j + 2], x[6 * j + 4]};
+  const float a2[3] = {x[6 * j + 1], x[6 * j + 3], x[6 * j + 5]};
+  const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-6f);
+  const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+  const float dp = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  const float u[3] = {a2[0] - dp * b1[0], a2[1] - dp * b1[1], a2[2] - dp * b1[2]};
+  const float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-6f);
+  const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2],
+                       b1[0] * b2[1] - b1[1] * b2[0]};
+  float R[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { R[r][0] = b1[r]; R[r][1] = b2[r]; R[r][2] = b3[r]; }
+  float aa[3];
+  rotmat_to_aa(R, aa);
+
+  // rest joint of this lane and of its parent
+  float beta[10];
+#pragma unroll
+  for (int l = 0; l < 10; ++l) beta[l] = x[kNPose + l];
+  float Jr[3];
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) {
+    float v = c.J0[j * 3 + cc];
+#pragma unroll
+    for (int l = 0; l < 10; ++l) v += c.JS[(j * 3 + cc) * 10 + l] * beta[l];
+    Jr[cc] = v;
+  }
+  const int par = act ? c.parents[j] : -1;
+  const int dep = act ? c.depth[j] : 0;
+  const int src = par < 0 ? 0 : par;
+  float rel[3];
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) {
+    const float pj = __shfl(Jr[cc], src);
+    rel[cc] = par < 0 ? Jr[cc] : Jr[cc] - pj;
+  }
+  // chain: G = [R | rel] for the root, G_parent * [R | rel] below it, level by level
+  float G[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { G[r][0] = R[r][0]; G[r][1] = R[r][1]; G[r][2] = R[r][2]; G[r][3] = rel[r]; }
+  for (int lvl = 1; lvl <= maxdepth; ++lvl) {
+    float P[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) P[r][cc] = __shfl(G[r][cc], src);
+    if (dep == lvl) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+          G[r][cc] = P[r][0] * R[0][cc] + P[r][1] * R[1][cc] + P[r][2] * R[2][cc];
+        G[r][3] = P[r][0] * rel[0] + P[r][1] * rel[1] + P[r][2] * rel[2] + P[r][3];
+      }
+    }
+  }
+  if (act) {
+    float* Ao = Amat + ((long)p * kNJ + j) * 12;
+    float* Ro = rotmat + ((long)p * kNJ + j) * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Ao[r * 4 + 0] = G[r][0]; Ao[r * 4 + 1] = G[r][1]; Ao[r * 4 + 2] = G[r][2];
+      Ao[r * 4 + 3] = G[r][3] - (G[r][0] * Jr[0] + G[r][1] * Jr[1] + G[r][2] * Jr[2]);
+      posed[((long)p * kNJ + j) * 3 + r] = G[r][3];
+      Ro[r * 3 + 0] = R[r][0]; Ro[r * 3 + 1] = R[r][1]; Ro[r * 3 + 2] = R[r][2];
+    }
+    float* th = theta + (long)p * kTheta;
+    th[3 + 3 * j + 0] = aa[0]; th[3 + 3 * j + 1] = aa[1]; th[3 + 3 * j + 2] = aa[2];
+    float* f = pf + (long)p * kBlendK;
+    if (j >= 1) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) f[11 + 9 * (j - 1) + 3 * r + cc] = R[r][cc] - (r == cc ? 1.f : 0.f);
+    } else {
+      f[0] = 1.f;
+#pragma unroll
+      for (int l = 0; l < 10; ++l) { f[1 + l] = beta[l]; th[75 + l] = beta[l]; }
+#pragma unroll
+      for (int l = 218; l < kBlendK; ++l) f[l] = 0.f;
+      th[0] = x[154]; th[1] = x[155]; th[2] = x[156];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ skinning
+// thread = vertex, 24 skin weights in registers; loops over a group of persons whose A
+// matrices are wave-uniform reads.  T = sum_j W[v,j] A_j ; vert = T[:3,:3] v_posed + T[:3,3].
+constexpr int kSkinPG = 32;
+__global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict__ lbsW,
+                                                        const float* __restrict__ vposed,
+                                                        const float* __restrict__ Amat, int N,
+                                                        float* __restrict__ verts) {
+  __shared__ float As[kNJ * 12];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = v < kNV;
+  float w[kNJ];
+#pragma unroll
+  for (int j = 0; j < kNJ; ++j) w[j] = ok ? lbsW[(long)v * kNJ + j] : 0.f;
+  const int p0 = blockIdx.y * kSkinPG;
+  const int p1 = min(p0 + kSkinPG, N);
+  for (int p = p0; p < p1; ++p) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kNJ * 12; i += 256) As[i] = Amat[(long)p * kNJ * 12 + i];
+    __syncthreads();
+    float t[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) t[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 12; ++e) t[e] += w[j] * As[j * 12 + e];
+    if (ok) {
+      const float* vp = vposed + (long)p * kVertLd + 3 * v;
+      const float x = vp[0], y = vp[1], z = vp[2];
+      float* o = verts + ((long)p * kNV + v) * 3;
+      o[0] = t[0] * x + t[1] * y + t[2] * z + t[3];
+      o[1] = t[4] * x + t[5] * y + t[6] * z + t[7];
+      o[2] = t[8] * x + t[9] * y + t[10] * z + t[11];
+    }
+  }
+}
+
+hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
+                            float* verts, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  dim3 grid((kNV + 255) / 256, (N + kSkinPG - 1) / kSkinPG);
+  hipLaunchKernelGGL(smpl_skin_kernel, grid, dim3(256), 0, s, c.lbsW, vposed, Amat, N, verts);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ joints + projection
+// block per person.  Regressed joints = CSR rows (9 extra rows always; 17 h36m rows when the
+// evaluation regressor is given).  kp_3d = 14 (h36m path) or 49 joints; kp_2d = projection.
+__global__ void __launch_bounds__(256) smpl_joints_kernel(SmplConsts c, JregPacked jr, int use_jr,
+                                                          const float* __restrict__ verts,
+                                                          const float* __restrict__ posed,
+                                                          const float* __restrict__ xs, int N,
+                                                          float* __restrict__ kp3d,
+                                                          float* __restrict__ kp2d) {
+  __shared__ float reg[17][3];
+  const int p = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* V = verts + (long)p * kNV * 3;
+  const int nrows = use_jr ? 17 : 9;
+  const int* ptr = use_jr ? jr.ptr : c.xr_ptr;
+  const int* idx = use_jr ? jr.idx : c.xr_idx;
+  const float* val = use_jr ? jr.val : c.xr_val;
+  for (int row = wave; row < nrows; row += 4) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int e1 = ptr[row + 1];
+    for (int e = ptr[row] + lane; e < e1; e += 64) {
+      const float wv = val[e];
+      const float* q = V + (long)idx[e] * 3;
+      a0 += wv * q[0]; a1 += wv * q[1]; a2 += wv * q[2];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      a0 += __shfl_down(a0, o); a1 += __shfl_down(a1, o); a2 += __shfl_down(a2, o);
+    }
+    if (lane == 0) { reg[row][0] = a0; reg[row][1] = a1; reg[row][2] = a2; }
+  }
+  __syncthreads();
+  const int nj = use_jr ? 14 : 49;
+  const int k = threadIdx.x;
+  if (k < nj) {
+    float q[3];
+    if (use_jr) {
+      const int s = kH36mToJ14[k];
+      q[0] = reg[s][0]; q[1] = reg[s][1]; q[2] = reg[s][2];
+    } else {
+      const int s = kJointMap49[k];
+      if (s < 24) {
+        const float* ps = posed + ((long)p * kNJ + s) * 3;
+        q[0] = ps[0]; q[1] = ps[1]; q[2] = ps[2];
+      } else if (s < 45) {
+        const float* ps = V + (long)kExtraVerts[s - 24] * 3;
+        q[0] = ps[0]; q[1] = ps[1]; q[2] = ps[2];
+      } else {
+        q[0] = reg[s - 45][0]; q[1] = reg[s - 45][1]; q[2] = reg[s - 45][2];
+      }
+    }
+    float* o3 = kp3d + ((long)p * nj + k) * 3;
+    o3[0] = q[0]; o3[1] = q[1]; o3[2] = q[2];
+    // spin.py:307-351: t = [cam1, cam2, 2*5000/(224*cam0 + 1e-9)], R = I, centre 0
+    const float* cam = xs + (long)p * kState + 154;
+    const float tz = 10000.f / (224.f * cam[0] + 1e-9f);
+    const float px = q[0] + cam[1], py = q[1] + cam[2], pz = q[2] + tz;
+    float* o2 = kp2d + ((long)p * nj + k) * 2;
+    o2[0] = (5000.f * (px / pz)) / 112.f;
+    o2[1] = (5000.f * (py / pz)) / 112.f;
+  }
+}
+
+hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const float* verts,
+                              const float* posed, const float* xs, int N, float* kp3d, float* kp2d,
+                              hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  JregPacked j = jr ? *jr : JregPacked{nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(smpl_joints_kernel, dim3(N), dim3(256), 0, s, c, j, jr ? 1 : 0, verts, posed, xs,
+                     N, kp3d, kp2d);
+  return hipGetLastError();
+}
+
+hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
+                            float* posed, float* rotmat, float* theta, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, xs, N, pf, Amat,
+                     posed, rotmat, theta);
+  return hipGetLastError();
+}
+
+}  // namespace tepose

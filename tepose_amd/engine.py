@@ -1,0 +1,201 @@
+"""Host-side owner of one tepose_model handle: the packed-weight blob, the workspace,
+and the calls into the C ABI.  PyTorch is used for device memory and streams only.
+"""
+import ctypes
+from ctypes import c_double, c_int, c_int32, c_void_p
+
+import torch
+
+from . import _lib
+from .synth import NUM_VERTS
+
+
+def _sig(tensors):
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+
+
+def _dev_f32(t, device):
+    """fp32 contiguous copy/view of t on device (no copy when already there)."""
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """One per TePose / standalone TemporalEncoder / standalone Regressor."""
+
+    def __init__(self, n_layers, hidden):
+        self.lib = _lib.load()
+        h = c_void_p()
+        _lib.check(self.lib.tepose_create(int(n_layers), int(hidden), ctypes.byref(h)), 'tepose_create')
+        self.handle = h
+        self.n_layers, self.hidden = int(n_layers), int(hidden)
+        self.blob = None
+        self.device = None
+        self._sig_enc = self._sig_reg = self._sig_smpl = None
+        self._ws = None
+        self._jreg_cache = {}
+        self.profiling = False
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.tepose_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ blob / packing
+    @property
+    def packed_bytes(self):
+        return int(self.lib.tepose_packed_bytes(self.handle))
+
+    def _ensure_blob(self, device):
+        if self.blob is None or self.device != device:
+            self.blob = torch.zeros(self.packed_bytes, dtype=torch.uint8, device=device)
+            self.device = device
+            _lib.check(self.lib.tepose_set_blob(self.handle, self.blob.data_ptr(), self.blob.numel()),
+                       'tepose_set_blob')
+            self._sig_enc = self._sig_reg = self._sig_smpl = None
+            self._ws = None
+            self._jreg_cache = {}
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def pack_encoder(self, enc, device):
+        """enc: module with gru_fwd, gru_rec (nn.GRU) and linear_fwd, linear_rec (nn.Linear)."""
+        self._ensure_blob(device)
+        L = self.n_layers
+        ts = []
+        for l in range(L):
+            ts += [getattr(enc.gru_fwd, '%s_l%d' % (k, l)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        for l in range(L):
+            for sfx in ('', '_reverse'):
+                ts += [getattr(enc.gru_rec, '%s_l%d%s' % (k, l, sfx))
+                       for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        ts += [enc.linear_fwd.weight, enc.linear_fwd.bias, enc.linear_rec.weight, enc.linear_rec.bias]
+        sig = _sig(ts)
+        if sig == self._sig_enc:
+            return
+        keep = [_dev_f32(t, device) for t in ts]
+        arr = _lib.ptr_array([t.data_ptr() for t in keep])
+        _lib.check(self.lib.tepose_pack_encoder(self.handle, arr, len(keep), self._stream()), 'tepose_pack_encoder')
+        self._sig_enc = sig
+
+    def pack_regressor(self, reg, device):
+        self._ensure_blob(device)
+        ts = [reg.fc1.weight, reg.fc1.bias, reg.fc2.weight, reg.fc2.bias, reg.decpose.weight, reg.decpose.bias,
+              reg.decshape.weight, reg.decshape.bias, reg.deccam.weight, reg.deccam.bias,
+              reg.init_pose, reg.init_shape, reg.init_cam]
+        sig = _sig(ts)
+        if sig != self._sig_reg:
+            keep = [_dev_f32(t, device) for t in ts]
+            arr = _lib.ptr_array([t.data_ptr() for t in keep])
+            _lib.check(self.lib.tepose_pack_regressor(self.handle, arr, len(keep), self._stream()),
+                       'tepose_pack_regressor')
+            self._sig_reg = sig
+        smpl = reg.smpl
+        ts = [smpl.v_template, smpl.shapedirs, smpl.posedirs, smpl.J_regressor, smpl.lbs_weights,
+              smpl.J_regressor_extra, smpl.parents]
+        sig = (id(smpl),) + _sig(ts)
+        if sig != self._sig_smpl:
+            keep = [_dev_f32(t, device) for t in ts[:6]]
+            if tuple(keep[0].shape) != (NUM_VERTS, 3) or tuple(keep[2].shape) != (207, NUM_VERTS * 3):
+                raise _lib.TeposeError('SMPL tables have unexpected shapes')
+            par = (c_int32 * 24)(*[int(p) for p in smpl.parents.detach().cpu().tolist()])
+            _lib.check(self.lib.tepose_pack_smpl(self.handle, *[t.data_ptr() for t in keep], par, self._stream()),
+                       'tepose_pack_smpl')
+            self._sig_smpl = sig
+
+    def jreg(self, J, device):
+        """Packed CSR of an evaluation joint regressor [17,6890] (any device; cached)."""
+        if J is None:
+            return None, 0
+        key = (J.data_ptr(), J._version, str(J.device))
+        hit = self._jreg_cache.get(key)
+        if hit is None:
+            if tuple(J.shape) != (17, NUM_VERTS):
+                raise _lib.TeposeError('J_regressor must be [17, 6890], got %s' % (tuple(J.shape),))
+            src = _dev_f32(J, device)
+            buf = torch.zeros(int(self.lib.tepose_jreg_packed_bytes()), dtype=torch.uint8, device=device)
+            _lib.check(self.lib.tepose_pack_jreg(src.data_ptr(), buf.data_ptr(), self._stream()), 'tepose_pack_jreg')
+            if len(self._jreg_cache) > 8:
+                self._jreg_cache.clear()
+            hit = self._jreg_cache[key] = (buf, J)   # keep J alive so its data_ptr stays unique
+        return hit[0], hit[0].data_ptr()
+
+    # ------------------------------------------------------------------ forward
+    def workspace(self, B, T, device):
+        need = int(self.lib.tepose_workspace_bytes(self.handle, int(B), int(T)))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def encoder_fwd(self, x, is_train):
+        B, T = x.shape[:2]
+        ws = self.workspace(B, T, x.device)
+        feat = torch.empty((B, 2, 2048) if is_train else (B, 2048), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.tepose_encoder_fwd(self.handle, x.data_ptr(), B, T, 1 if is_train else 0,
+                                               feat.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                   'tepose_encoder_fwd')
+        return feat
+
+    def regressor_fwd(self, feat, n_iter, J_regressor, ws_hint=None):
+        N = feat.shape[0]
+        dev = feat.device
+        ws = self.workspace(max(1, (N + 1) // 2), 1, dev) if ws_hint is None else ws_hint
+        _, jp = self.jreg(J_regressor, dev)
+        nj = 14 if J_regressor is not None else 49
+        out = {
+            'theta': torch.empty((N, 85), dtype=torch.float32, device=dev),
+            'verts': torch.empty((N, NUM_VERTS, 3), dtype=torch.float32, device=dev),
+            'kp_2d': torch.empty((N, nj, 2), dtype=torch.float32, device=dev),
+            'kp_3d': torch.empty((N, nj, 3), dtype=torch.float32, device=dev),
+            'rotmat': torch.empty((N, 24, 3, 3), dtype=torch.float32, device=dev),
+        }
+        _lib.check(self.lib.tepose_regressor_fwd(
+            self.handle, feat.data_ptr(), N, int(n_iter), jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
+            out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
+            self._stream()), 'tepose_regressor_fwd')
+        return out
+
+    def forward(self, x, J_regressor):
+        B, T = x.shape[:2]
+        dev = x.device
+        ws = self.workspace(B, T, dev)
+        _, jp = self.jreg(J_regressor, dev)
+        nj = 14 if J_regressor is not None else 49
+        out = {
+            'theta': torch.empty((B, 85), dtype=torch.float32, device=dev),
+            'verts': torch.empty((B, NUM_VERTS, 3), dtype=torch.float32, device=dev),
+            'kp_2d': torch.empty((B, nj, 2), dtype=torch.float32, device=dev),
+            'kp_3d': torch.empty((B, nj, 3), dtype=torch.float32, device=dev),
+            'rotmat': torch.empty((B, 24, 3, 3), dtype=torch.float32, device=dev),
+        }
+        _lib.check(self.lib.tepose_forward(
+            self.handle, x.data_ptr(), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
+            out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
+            self._stream()), 'tepose_forward')
+        return out
+
+    # ------------------------------------------------------------------ profiling hook (bench.py)
+    def profile_enable(self, on):
+        _lib.check(self.lib.tepose_profile_enable(self.handle, 1 if on else 0), 'tepose_profile_enable')
+
+    def profile_read(self):
+        ms, n, fl = c_double(), c_int(), c_double()
+        _lib.check(self.lib.tepose_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
+                   'tepose_profile_read')
+        return ms.value, n.value, fl.value
+
+
+def check_input(x):
+    if not torch.is_tensor(x) or x.dim() != 3 or x.shape[2] != 2133:
+        raise ValueError('input must be a [B, T, 2133] tensor (reference lib/models/tepose.py:54)')
+    if not x.is_cuda:
+        raise RuntimeError('tepose_amd runs on MI355X only: move the model and input to a cuda device '
+                           '(there is no CPU path)')
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous()
