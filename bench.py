@@ -1,0 +1,193 @@
+"""bench.py -- windows/s of the TePose per-window inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], SURVEY.md 8d cfg-C): synthetic [8192,16,2133] fp32
+windows per GPU, model n_layers=2 / hidden=1024 (configs/config.yaml of the reference:
+SEQLEN 16, the published checkpoints' GRU size), random-init weights of that architecture,
+synthetic SMPL tables of the true shapes, H36M joint-regressor path (evaluate.py:109).
+One step = one TePose.forward over the batch, inputs resident in HBM before the clock
+starts.  N > 1: one process per GPU (torchrun), clips/windows are independent, so ranks
+share nothing on the data path (weak scaling); rank 0 packs the weights and broadcasts
+the packed blob over RCCL, per-rank results are gathered to rank 0.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the layer-0
+input-projection GEMM, 42 % of the FLOPs, one launch per step), timed with hipEvents on
+the launch stream inside the timed region.  `cpu_baseline` is the oracle's torch-CPU
+restatement of the reference op sequence (nn.GRU + Linear + LBS) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work per window, L=2 H=1024
+GFLOP_PER_WINDOW = {6: 0.600, 16: 1.497, 32: 2.931}
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, fp32-input MFMA
+
+
+def synthetic_windows_device(B, T, seed, device):
+    """Same distribution as tepose_amd.synth.synthetic_windows, generated on the GPU."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.zeros(B, T, 2133, device=device)
+    x[:, :, :2048] = torch.randn(B, T, 2048, device=device, generator=g).abs_() * 0.5
+    th = torch.cat([torch.randn(B, T, 3, device=device, generator=g) * 0.05 +
+                    torch.tensor([0.9, 0.0, 0.0], device=device),
+                    torch.randn(B, T, 72, device=device, generator=g) * 0.2,
+                    torch.randn(B, T, 10, device=device, generator=g) * 0.5], dim=-1)
+    x[:, :T - 1, 2048:] = th[:, :T - 1]
+    return x
+
+
+def cpu_baseline(state, smpl_np, L, T, budget_s=15.0):
+    """Reference op sequence on the host cores (oracle, torch CPU), windows/s."""
+    from oracle import tepose_ref as O
+    from tepose_amd import synth
+    Bc = 64
+    x = synth.synthetic_windows(Bc, T, 4321)
+    J = smpl_np['J_regressor_h36m']
+    cores = torch.get_num_threads()
+    O.tepose_fwd(state, smpl_np, x[:8], L, J_regressor=J, nn_gru=True)      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.tepose_fwd(state, smpl_np, x, L, J_regressor=J, nn_gru=True)
+        n += Bc
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return {'value': n / el, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d windows of [%d,2133] in batches of %d, torch %s CPU, nn.GRU op sequence, %.1f s'
+                      % (n, T, Bc, torch.__version__, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8192, help='windows per GPU per step')
+    ap.add_argument('--seqlen', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    from tepose_amd import synth
+    from tepose_amd.testing import build_model
+    L, H, B, T = 2, 1024, args.batch, args.seqlen
+    smpl_np = synth.synthetic_smpl(0)
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    if rank == 0:
+        model, state, _ = build_model(L, H, seed=0, device=device, smpl_np=smpl_np, seqlen=T)
+        eng = model._engine
+        with torch.no_grad():
+            model(synthetic_windows_device(2, T, 1, device), J_regressor=J)     # packs the blob
+        blob = eng.blob
+    else:
+        from tepose_amd.smpl import SMPL
+        from tepose_amd.tepose import TePose
+        mean = synth.synthetic_mean_params(0)
+        model = TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='', smpl=SMPL.from_tables(smpl_np),
+                       smpl_mean_params=mean).to(device).eval()
+        eng = model._engine
+        blob = torch.empty(eng.packed_bytes, dtype=torch.uint8, device=device)
+        state = None
+    bcast_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(blob, src=0)           # RCCL over xGMI: the packed weights, once
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+        if rank != 0:
+            eng.adopt_blob(blob, model)
+
+    x = synthetic_windows_device(B, T, 1234 + rank, device)
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            return model(x, J_regressor=J)[0]
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    eng.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n, k_flops = eng.profile_read()
+    eng.profile_enable(False)
+    finite = bool(torch.isfinite(out['verts']).all().item() and torch.isfinite(out['theta']).all().item())
+
+    t_all = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        rec = torch.tensor([float(rank), elapsed, float(B * args.steps), float(finite)], device=device,
+                           dtype=torch.float64)
+        gathered = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
+        dist.gather(rec, gathered, dst=0)     # per-rank records -> rank 0
+    t_max = float(t_all.item())
+
+    if rank == 0:
+        windows = B * world * args.steps
+        res = {
+            'metric': '16-frame windows/sec (whole node)' if T == 16 else '%d-frame windows/sec (whole node)' % T,
+            'value': windows / t_max, 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'cfg-C synthetic [%d,%d,2133] fp32 windows per GPU, TePose n_layers=2 '
+                                   'hidden=1024, random-init weights, synthetic SMPL tables, H36M-14 joint path'
+                                   % (B, T),
+                       'windows_per_gpu_per_step': B, 'seqlen': T, 'parallelism': 'clip-sharded dp%d' % world},
+            'outputs_finite': finite,
+        }
+        if T in GFLOP_PER_WINDOW:
+            res['whole_path_tflops'] = windows * GFLOP_PER_WINDOW[T] / t_max / 1e3
+            res['whole_path_frac_of_f32_mfma_peak'] = res['whole_path_tflops'] / (PEAK_F32_MFMA_TFLOPS * world)
+        if k_n > 0:
+            ach = k_flops / (k_ms / k_n * 1e-3) / 1e12
+            res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'kernel': 'gemm_f32_kernel<false> (layer-0 input projection, M=%d N=9216 K=2133)'
+                                         % (B * T),
+                               'launches': k_n, 'avg_ms': k_ms / k_n}
+        if bcast_ms is not None:
+            res['weight_broadcast_ms'] = bcast_ms
+            res['weight_blob_MB'] = eng.packed_bytes / 1e6
+            res['per_rank'] = [[float(v) for v in g.tolist()] for g in gathered]
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(state, smpl_np, L, T)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -57,6 +57,10 @@ void tepose_destroy(tepose_model* m);
  * broadcast to the other ranks of a node.                                            */
 size_t tepose_packed_bytes(const tepose_model* m);
 int tepose_set_blob(tepose_model* m, void* blob, size_t bytes);
+/* Declare that the registered blob already holds a fully packed model (it was filled by
+ * tepose_pack_* on another handle of the same n_layers/hidden and copied or broadcast
+ * here, e.g. rank 0 -> all ranks over RCCL).                                          */
+int tepose_adopt_blob(tepose_model* m);
 
 /* Pack encoder weights.  `w` = HOST array of DEVICE pointers in the reference's
  * state-dict order, n_w = 8*L + 16*L... precisely:

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libtepose_hip.so')
 # every symbol include/tepose_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     'tepose_version', 'tepose_error_string', 'tepose_create', 'tepose_destroy',
-    'tepose_packed_bytes', 'tepose_set_blob', 'tepose_pack_encoder', 'tepose_pack_regressor',
+    'tepose_packed_bytes', 'tepose_set_blob', 'tepose_adopt_blob', 'tepose_pack_encoder', 'tepose_pack_regressor',
     'tepose_pack_smpl', 'tepose_jreg_packed_bytes', 'tepose_pack_jreg', 'tepose_workspace_bytes',
     'tepose_encoder_fwd', 'tepose_regressor_fwd', 'tepose_forward', 'tepose_gemm_workspace_bytes',
     'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read',
@@ -46,6 +46,7 @@ def load():
     lib.tepose_packed_bytes.argtypes = [c_void_p]
     lib.tepose_packed_bytes.restype = c_size_t
     lib.tepose_set_blob.argtypes = [c_void_p, fp, c_size_t]
+    lib.tepose_adopt_blob.argtypes = [c_void_p]
     lib.tepose_pack_encoder.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     lib.tepose_pack_regressor.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     lib.tepose_pack_smpl.argtypes = [c_void_p, fp, fp, fp, fp, fp, fp, POINTER(c_int32), c_void_p]

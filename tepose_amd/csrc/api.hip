@@ -213,6 +213,14 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
   return 0;
 }
 
+int tepose_adopt_blob(tepose_model* m) {
+  if (!m) return TEPOSE_E_ARG;
+  if (!m->blob) return TEPOSE_E_STATE;
+  m->enc_packed = m->reg_packed = m->smpl_packed = true;
+  m->maxdepth = kNJ - 1;   // upper bound; chain levels past the real depth are no-ops
+  return 0;
+}
+
 int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* stream) {
   if (!m || !w) return TEPOSE_E_ARG;
   if (!m->blob) return TEPOSE_E_STATE;

@@ -58,25 +58,52 @@ class Engine:
             self._ws = None
             self._jreg_cache = {}
 
+    def adopt_blob(self, blob, model):
+        """Use a packed blob produced by another Engine of the same (n_layers, hidden) --
+        e.g. received through an RCCL broadcast from rank 0 -- instead of packing `model`'s
+        own parameters, which are then ignored until one of them changes."""
+        assert blob.dtype == torch.uint8 and blob.numel() >= self.packed_bytes
+        self.blob, self.device = blob, blob.device
+        _lib.check(self.lib.tepose_set_blob(self.handle, blob.data_ptr(), blob.numel()), 'tepose_set_blob')
+        _lib.check(self.lib.tepose_adopt_blob(self.handle), 'tepose_adopt_blob')
+        self._sig_enc = _sig(self._enc_tensors(model.encoder))
+        self._sig_reg = _sig(self._reg_tensors(model.regressor))
+        self._sig_smpl = (id(model.regressor.smpl),) + _sig(self._smpl_tensors(model.regressor.smpl))
+        self._ws = None
+        self._jreg_cache = {}
+
+    def _enc_tensors(self, enc):
+        ts = []
+        for l in range(self.n_layers):
+            ts += [getattr(enc.gru_fwd, '%s_l%d' % (k, l)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        for l in range(self.n_layers):
+            for sfx in ('', '_reverse'):
+                ts += [getattr(enc.gru_rec, '%s_l%d%s' % (k, l, sfx))
+                       for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        return ts + [enc.linear_fwd.weight, enc.linear_fwd.bias, enc.linear_rec.weight, enc.linear_rec.bias]
+
+    @staticmethod
+    def _reg_tensors(reg):
+        return [reg.fc1.weight, reg.fc1.bias, reg.fc2.weight, reg.fc2.bias, reg.decpose.weight, reg.decpose.bias,
+                reg.decshape.weight, reg.decshape.bias, reg.deccam.weight, reg.deccam.bias,
+                reg.init_pose, reg.init_shape, reg.init_cam]
+
+    @staticmethod
+    def _smpl_tensors(smpl):
+        return [smpl.v_template, smpl.shapedirs, smpl.posedirs, smpl.J_regressor, smpl.lbs_weights,
+                smpl.J_regressor_extra, smpl.parents]
+
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
     def pack_encoder(self, enc, device):
         """enc: module with gru_fwd, gru_rec (nn.GRU) and linear_fwd, linear_rec (nn.Linear)."""
-        self._ensure_blob(device)
-        L = self.n_layers
-        ts = []
-        for l in range(L):
-            ts += [getattr(enc.gru_fwd, '%s_l%d' % (k, l)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
-        for l in range(L):
-            for sfx in ('', '_reverse'):
-                ts += [getattr(enc.gru_rec, '%s_l%d%s' % (k, l, sfx))
-                       for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
-        ts += [enc.linear_fwd.weight, enc.linear_fwd.bias, enc.linear_rec.weight, enc.linear_rec.bias]
+        ts = self._enc_tensors(enc)
         sig = _sig(ts)
-        if sig == self._sig_enc:
+        if sig == self._sig_enc and self.device == device:
             return
+        self._ensure_blob(device)
         keep = [_dev_f32(t, device) for t in ts]
         arr = _lib.ptr_array([t.data_ptr() for t in keep])
         _lib.check(self.lib.tepose_pack_encoder(self.handle, arr, len(keep), self._stream()), 'tepose_pack_encoder')
@@ -84,9 +111,7 @@ class Engine:
 
     def pack_regressor(self, reg, device):
         self._ensure_blob(device)
-        ts = [reg.fc1.weight, reg.fc1.bias, reg.fc2.weight, reg.fc2.bias, reg.decpose.weight, reg.decpose.bias,
-              reg.decshape.weight, reg.decshape.bias, reg.deccam.weight, reg.deccam.bias,
-              reg.init_pose, reg.init_shape, reg.init_cam]
+        ts = self._reg_tensors(reg)
         sig = _sig(ts)
         if sig != self._sig_reg:
             keep = [_dev_f32(t, device) for t in ts]
@@ -95,8 +120,7 @@ class Engine:
                        'tepose_pack_regressor')
             self._sig_reg = sig
         smpl = reg.smpl
-        ts = [smpl.v_template, smpl.shapedirs, smpl.posedirs, smpl.J_regressor, smpl.lbs_weights,
-              smpl.J_regressor_extra, smpl.parents]
+        ts = self._smpl_tensors(smpl)
         sig = (id(smpl),) + _sig(ts)
         if sig != self._sig_smpl:
             keep = [_dev_f32(t, device) for t in ts[:6]]
