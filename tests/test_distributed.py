@@ -1,0 +1,60 @@
+"""CPU, world_size 2 on gloo: the clip partitioner, the blob broadcast and the padded
+per-clip record gather used by the multi-GPU path (one process per GPU on the real node)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tepose_amd.distributed import broadcast_blob, gather_records, imbalance, partition_clips
+
+
+def test_partition_is_a_balanced_exact_cover():
+    lengths = [1824, 910, 777, 1500, 64, 333, 2048, 12, 905, 640, 1200, 87]
+    for world in (1, 2, 4, 8):
+        parts = partition_clips(lengths, world)
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(lengths)))          # every clip exactly once, never split
+        assert imbalance(lengths, parts) < 1.6
+    assert partition_clips(lengths, 8) == partition_clips(list(lengths), 8)    # deterministic
+    assert partition_clips([], 4) == [[], [], [], []]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, lengths):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        blob = (torch.arange(4096, dtype=torch.int64) % 251).to(torch.uint8) if rank == 0 \
+            else torch.zeros(4096, dtype=torch.uint8)
+        broadcast_blob(blob, src=0)
+        assert int(blob.to(torch.int64).sum()) == int((torch.arange(4096) % 251).sum())
+        parts = partition_clips(lengths, world)
+        mine = parts[rank]
+        rec = torch.tensor([[float(i), float(lengths[i]), 0.5 * lengths[i]] for i in mine], dtype=torch.float64)
+        rec = rec.reshape(-1, 3)
+        out = gather_records(rec, dst=0)
+        if rank == 0:
+            assert out.shape == (len(lengths), 3)
+            ids = sorted(int(v) for v in out[:, 0].tolist())
+            assert ids == list(range(len(lengths)))
+            # frame-weighted mean formed on rank 0 exactly like evaluate.py:461
+            assert abs(float(out[:, 2].sum() / out[:, 1].sum()) - 0.5) < 1e-12
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world2_gloo():
+    lengths = [300, 20, 75, 1200, 64, 333, 48]     # 7 clips -> ranks hold 3 and 4 (ragged gather)
+    mp.spawn(_worker, args=(2, _free_port(), lengths), nprocs=2, join=True)
