@@ -21,7 +21,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
-constexpr int BK = 32;
+#ifndef TEPOSE_BK
+#define TEPOSE_BK 32
+#endif
+constexpr int BK = TEPOSE_BK;          // K-tile (floats): 32 -> 64/80 KB LDS per block, 16 -> 32/40 KB
+constexpr int SLOTS = BK / 4;          // 16-byte slots per tile row
+constexpr int RPI = 64 / SLOTS;        // tile rows moved by one wave-wide DMA instruction
+constexpr int SWZ_SH = BK == 32 ? 1 : 2;  // rows per 256-B LDS bank row = 2 (BK 32) or 4 (BK 16)
+static_assert(BK == 16 || BK == 32, "K-tile must be 16 or 32");
+#ifndef TEPOSE_GEMM_OCC
+#define TEPOSE_GEMM_OCC 2
+#endif
+#ifndef TEPOSE_PIPE
+#define TEPOSE_PIPE 1
+#endif
+#ifndef TEPOSE_GRU_OCC
+#define TEPOSE_GRU_OCC 2
+#endif
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -50,38 +66,39 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
                                          const float* __restrict__ W, int Kp, int n0, float* lds,
                                          f32x16 (&acc)[2][WN]) {
   constexpr int BN = 64 * WN;
-  constexpr int NWQ = BN / 32;               // W-tile DMA instructions per wave
+  constexpr int NAQ = BM / RPI / 4;          // A-tile DMA instructions per wave
+  constexpr int NWQ = BN / RPI / 4;          // W-tile DMA instructions per wave
   constexpr int STAGE = (BM + BN) * BK;      // floats per pipeline stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
   // ---- DMA source pointers: one wave-instruction moves 8 rows x 128 B ------------------
-  const int lrow = lane >> 3, lslot = lane & 7;
-  const float* ga[4];
+  const int lrow = lane / SLOTS, lslot = lane % SLOTS;
+  const float* ga[NAQ];
   const float* gw[NWQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = (wave * 4 + q) * 8 + lrow;
+  for (int q = 0; q < NAQ; ++q) {
+    const int row = (wave * NAQ + q) * RPI + lrow;
     const int grow = min(m0 + row, M - 1);   // tail rows re-read the last valid row
-    ga[q] = A + (long)grow * lda + 4 * (lslot ^ ((row >> 1) & 7));
+    ga[q] = A + (long)grow * lda + 4 * (lslot ^ ((row >> SWZ_SH) & (SLOTS - 1)));
   }
 #pragma unroll
   for (int q = 0; q < NWQ; ++q) {
-    const int row = (wave * NWQ + q) * 8 + lrow;
-    gw[q] = W + (long)(n0 + row) * Kp + 4 * (lslot ^ ((row >> 1) & 7));
+    const int row = (wave * NWQ + q) * RPI + lrow;
+    gw[q] = W + (long)(n0 + row) * Kp + 4 * (lslot ^ ((row >> SWZ_SH) & (SLOTS - 1)));
   }
   auto issue = [&](int kt, int buf) {
     float* la = lds + buf * STAGE;
     float* lw = la + BM * BK;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(ga[q] + kt * BK, la + (wave * 4 + q) * 256);
+    for (int q = 0; q < NAQ; ++q) glds16(ga[q] + kt * BK, la + (wave * NAQ + q) * 256);
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) glds16(gw[q] + kt * BK, lw + (wave * NWQ + q) * 256);
   };
 
   // ---- fragment read offsets (floats) ---------------------------------------------------
-  const int sw = (r >> 1) & 7;
+  const int sw = (r >> SWZ_SH) & (SLOTS - 1);
   int aoff[2], boff[WN];
 #pragma unroll
   for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + i * 32 + r) * BK;
@@ -89,6 +106,53 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
   for (int j = 0; j < WN; ++j) boff[j] = BM * BK + (wn * 32 * WN + j * 32 + r) * BK;
 
   const int KT = Kp / BK;
+  constexpr int NC = BK / 8;                 // 8-k chunks per K-tile
+  auto load_frags = [&](const float* st, int c, f32x4 (&a)[2], f32x4 (&b)[WN]) {
+    const int sx = 4 * ((2 * c + h) ^ sw);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *(const f32x4*)(st + aoff[i] + sx);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b[j] = *(const f32x4*)(st + boff[j] + sx);
+  };
+  auto mma = [&](f32x4 (&a)[2], f32x4 (&b)[WN]) {
+    if (RELU) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[i][m] = fmaxf(a[i][m], 0.f);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
+  };
+#if TEPOSE_PIPE
+  // Software pipeline: fragments of chunk c+1 are read while chunk c's MFMAs run; the
+  // stage barrier sits in front of the LAST chunk's MFMAs, so the first fragments of the
+  // next stage are fetched underneath them and no ds_read latency is exposed per K-tile.
+  f32x4 fa[2][2], fb[2][WN];
+  issue(0, 0);
+  __syncthreads();
+  load_frags(lds, 0, fa[0], fb[0]);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+    const float* st = lds + buf * STAGE;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c + 1 < NC) {
+        load_frags(st, c + 1, fa[(c + 1) & 1], fb[(c + 1) & 1]);
+      } else {
+        __syncthreads();                                     // DMA(kt+1) landed; reads of `buf` issued
+        if (kt + 1 < KT) load_frags(lds + (buf ^ 1) * STAGE, 0, fa[(c + 1) & 1], fb[(c + 1) & 1]);
+      }
+      mma(fa[c & 1], fb[c & 1]);
+    }
+  }
+#else
   issue(0, 0);
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
@@ -96,34 +160,19 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
     if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
     const float* st = lds + buf * STAGE;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int sx = 4 * ((2 * c + h) ^ sw);
+    for (int c = 0; c < NC; ++c) {
       f32x4 a[2], b[WN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *(const f32x4*)(st + aoff[i] + sx);
-        if (RELU) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) a[i][m] = fmaxf(a[i][m], 0.f);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = *(const f32x4*)(st + boff[j] + sx);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
+      load_frags(st, c, a, b);
+      mma(a, b);
     }
     __syncthreads();   // all reads of `buf` done; DMA of the next stage has landed (vmcnt(0))
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------ plain GEMM
 template <bool RELU>
-__global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmArgs a, int tilesM, int tilesN) {
+__global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs a, int tilesM, int tilesN) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + 128) * BK];
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
@@ -174,9 +223,28 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
 // The W_hh tile of a block is 64 hidden units x 3 gates; packed row order inside the tile
 // is [wave_n(2)][gate(3)][32], so a wave's three N-subtiles are the r, z, n pre-activations
 // of the same 32 hidden units and the whole cell update happens in registers.
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// sigma(x) = 1/(1+2^(-x log2 e)), tanh(x) = 2 sigma(2x) - 1 on the hardware exp2 / rcp units
+// (v_exp_f32, v_rcp_f32: ~1 ulp each).  Absolute error of a gate value < 3e-7, far inside the
+// 1e-4 parity budget (tests/test_gpu_parity.py::test_encoder_vs_oracle runs 32-step recurrences).
+#ifndef TEPOSE_FAST_GATES
+#define TEPOSE_FAST_GATES 1
+#endif
+__device__ __forceinline__ float sigmoidf_(float x) {
+#if TEPOSE_FAST_GATES
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+#else
+  return 1.f / (1.f + expf(-x));
+#endif
+}
+__device__ __forceinline__ float tanhf_(float x) {
+#if TEPOSE_FAST_GATES
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+#else
+  return tanhf(x);
+#endif
+}
 
-__global__ void __launch_bounds__(256, 2) gru_step_kernel(GruArgs a, int tilesM, int tilesJ) {
+__global__ void __launch_bounds__(256, TEPOSE_GRU_OCC) gru_step_kernel(GruArgs a, int tilesM, int tilesJ) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + 192) * BK];
   const GruDir& d = a.d[blockIdx.y];
   int tm, tj;
@@ -195,20 +263,30 @@ __global__ void __launch_bounds__(256, 2) gru_step_kernel(GruArgs a, int tilesM,
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
   const int Hp = a.Hp;
   const int j = tj * 64 + wn * 32 + r;
+  const float* __restrict__ gip = d.gi;
+  const float* __restrict__ hpp = d.hprev;
+  float* __restrict__ hop = d.hout;
   const float br = d.bhh[j], bz = d.bhh[Hp + j], bn = d.bhh[2 * Hp + j];
+  const bool first = a.first != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    const int rbase = m0 + wm * 64 + i * 32 + 4 * h;
+    // all loads of this 32-row fragment first (rows past M re-read row M-1, never stored)
+    float gr[16], gz[16], gn[16], hp[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row < a.M) {
-        const float* gi = d.gi + (long)row * d.ldgi + j;
-        const float rg = sigmoidf_(gi[0] + (acc[i][0][e] + br));
-        const float zg = sigmoidf_(gi[Hp] + (acc[i][1][e] + bz));
-        const float ng = tanhf(gi[2 * Hp] + rg * (acc[i][2][e] + bn));
-        const float hp = a.first ? 0.f : d.hprev[(long)row * d.ldh + j];
-        d.hout[(long)row * d.ldo + j] = (1.f - zg) * ng + zg * hp;
-      }
+      const int row = min(rbase + (e & 3) + 8 * (e >> 2), a.M - 1);
+      const float* gi = gip + (long)row * d.ldgi + j;
+      gr[e] = gi[0]; gz[e] = gi[Hp]; gn[e] = gi[2 * Hp];
+      hp[e] = first ? 0.f : hpp[(long)row * d.ldh + j];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = rbase + (e & 3) + 8 * (e >> 2);
+      const float rg = sigmoidf_(gr[e] + (acc[i][0][e] + br));
+      const float zg = sigmoidf_(gz[e] + (acc[i][1][e] + bz));
+      const float ng = tanhf_(gn[e] + rg * (acc[i][2][e] + bn));
+      if (row < a.M) hop[(long)row * d.ldo + j] = (1.f - zg) * ng + zg * hp[e];
     }
   }
 }
