@@ -51,6 +51,10 @@ struct GruArgs {
   int first;                     // h_{-1} = 0: skip the matmul
 };
 hipError_t launch_gru_step(const GruArgs& a, hipStream_t s);
+// small-M variants (skinny.hip); the launchers above dispatch to them when M <= skinny_max_m()
+hipError_t launch_skinny_gemm(const GemmArgs& a, hipStream_t s);
+hipError_t launch_skinny_gru(const GruArgs& a, hipStream_t s);
+int skinny_max_m();
 
 // ---------------------------------------------------------------- misc.hip
 // dst[np][kp] (row-major [Np][Kp]) = src[rowmap(np)][colmap(kp)] or 0.

@@ -15,6 +15,8 @@
 // must stay lane-linear for LDS-DMA), which makes every ds_read_b128 conflict-free.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace tepose {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -208,8 +210,19 @@ __global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs
   }
 }
 
+// Rows at or below which the width-first kernels of skinny.hip win over 128-row tiles
+// (measured crossover; TEPOSE_SKINNY_MAX_M overrides it for experiments).
+int skinny_max_m() {
+  static const int v = [] {
+    const char* e = getenv("TEPOSE_SKINNY_MAX_M");
+    return e ? atoi(e) : 256;
+  }();
+  return v;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (a.M <= skinny_max_m()) return launch_skinny_gemm(a, s);
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + 127) / 128;
   dim3 grid(tilesM * tilesN), block(256);
   if (a.relu_a)
@@ -293,6 +306,7 @@ __global__ void __launch_bounds__(256, TEPOSE_GRU_OCC) gru_step_kernel(GruArgs a
 
 hipError_t launch_gru_step(const GruArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.ndir <= 0) return hipSuccess;
+  if (a.M <= skinny_max_m()) return launch_skinny_gru(a, s);
   const int tilesM = (a.M + BM - 1) / BM, tilesJ = a.Hp / 64;
   dim3 grid(tilesM * tilesJ, a.ndir), block(256);
   hipLaunchKernelGGL(gru_step_kernel, grid, block, 0, s, a, tilesM, tilesJ);
