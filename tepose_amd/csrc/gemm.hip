@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs
 int skinny_max_m() {
   static const int v = [] {
     const char* e = getenv("TEPOSE_SKINNY_MAX_M");
-    return e ? atoi(e) : 256;
+    return e ? atoi(e) : 768;
   }();
   return v;
 }

@@ -59,6 +59,8 @@ class TePose(nn.Module):
     def forward(self, input, is_train=False, J_regressor=None):
         x = check_input(input)
         batch_size = x.shape[0]
+        if batch_size == 0 or x.shape[1] == 0:
+            raise ValueError('empty batch / zero-length window: torch.nn.GRU in the reference rejects it too')
         eng = self._engine
         with torch.cuda.device(x.device):
             eng.pack_encoder(self.encoder, x.device)

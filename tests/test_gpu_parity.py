@@ -62,7 +62,8 @@ def test_gemm_rejects_bad_arguments():
 
 # ---------------------------------------------------------------- modules vs oracle
 @pytest.mark.parametrize('L,H,B,T', [(2, 1024, 2, 6), (1, 128, 3, 5), (2, 256, 130, 4), (3, 64, 2, 4),
-                                      (1, 100, 2, 3), (2, 1024, 1, 32), (2, 256, 300, 3), (2, 128, 40, 7), (1, 64, 17, 4)])
+                                      (1, 100, 2, 3), (2, 1024, 1, 32), (2, 256, 300, 3), (2, 128, 40, 7), (1, 64, 17, 4),
+                                      (2, 128, 3, 1), (1, 64, 2, 2), (2, 64, 900, 2)])
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
     from oracle import tepose_ref as O
     model, state, _ = _model(L, H, 11, smpl_np)
@@ -187,3 +188,50 @@ def test_outputs_are_fresh_and_deterministic(smpl_np):
     for k in a:
         assert a[k].data_ptr() != b[k].data_ptr()
         assert torch.equal(a[k], b[k]), k
+
+
+# ---------------------------------------------------------------- full benchmark size
+def test_full_size_batch_matches_oracle_on_sampled_rows(smpl_np):
+    """BASELINE.json configs[2] size ([8192,16,2133], L=2, H=1024): rows of the big batch are
+    independent windows, so (i) sampled rows must match the CPU oracle to 1e-4 and (ii) the same
+    rows pushed through the small-batch kernels must agree with the big-batch kernels."""
+    from bench import synthetic_windows_device
+    from oracle import tepose_ref as O
+    model, state, _ = _model(2, 1024, 0, smpl_np)
+    B, T = 8192, 16
+    x = synthetic_windows_device(B, T, 99, torch.device('cuda'))
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    with torch.no_grad():
+        big = model(x, J_regressor=J)[0]
+    for v in big.values():
+        assert torch.isfinite(v).all()
+    R = big['rotmat'].reshape(-1, 3, 3)
+    eye = torch.eye(3, device='cuda')
+    assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-4          # rot6d output is orthonormal
+    assert (torch.linalg.det(R) - 1).abs().max() < 1e-4
+    idx = torch.tensor([0, 1, 127, 128, 4095, 4096, 8191, 5000, 333, 7777, 2048, 6001])
+    with torch.no_grad():
+        small = model(x[idx.cuda()].contiguous(), J_regressor=J)[0]
+    for k in big:
+        assert (big[k][idx.cuda()] - small[k]).abs().max() < 2e-5, k   # tile / split-K order only
+    ref = O.tepose_fwd(state, smpl_np, x[idx.cuda()].cpu().numpy(), 2, J_regressor=smpl_np['J_regressor_h36m'])
+    for k in ('verts', 'kp_3d', 'rotmat'):
+        assert (big[k][idx.cuda()].cpu() - ref[k]).abs().max() < TOL, k
+    _check_theta(big['theta'][idx.cuda()].cpu().double().numpy(), ref['theta'].double().numpy(), None)
+
+
+def test_row_permutation_equivariance(smpl_np):
+    model, _, _ = _model(1, 128, 2, smpl_np)
+    x = _dev(synth.synthetic_windows(70, 5, 21))
+    perm = torch.randperm(70, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        a = model(x)[0]
+        b = model(x[perm].contiguous())[0]
+    for k in a:
+        assert (a[k][perm] - b[k]).abs().max() < 1e-6, k
+
+
+def test_empty_batch_is_rejected(smpl_np):
+    model, _, _ = _model(1, 64, 1, smpl_np)
+    with pytest.raises(ValueError):
+        model(torch.zeros(0, 6, 2133, device='cuda'))
