@@ -279,3 +279,28 @@ def tepose_fwd(state, smpl_np, x, n_layers, J_regressor=None, dtype=torch.float3
                             None if J_regressor is None else _t(J_regressor, dtype))
     out['feature'] = feat
     return out
+
+
+def run_clip(state, smpl_np, feats, theta_init, seqlen, n_layers, J_regressor=None, dtype=torch.float32):
+    """The per-clip autoregressive loop of evaluate.py:247-269 (B = 1, strictly serial):
+    window j = frames j..j+T-1 with theta slots of its first T-1 frames = theta_input, last
+    frame zero; afterwards theta_input shifts by one and takes the new prediction.
+    Returns dict of stacked per-window outputs [N-T+1, ...]."""
+    T = seqlen
+    feats = _t(feats, dtype)
+    theta_input = _t(theta_init, dtype).clone()
+    enc, reg = split_state_dict(state, dtype)
+    smpl = smpl_tensors(smpl_np, dtype)
+    J = None if J_regressor is None else _t(J_regressor, dtype)
+    outs = {'theta': [], 'kp_3d': [], 'verts': [], 'rotmat': []}
+    with torch.no_grad():
+        for j in range(feats.shape[0] - T + 1):
+            x = torch.zeros(1, T, 2133, dtype=dtype)
+            x[0, :, :2048] = feats[j:j + T]
+            x[0, :T - 1, 2048:] = theta_input
+            o = regressor_fwd(reg, smpl, encoder_fwd(enc, x, n_layers), J)
+            for k in outs:
+                outs[k].append(o[k][0])
+            theta_input[:T - 2] = theta_input[1:T - 1].clone()
+            theta_input[T - 2] = o['theta'][0]
+    return {k: torch.stack(v) for k, v in outs.items()}

@@ -150,6 +150,40 @@ def run_case(T_mod, name, L, H, B, T, use_jreg, seed_w=0, seed_x=1234):
     print('wrote', name, {k: v.shape for k, v in d.items()})
 
 
+def driver_case(T_mod, name, L, H, N, T, seed_w, seed_x):
+    """One clip through the reference's own autoregressive loop (evaluate.py:247-269,
+    written out here as the caller does it, model = the reference TePose)."""
+    model = T_mod.TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='').eval()
+    sd_np = synth.synthetic_state_dict(L, H, seed_w)
+    sd = model.state_dict()
+    for k in sd:
+        if k in sd_np:
+            sd[k] = torch.from_numpy(sd_np[k])
+    model.load_state_dict(sd, strict=True)
+    w = synth.synthetic_windows(1, N, seed_x)[0]           # [N,2133]: features + plausible thetas
+    feat = torch.from_numpy(w[:, :2048].copy())
+    theta_input = torch.from_numpy(w[:T - 1, 2048:].copy())
+    theta_input[:, :3] = torch.tensor([1., 0., 0.])        # evaluate.py:177-178
+    theta0 = theta_input.clone()
+    J = torch.from_numpy(SMPL_NP['J_regressor_h36m'])
+    th, kp, vs = [], [], []
+    with torch.no_grad():
+        for j in range(N - T + 1):
+            inp = torch.zeros((1, T, 2048 + 85))
+            inp[0, :, :2048] = feat[None, j:j + T, :].clone()
+            inp[0, :T - 1, 2048:] = theta_input.clone()
+            preds = model(inp, J_regressor=J, is_train=False)
+            th.append(preds[-1]['theta'].view(-1, 85).numpy().copy())
+            kp.append(preds[-1]['kp_3d'].view(-1, 14, 3).numpy().copy())
+            vs.append(preds[-1]['verts'].view(-1, 6890, 3)[:, ::53].numpy().copy())
+            theta_input[:T - 2, :] = theta_input[1:T - 1, :].clone()
+            theta_input[T - 2, :] = preds[-1]['theta'].clone().detach()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'),
+                        meta=np.array([L, H, N, T, seed_w, seed_x], dtype=np.int64), theta_init=theta0.numpy(),
+                        theta=np.concatenate(th), kp_3d=np.concatenate(kp), verts_sub=np.concatenate(vs))
+    print('wrote', name, np.concatenate(th).shape)
+
+
 def geometry_cases(G):
     """Edge vectors for R->aa (each quaternion branch, angle 0, angles near pi about
     each axis), rot6d->R (incl. degenerate input) and projection."""
@@ -196,6 +230,8 @@ def main():
     run_case(T_mod, 'tepose_L2H1024_B1T32_j14', 2, 1024, 1, 32, True)
     run_case(T_mod, 'tepose_L1H128_B3T5_j49', 1, 128, 3, 5, False, seed_w=3, seed_x=77)
     run_case(T_mod, 'tepose_L3H64_B2T4_j14', 3, 64, 2, 4, True, seed_w=4, seed_x=78)
+    driver_case(T_mod, 'driver_L2H128_N40T6', 2, 128, 40, 6, 6, 555)
+    driver_case(T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
     geometry_cases(G)
     # projection vector
     j = torch.from_numpy(synth.normal('geom/j', (4, 14, 3), std=0.5))

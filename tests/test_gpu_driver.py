@@ -1,0 +1,72 @@
+"""GPU: the autoregressive window driver batched over clips (tepose_amd/driver.py) against the
+reference's per-clip loop (golden vectors from evaluate.py:247-269 semantics) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tepose_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def smpl_np():
+    return synth.synthetic_smpl(0)
+
+
+def _aa_close(a, b, tol):
+    a, b = a.reshape(-1, 3), b.reshape(-1, 3)
+    ok = np.linalg.norm(b, axis=1) < 3.0
+    return np.abs(a[ok] - b[ok]).max() < tol and ok.mean() > 0.8
+
+
+@pytest.mark.parametrize('name', ['driver_L2H128_N40T6', 'driver_L1H64_N9T4'])
+def test_single_clip_matches_reference_loop(name, smpl_np):
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    L, H, N, T, seed_w, seed_x = [int(v) for v in g['meta']]
+    model, _, _ = build_model(L, H, seed=seed_w, device='cuda', smpl_np=smpl_np)
+    w = synth.synthetic_windows(1, N, seed_x)[0]
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    out = run_clips(model, [torch.from_numpy(w[:, :2048].copy())], [torch.from_numpy(g['theta_init'])], T,
+                    J_regressor=J)[0]
+    assert out['theta'].shape == (N - T + 1, 85)
+    # 35 feedback steps: errors of window j feed window j+1; budget stays 1e-4
+    assert np.abs(out['kp_3d'].cpu().numpy() - g['kp_3d']).max() < 1e-4
+    assert np.abs(out['verts'].cpu().numpy()[:, ::53] - g['verts_sub']).max() < 1e-4
+    th = out['theta'].cpu().numpy()
+    assert np.abs(th[:, :3] - g['theta'][:, :3]).max() < 1e-4
+    assert np.abs(th[:, 75:] - g['theta'][:, 75:]).max() < 1e-4
+    assert _aa_close(th[:, 3:75], g['theta'][:, 3:75], 1e-4)
+
+
+def test_ragged_clips_in_lockstep_equal_per_clip_runs(smpl_np):
+    """Clips of different lengths (one shorter than the window) advance together; each must equal
+    its own B=1 oracle run, and the result order must follow the input order."""
+    from oracle import tepose_ref as O
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    L, H, T = 1, 64, 5
+    model, state, _ = build_model(L, H, seed=9, device='cuda', smpl_np=smpl_np)
+    lens = [9, 3, 14, 5, 11]
+    feats, inits = [], []
+    for i, n in enumerate(lens):
+        w = synth.synthetic_windows(1, max(n, T), 600 + i)[0]
+        feats.append(torch.from_numpy(w[:n, :2048].copy()))
+        th = w[:T - 1, 2048:].copy()
+        th[:, :3] = [1, 0, 0]
+        inits.append(torch.from_numpy(th))
+    res = run_clips(model, feats, inits, T)
+    assert res[1] is None                                   # shorter than the window: skipped
+    for i, n in enumerate(lens):
+        if n < T:
+            continue
+        ref = O.run_clip(state, smpl_np, feats[i].numpy(), inits[i].numpy(), T, L)
+        assert res[i]['theta'].shape[0] == n - T + 1
+        assert (res[i]['verts'].cpu() - ref['verts']).abs().max() < 1e-4
+        assert (res[i]['kp_3d'].cpu() - ref['kp_3d']).abs().max() < 1e-4
+        assert (res[i]['rotmat'].cpu() - ref['rotmat']).abs().max() < 1e-4

@@ -124,3 +124,17 @@ def test_batch_rodrigues_is_rotation():
     aa = torch.from_numpy(synth.normal('rot3', (50, 3), std=0.8)).double()
     back = O.rotmat_to_angle_axis(R)
     assert (back - aa).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('name', ['driver_L2H128_N40T6', 'driver_L1H64_N9T4'])
+def test_oracle_clip_loop_matches_reference_golden(name, smpl_np):
+    """evaluate.py:247-269 autoregressive loop: theta feedback over up to 35 windows."""
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    L, H, N, T, seed_w, seed_x = [int(v) for v in g['meta']]
+    state = synth.synthetic_state_dict(L, H, seed_w)
+    w = synth.synthetic_windows(1, N, seed_x)[0]
+    out = O.run_clip(state, smpl_np, w[:, :2048], g['theta_init'], T, L, J_regressor=smpl_np['J_regressor_h36m'])
+    assert np.abs(out['kp_3d'].numpy() - g['kp_3d']).max() < 1e-4
+    assert np.abs(out['verts'].numpy()[:, ::53] - g['verts_sub']).max() < 1e-4
+    assert np.abs(out['theta'].numpy()[:, :3] - g['theta'][:, :3]).max() < 1e-4
+    assert np.abs(out['theta'].numpy()[:, 75:] - g['theta'][:, 75:]).max() < 1e-4
