@@ -37,6 +37,9 @@ static_assert(BK == 16 || BK == 32, "K-tile must be 16 or 32");
 #ifndef TEPOSE_PIPE
 #define TEPOSE_PIPE 1
 #endif
+#ifndef TEPOSE_ABL
+#define TEPOSE_ABL 0   // diagnostic timing builds only: 1 no DMA, 2 no fragment reads, 3 no barrier, 4 no epilogue
+#endif
 #ifndef TEPOSE_GRU_OCC
 #define TEPOSE_GRU_OCC 2
 #endif
@@ -141,16 +144,24 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
   load_frags(lds, 0, fa[0], fb[0]);
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
+#if TEPOSE_ABL != 1
     if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+#endif
     const float* st = lds + buf * STAGE;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+#if TEPOSE_ABL != 2
       if (c + 1 < NC) {
         load_frags(st, c + 1, fa[(c + 1) & 1], fb[(c + 1) & 1]);
       } else {
+#if TEPOSE_ABL != 3
         __syncthreads();                                     // DMA(kt+1) landed; reads of `buf` issued
+#endif
         if (kt + 1 < KT) load_frags(lds + (buf ^ 1) * STAGE, 0, fa[(c + 1) & 1], fb[(c + 1) & 1]);
       }
+#else
+      if (c + 1 == NC) __syncthreads();
+#endif
       mma(fa[c & 1], fb[c & 1]);
     }
   }
@@ -187,6 +198,14 @@ __global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   mainloop<2, RELU>(a.A, a.lda, a.M, m0, a.W, a.Kp, n0, lds, acc);
+#if TEPOSE_ABL == 4
+  if (a.scale != 123.f) {
+    float sacc = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+    if (sacc == 1.2345f) a.C[0] = sacc;
+    return;
+  }
+#endif
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;

@@ -3,7 +3,7 @@
 for lib in "$@"; do
   export TEPOSE_AMD_LIB=$PWD/$lib
   echo "== $lib"
-  python -m pytest tests/test_gpu_parity.py -x -q -k "gemm or golden or encoder" 2>&1 | tail -1
+  python -m pytest tests/test_gpu_parity.py -x -q -k "gemm or golden or encoder or full_size" 2>&1 | tail -1
   for rep in 1 2; do
     python bench.py --batch 4096 --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
