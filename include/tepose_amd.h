@@ -116,6 +116,20 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
                    float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
                    void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- VIBE bootstrap encoder (lib/models/vibe.py:27-117; used by evaluate.py:89-107,233-245
+ * and demo.py:104-130,229-237 to predict the first seqlen-1 frames) ----------------------
+ * A handle made by tepose_create_vibe holds: uni-directional GRU(2048 -> hidden, n_layers),
+ * Linear(hidden -> 2048) on relu(y), residual add, plus the same regressor / SMPL sections
+ * as a TePose handle (tepose_pack_regressor / tepose_pack_smpl / tepose_regressor_fwd work
+ * on it).  w = { for l: gru.weight_ih_l{l}, weight_hh, bias_ih, bias_hh ; linear.weight,
+ * linear.bias }, n_w = 4*L + 2.                                                          */
+int tepose_create_vibe(int n_layers, int hidden, tepose_model** out);
+int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, void* stream);
+size_t tepose_vibe_workspace_bytes(const tepose_model* m, int B, int N);
+/* x[B,N,2048] -> feat[B*N,2048] (row b*N+t) = linear(relu(gru(x))) (+ x when use_residual). */
+int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N, int use_residual,
+                            float* feat, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- building blocks exported for tests and bench.py --------------------------------- */
 /* C[M,N] = (relu_a ? relu(A) : A)[M,K] * W[N,K]^T (+ bias[N]) with the library's own
  * fp32-MFMA kernel.  A rows must be 16-byte aligned (lda % 4 == 0); W is packed on the

@@ -304,3 +304,28 @@ def run_clip(state, smpl_np, feats, theta_init, seqlen, n_layers, J_regressor=No
             theta_input[:T - 2] = theta_input[1:T - 1].clone()
             theta_input[T - 2] = o['theta'][0]
     return {k: torch.stack(v) for k, v in outs.items()}
+
+
+def vibe_encoder_fwd(sd, x, n_layers, use_residual=True):
+    """VIBE TemporalEncoder.forward (lib/models/vibe.py:52-65), uni-directional, add_linear:
+    y = linear(relu(gru(x))) (+ x).  sd keys: gru.weight_ih_l0 ..., linear.weight, linear.bias.
+    x [B,N,2048] -> [B,N,2048]."""
+    seq = x.transpose(0, 1)
+    for l in range(n_layers):
+        seq = _scan(seq, sd, 'gru.@_l%d' % l)
+    y = F.relu(seq) @ sd['linear.weight'].t() + sd['linear.bias']
+    if use_residual:
+        y = y + x.transpose(0, 1)
+    return y.transpose(0, 1)
+
+
+def vibe_fwd(state, smpl_np, x, n_layers, J_regressor=None, dtype=torch.float32):
+    """VIBE.forward (lib/models/vibe.py:104-117): per-frame regressor over the encoder output."""
+    enc, reg = split_state_dict(state, dtype)
+    smpl = smpl_tensors(smpl_np, dtype)
+    x = _t(x, dtype)
+    with torch.no_grad():
+        feat = vibe_encoder_fwd(enc, x, n_layers).reshape(-1, 2048)
+        out = regressor_fwd(reg, smpl, feat, None if J_regressor is None else _t(J_regressor, dtype))
+    out['feature'] = feat
+    return out

@@ -16,7 +16,8 @@ SYMBOLS = [
     'tepose_packed_bytes', 'tepose_set_blob', 'tepose_adopt_blob', 'tepose_pack_encoder', 'tepose_pack_regressor',
     'tepose_pack_smpl', 'tepose_jreg_packed_bytes', 'tepose_pack_jreg', 'tepose_workspace_bytes',
     'tepose_encoder_fwd', 'tepose_regressor_fwd', 'tepose_forward', 'tepose_gemm_workspace_bytes',
-    'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read',
+    'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read', 'tepose_create_vibe',
+    'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
 ]
 
 _lib = None
@@ -63,6 +64,11 @@ def load():
     lib.tepose_gemm_workspace_bytes.restype = c_size_t
     lib.tepose_gemm_f32.argtypes = [fp, c_long, fp, c_long, fp, fp, c_long, c_int, c_int, c_int, c_int,
                                     fp, c_size_t, c_void_p]
+    lib.tepose_create_vibe.argtypes = [c_int, c_int, POINTER(c_void_p)]
+    lib.tepose_pack_vibe_encoder.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
+    lib.tepose_vibe_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.tepose_vibe_workspace_bytes.restype = c_size_t
+    lib.tepose_vibe_encoder_fwd.argtypes = [c_void_p, fp, c_int, c_int, c_int, fp, fp, c_size_t, c_void_p]
     lib.tepose_profile_enable.argtypes = [c_void_p, c_int]
     lib.tepose_profile_read.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     for name in SYMBOLS:

@@ -24,6 +24,10 @@ struct SmplOff {
 }  // namespace
 
 struct tepose_model {
+  int kind = 0;                                 // 0 = TePose, 1 = VIBE bootstrap encoder
+  std::vector<DirW> vibe;                       // VIBE: per-layer uni-GRU weights
+  size_t vlin_w = 0, vlin_b = 0;
+  bool vibe_packed = false;
   int L = 0, H = 0, Hp = 0;
   float* blob = nullptr;
   size_t blob_floats = 0;
@@ -53,6 +57,24 @@ size_t take(size_t& cur, size_t n) {
   return o;
 }
 
+void layout_tail(tepose_model* m, size_t cur);
+
+void layout_vibe(tepose_model* m) {
+  const size_t Hp = m->Hp, L = m->L;
+  size_t cur = 0;
+  const size_t n128 = round_up(3 * (int)Hp, 128);
+  m->vibe.assign(L, DirW());
+  for (size_t l = 0; l < L; ++l) {
+    m->vibe[l].wih = take(cur, n128 * (l == 0 ? (size_t)kFeat : Hp));
+    m->vibe[l].bih = take(cur, 3 * Hp);
+    m->vibe[l].whh = take(cur, 3 * Hp * Hp);
+    m->vibe[l].bhh = take(cur, 3 * Hp);
+  }
+  m->vlin_w = take(cur, (size_t)kFeat * Hp);
+  m->vlin_b = take(cur, kFeat);
+  layout_tail(m, cur);
+}
+
 void layout(tepose_model* m) {
   const size_t Hp = m->Hp, L = m->L;
   size_t cur = 0;
@@ -80,6 +102,10 @@ void layout(tepose_model* m) {
   m->blf = take(cur, kFeat);
   m->wlr = take(cur, (size_t)kFeat * 2 * Hp);
   m->blr = take(cur, kFeat);
+  layout_tail(m, cur);
+}
+
+void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, shared by both kinds
   m->w1a = take(cur, 1024 * (size_t)kFeat);
   m->b1 = take(cur, 1024);
   m->w1b = take(cur, 1024 * (size_t)kState);
@@ -213,16 +239,95 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
   return 0;
 }
 
+int tepose_create_vibe(int n_layers, int hidden, tepose_model** out) {
+  if (!out || n_layers < 1 || hidden < 1) return TEPOSE_E_ARG;
+  if (n_layers > 8 || hidden > 8192) return TEPOSE_E_SHAPE;
+  tepose_model* m = new (std::nothrow) tepose_model();
+  if (!m) return TEPOSE_E_ARG;
+  m->kind = 1; m->L = n_layers; m->H = hidden; m->Hp = round_up(hidden, 64);
+  layout_vibe(m);
+  *out = m;
+  return 0;
+}
+
 int tepose_adopt_blob(tepose_model* m) {
   if (!m) return TEPOSE_E_ARG;
   if (!m->blob) return TEPOSE_E_STATE;
-  m->enc_packed = m->reg_packed = m->smpl_packed = true;
+  m->enc_packed = m->reg_packed = m->smpl_packed = m->vibe_packed = true;
   m->maxdepth = kNJ - 1;   // upper bound; chain levels past the real depth are no-ops
   return 0;
 }
 
+int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, void* stream) {
+  if (!m || !w || m->kind != 1) return TEPOSE_E_ARG;
+  if (!m->blob) return TEPOSE_E_STATE;
+  const int L = m->L, H = m->H, Hp = m->Hp;
+  if (n_w != 4 * L + 2) return TEPOSE_E_ARG;
+  for (int i = 0; i < n_w; ++i)
+    if (!w[i]) return TEPOSE_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* B = m->blob;
+  const int n128 = round_up(3 * Hp, 128);
+  for (int l = 0; l < L; ++l) {
+    const int K = l == 0 ? kFeat : H, Kp = l == 0 ? kFeat : Hp;
+    CK((hipError_t)pack(w[4 * l + 0], K, 3 * H, K, B + m->vibe[l].wih, n128, Kp, ROW_GATES, COL_PLAIN, H, Hp, s));
+    CK((hipError_t)pack(w[4 * l + 2], 1, 3 * H, 1, B + m->vibe[l].bih, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+    CK((hipError_t)pack(w[4 * l + 1], H, 3 * H, H, B + m->vibe[l].whh, 3 * Hp, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
+    CK((hipError_t)pack(w[4 * l + 3], 1, 3 * H, 1, B + m->vibe[l].bhh, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+  }
+  CK((hipError_t)pack(w[4 * L], H, kFeat, H, B + m->vlin_w, kFeat, Hp, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  CK((hipError_t)pack(w[4 * L + 1], 1, kFeat, 1, B + m->vlin_b, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  m->vibe_packed = true;
+  return 0;
+}
+
+size_t tepose_vibe_workspace_bytes(const tepose_model* m, int B, int N) {
+  if (!m || m->kind != 1 || B < 1 || N < 1) return 0;
+  const size_t BN = (size_t)B * N, Hp = m->Hp;
+  return align_up(BN * 3 * Hp * 4, 256) + 2 * align_up(BN * Hp * 4, 256) + 256;
+}
+
+int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N, int use_residual, float* feat,
+                            void* workspace, size_t ws_bytes, void* stream) {
+  if (!m || m->kind != 1 || !x || !feat || !workspace || B < 1 || N < 1) return TEPOSE_E_ARG;
+  if (!m->vibe_packed) return TEPOSE_E_STATE;
+  if (ws_bytes < tepose_vibe_workspace_bytes(m, B, N)) return TEPOSE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int L = m->L, Hp = m->Hp, H3 = 3 * Hp;
+  const long BN = (long)B * N;
+  Carver c(workspace, ws_bytes);
+  float* G = c.f((size_t)BN * H3);
+  float* S[2] = {c.f((size_t)BN * Hp), c.f((size_t)BN * Hp)};
+  const float* Bl = m->blob;
+  // everything is batch-major (row = b*N + t), like the caller's [B,N,2048]: time steps are a
+  // column offset t*ld with row stride N*ld, so no permute (vibe.py:53,62) is ever materialised
+  const float* in = x;
+  int ldin = kFeat;
+  for (int l = 0; l < L; ++l) {
+    GemmArgs g = gemm(in, ldin, Bl + m->vibe[l].wih, ldin, G, H3, Bl + m->vibe[l].bih, (int)BN, H3);
+    CK(launch_gemm(g, s));
+    float* So = S[l & 1];
+    for (int t = 0; t < N; ++t) {
+      GruArgs a{};
+      a.M = B; a.Hp = Hp; a.first = t == 0; a.ndir = 1;
+      GruDir& d = a.d[0];
+      d.Whh = Bl + m->vibe[l].whh; d.bhh = Bl + m->vibe[l].bhh;
+      d.gi = G + (long)t * H3; d.ldgi = (long)N * H3;
+      d.hprev = So + (long)(t - 1) * Hp; d.ldh = (long)N * Hp;
+      d.hout = So + (long)t * Hp; d.ldo = (long)N * Hp;
+      CK(launch_gru_step(a, s));
+    }
+    in = So; ldin = Hp;
+  }
+  GemmArgs g = gemm(in, Hp, Bl + m->vlin_w, Hp, feat, kFeat, Bl + m->vlin_b, (int)BN, kFeat);
+  g.relu_a = 1;
+  if (use_residual) { g.addend = x; g.ldadd = kFeat; }
+  CK(launch_gemm(g, s));
+  return 0;
+}
+
 int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* stream) {
-  if (!m || !w) return TEPOSE_E_ARG;
+  if (!m || !w || m->kind != 0) return TEPOSE_E_ARG;
   if (!m->blob) return TEPOSE_E_STATE;
   const int L = m->L, H = m->H, Hp = m->Hp;
   if (n_w != 12 * L + 4) return TEPOSE_E_ARG;
@@ -373,7 +478,7 @@ int tepose_profile_read(tepose_model* m, double* total_ms, int* n_launches, doub
 
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {
-  if (!m || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
+  if (!m || m->kind != 0 || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
   if ((size_t)B * T > (1u << 30) / 4) return TEPOSE_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;

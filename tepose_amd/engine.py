@@ -22,10 +22,14 @@ def _dev_f32(t, device):
 class Engine:
     """One per TePose / standalone TemporalEncoder / standalone Regressor."""
 
-    def __init__(self, n_layers, hidden):
+    def __init__(self, n_layers, hidden, kind='tepose'):
         self.lib = _lib.load()
         h = c_void_p()
-        _lib.check(self.lib.tepose_create(int(n_layers), int(hidden), ctypes.byref(h)), 'tepose_create')
+        self.kind = kind
+        if kind == 'vibe':
+            _lib.check(self.lib.tepose_create_vibe(int(n_layers), int(hidden), ctypes.byref(h)), 'tepose_create_vibe')
+        else:
+            _lib.check(self.lib.tepose_create(int(n_layers), int(hidden), ctypes.byref(h)), 'tepose_create')
         self.handle = h
         self.n_layers, self.hidden = int(n_layers), int(hidden)
         self.blob = None
@@ -202,6 +206,32 @@ class Engine:
             out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
             self._stream()), 'tepose_forward')
         return out
+
+    # ------------------------------------------------------------------ VIBE bootstrap encoder
+    def pack_vibe_encoder(self, enc, device):
+        ts = []
+        for l in range(self.n_layers):
+            ts += [getattr(enc.gru, '%s_l%d' % (k, l)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        ts += [enc.linear.weight, enc.linear.bias]
+        sig = _sig(ts)
+        if sig == self._sig_enc and self.device == device:
+            return
+        self._ensure_blob(device)
+        keep = [_dev_f32(t, device) for t in ts]
+        arr = _lib.ptr_array([t.data_ptr() for t in keep])
+        _lib.check(self.lib.tepose_pack_vibe_encoder(self.handle, arr, len(keep), self._stream()),
+                   'tepose_pack_vibe_encoder')
+        self._sig_enc = sig
+
+    def vibe_encoder_fwd(self, x, use_residual):
+        B, N = x.shape[:2]
+        need = int(self.lib.tepose_vibe_workspace_bytes(self.handle, B, N))
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        feat = torch.empty((B * N, 2048), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.tepose_vibe_encoder_fwd(self.handle, x.data_ptr(), B, N, 1 if use_residual else 0,
+                                                    feat.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                   'tepose_vibe_encoder_fwd')
+        return feat
 
     # ------------------------------------------------------------------ profiling hook (bench.py)
     def profile_enable(self, on):

@@ -184,6 +184,29 @@ def driver_case(T_mod, name, L, H, N, T, seed_w, seed_x):
     print('wrote', name, np.concatenate(th).shape)
 
 
+def vibe_case(name, L, H, B, N, seed_w, seed_x):
+    """Reference lib.models.vibe.VIBE (uni-GRU + Linear + residual, then the per-frame regressor)."""
+    import lib.models.vibe as V_mod
+    model = V_mod.VIBE(seqlen=N, n_layers=L, hidden_size=H, add_linear=True, bidirectional=False,
+                       use_residual=True, pretrained='').eval()
+    sd_np = synth.synthetic_vibe_state_dict(L, H, seed_w)
+    sd = model.state_dict()
+    for k in sd_np:
+        assert k in sd and tuple(sd[k].shape) == sd_np[k].shape, k
+        sd[k] = torch.from_numpy(sd_np[k])
+    model.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synth.synthetic_windows(B, N, seed_x)[:, :, :2048].copy())
+    J = torch.from_numpy(SMPL_NP['J_regressor_h36m'])
+    with torch.no_grad():
+        feat = model.encoder(x)
+        out = model(x, J_regressor=J)[-1]
+    np.savez_compressed(os.path.join(HERE, name + '.npz'),
+                        meta=np.array([L, H, B, N, seed_w, seed_x], dtype=np.int64), feature=feat.numpy(),
+                        theta=out['theta'].numpy(), kp_3d=out['kp_3d'].numpy(), rotmat=out['rotmat'].numpy(),
+                        verts_sub=out['verts'].numpy()[:, :, ::53])
+    print('wrote', name, feat.shape, out['theta'].shape)
+
+
 def geometry_cases(G):
     """Edge vectors for R->aa (each quaternion branch, angle 0, angles near pi about
     each axis), rot6d->R (incl. degenerate input) and projection."""
@@ -232,6 +255,8 @@ def main():
     run_case(T_mod, 'tepose_L3H64_B2T4_j14', 3, 64, 2, 4, True, seed_w=4, seed_x=78)
     driver_case(T_mod, 'driver_L2H128_N40T6', 2, 128, 40, 6, 6, 555)
     driver_case(T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
+    vibe_case('vibe_L2H128_B2N20', 2, 128, 2, 20, 8, 901)
+    vibe_case('vibe_L1H64_B1N5', 1, 64, 1, 5, 9, 902)
     geometry_cases(G)
     # projection vector
     j = torch.from_numpy(synth.normal('geom/j', (4, 14, 3), std=0.5))

@@ -138,3 +138,16 @@ def test_oracle_clip_loop_matches_reference_golden(name, smpl_np):
     assert np.abs(out['verts'].numpy()[:, ::53] - g['verts_sub']).max() < 1e-4
     assert np.abs(out['theta'].numpy()[:, :3] - g['theta'][:, :3]).max() < 1e-4
     assert np.abs(out['theta'].numpy()[:, 75:] - g['theta'][:, 75:]).max() < 1e-4
+
+
+@pytest.mark.parametrize('name', ['vibe_L2H128_B2N20', 'vibe_L1H64_B1N5'])
+def test_oracle_vibe_matches_reference_golden(name, smpl_np):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    L, H, B, N, seed_w, seed_x = [int(v) for v in g['meta']]
+    state = synth.synthetic_vibe_state_dict(L, H, seed_w)
+    x = synth.synthetic_windows(B, N, seed_x)[:, :, :2048].copy()
+    out = O.vibe_fwd(state, smpl_np, x, L, J_regressor=smpl_np['J_regressor_h36m'])
+    assert np.abs(out['feature'].numpy().reshape(B, N, 2048) - g['feature']).max() < 2e-5
+    assert np.abs(out['kp_3d'].numpy().reshape(B, N, 14, 3) - g['kp_3d']).max() < 2e-5
+    assert np.abs(out['rotmat'].numpy().reshape(B, N, 24, 3, 3) - g['rotmat']).max() < 2e-5
+    assert np.abs(out['verts'].numpy().reshape(B, N, 6890, 3)[:, :, ::53] - g['verts_sub']).max() < 2e-5
