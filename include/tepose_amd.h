@@ -130,6 +130,22 @@ size_t tepose_vibe_workspace_bytes(const tepose_model* m, int B, int N);
 int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N, int use_residual,
                             float* feat, void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- evaluation metrics on the device (evaluate.py:413-457, lib/utils/eval_utils.py) -------
+ * Joint metrics per frame, in mm: pred/target [N,J,3] (J <= 17) are pelvis-aligned inside
+ * (pelvis_mode 0: mean of joints 2,3 -- 3DPW / H36M 14-joint order, evaluate.py:424-425;
+ * 1: joint J-3 -- mpii3d_test order, evaluate.py:420-422).  mpjpe[N], pa_mpjpe[N]
+ * (batch_compute_similarity_transform_torch, eval_utils.py:287-337), accel[N] (second
+ * difference, eval_utils.py:110-138; 0 for the first and last frame of the sequence).     */
+int tepose_metrics_joints(const float* pred, const float* target, int N, int J, int pelvis_mode,
+                          float* mpjpe, float* pa_mpjpe, float* accel, void* stream);
+/* Vertices of the ground-truth mesh from theta[N,85] = cam3 | axis-angle 72 | betas 10 with
+ * pose2rot=True (eval_utils.py:155-169).  Workspace >= tepose_workspace_bytes(m, ceil(N/2), 1). */
+int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int N, float* verts,
+                                 void* workspace, size_t ws_bytes, void* stream);
+/* mpvpe[N] = mean_v |pred_verts - target_verts| in mm (eval_utils.py:173-175).             */
+int tepose_metrics_verts(const float* pred_verts, const float* target_verts, int N, float* mpvpe,
+                         void* stream);
+
 /* ---- building blocks exported for tests and bench.py --------------------------------- */
 /* C[M,N] = (relu_a ? relu(A) : A)[M,K] * W[N,K]^T (+ bias[N]) with the library's own
  * fp32-MFMA kernel.  A rows must be 16-byte aligned (lda % 4 == 0); W is packed on the

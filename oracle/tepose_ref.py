@@ -329,3 +329,47 @@ def vibe_fwd(state, smpl_np, x, n_layers, J_regressor=None, dtype=torch.float32)
         out = regressor_fwd(reg, smpl, feat, None if J_regressor is None else _t(J_regressor, dtype))
     out['feature'] = feat
     return out
+
+
+# ---- metrics (evaluate.py:413-457; lib/utils/eval_utils.py) ---------------------------------
+def procrustes_align(S1, S2):
+    """batch_compute_similarity_transform_torch (eval_utils.py:287-337) on [N,J,3] inputs."""
+    S1t, S2t = S1.permute(0, 2, 1), S2.permute(0, 2, 1)
+    mu1, mu2 = S1t.mean(dim=-1, keepdim=True), S2t.mean(dim=-1, keepdim=True)
+    X1, X2 = S1t - mu1, S2t - mu2
+    var1 = (X1 ** 2).sum(dim=1).sum(dim=1)
+    K = X1.bmm(X2.permute(0, 2, 1))
+    U, s, Vh = torch.linalg.svd(K)
+    V = Vh.transpose(1, 2)
+    Z = torch.eye(3, dtype=S1.dtype).repeat(U.shape[0], 1, 1)
+    Z[:, -1, -1] *= torch.sign(torch.det(U.bmm(V.permute(0, 2, 1))))
+    R = V.bmm(Z.bmm(U.permute(0, 2, 1)))
+    scale = torch.stack([torch.trace(x) for x in R.bmm(K)]) / var1
+    t = mu2 - scale[:, None, None] * R.bmm(mu1)
+    return (scale[:, None, None] * R.bmm(S1t) + t).permute(0, 2, 1)
+
+
+def joint_metrics(pred, target, pelvis='lsp'):
+    """Per-frame mpjpe, pa_mpjpe, accel (mm) as evaluate.py:419-450 computes them."""
+    pred, target = pred.clone(), target.clone()
+    if pelvis == 'lsp':
+        pp, tp = (pred[:, [2]] + pred[:, [3]]) / 2.0, (target[:, [2]] + target[:, [3]]) / 2.0
+    else:
+        pp, tp = pred[:, [-3]], target[:, [-3]]
+    pred, target = pred - pp, target - tp
+    mpjpe = torch.sqrt(((pred - target) ** 2).sum(-1)).mean(-1) * 1000
+    pa = torch.sqrt(((procrustes_align(pred, target) - target) ** 2).sum(-1)).mean(-1) * 1000
+    accel = torch.zeros(pred.shape[0], dtype=pred.dtype)
+    if pred.shape[0] > 2:
+        ag = target[:-2] - 2 * target[1:-1] + target[2:]
+        ap = pred[:-2] - 2 * pred[1:-1] + pred[2:]
+        accel[1:-1] = torch.linalg.norm(ap - ag, dim=2).mean(1) * 1000
+    return {'mpjpe': mpjpe, 'pa_mpjpe': pa, 'accel': accel}
+
+
+def verts_from_theta(smpl_np, theta, dtype=torch.float32):
+    """GT mesh of compute_error_verts (eval_utils.py:155-169): pose2rot=True [LBS unpinned]."""
+    smpl = smpl_tensors(smpl_np, dtype)
+    theta = _t(theta, dtype)
+    R = batch_rodrigues(theta[:, 3:75].reshape(-1, 3)).view(-1, 24, 3, 3)
+    return lbs(smpl, theta[:, 75:], R)[0]

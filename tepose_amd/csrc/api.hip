@@ -679,6 +679,41 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
                               stream);
 }
 
+int tepose_metrics_joints(const float* pred, const float* target, int N, int J, int pelvis_mode, float* mpjpe,
+                          float* pa_mpjpe, float* accel, void* stream) {
+  if (!pred || !target || !mpjpe || !pa_mpjpe || !accel || N < 1) return TEPOSE_E_ARG;
+  if (J < 4 || J > 17 || (pelvis_mode != 0 && pelvis_mode != 1)) return TEPOSE_E_SHAPE;
+  CK(launch_metrics_joints(pred, target, N, J, pelvis_mode, mpjpe, pa_mpjpe, accel, (hipStream_t)stream));
+  return 0;
+}
+
+int tepose_metrics_verts(const float* pred_verts, const float* target_verts, int N, float* mpvpe, void* stream) {
+  if (!pred_verts || !target_verts || !mpvpe || N < 1) return TEPOSE_E_ARG;
+  CK(launch_metrics_verts(pred_verts, target_verts, N, mpvpe, (hipStream_t)stream));
+  return 0;
+}
+
+int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int N, float* verts, void* workspace,
+                                 size_t ws_bytes, void* stream) {
+  if (!m || !theta || !verts || !workspace || N < 1) return TEPOSE_E_ARG;
+  if (!m->smpl_packed) return TEPOSE_E_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(workspace, ws_bytes);
+  RegWs w;
+  carve_regressor(N, c, w);
+  if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
+  const float* Bl = m->blob;
+  SmplConsts sc{};
+  sc.J0 = Bl + m->smpl.J0; sc.JS = Bl + m->smpl.JS; sc.blendW = Bl + m->smpl.blendW;
+  sc.lbsW = Bl + m->smpl.lbsW; sc.parents = (const int*)(Bl + m->smpl.parents);
+  sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
+  CK(launch_smpl_prep_aa(sc, theta, N, w.pf, w.amat, s));
+  GemmArgs gv = gemm(w.pf, kBlendK, sc.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
+  CK(launch_gemm(gv, s));
+  CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
+  return 0;
+}
+
 size_t tepose_gemm_workspace_bytes(int N, int K) {
   if (N < 1 || K < 1) return 0;
   return (size_t)round_up(N, 128) * round_up(K, 32) * sizeof(float) + 256;

@@ -89,6 +89,8 @@ struct JregPacked {              // CSR of the optional 17-row evaluation regres
 };
 hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
                             float* posed, float* rotmat, float* theta, hipStream_t s);
+hipError_t launch_smpl_prep_aa(const SmplConsts& c, const float* theta_in, int N, float* pf, float* Amat,
+                               hipStream_t s);
 hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
                             float* verts, hipStream_t s);
 hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const float* verts,
@@ -100,5 +102,10 @@ hipError_t launch_csr_build(const float* dense, int rows, int cols, int* ptr, in
 hipError_t launch_smpl_consts(const float* v_template, const float* shapedirs, const float* posedirs,
                               const float* J_regressor, float* J0, float* JS, float* blendW,
                               hipStream_t s);
+
+// ---------------------------------------------------------------- metrics.hip
+hipError_t launch_metrics_joints(const float* pred, const float* target, int N, int J, int pelvis_mode,
+                                 float* mpjpe, float* pa, float* accel, hipStream_t s);
+hipError_t launch_metrics_verts(const float* pred, const float* target, int N, float* mpvpe, hipStream_t s);
 
 }  // namespace tepose

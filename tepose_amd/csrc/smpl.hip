@@ -142,7 +142,10 @@ __device__ __forceinline__ void rotmat_to_aa(const float R[3][3], float aa[3]) {
 }
 
 // One wave per person, lane = joint (24 active).  xs row = [pose6d 144 | betas 10 | cam 3 | 0 0 0].
-__global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth,
+// mode 0: xs row = regressor state (6D pose, rot6d_to_rotmat).  mode 1: xs row = theta[85]
+// (cam3 | axis-angle 72 | betas 10) and R = Rodrigues(aa) as smplx does for pose2rot=True
+// (GT meshes of MPVPE, lib/utils/eval_utils.py:155-169).
+__global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth, int mode,
                                                         const float* __restrict__ xs, int N,
                                                         float* __restrict__ pf, float* __restrict__ Amat,
                                                         float* __restrict__ posed,
@@ -151,9 +154,29 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= N) return;                       // wave-uniform
-  const float* x = xs + (long)p * kState;
+  const float* x = xs + (long)p * (mode == 0 ? kState : kTheta);
   const int j = lane < kNJ ? lane : 0;
   const bool act = lane < kNJ;
+  float R[3][3];
+  float beta[10];
+  if (mode == 1) {
+    // smplx.lbs.batch_rodrigues: angle = |aa + 1e-8|, R = I + sin K + (1 - cos) K^2
+    const float ax = x[3 + 3 * j], ay = x[4 + 3 * j], az = x[5 + 3 * j];
+    const float ex = ax + 1e-8f, ey = ay + 1e-8f, ez = az + 1e-8f;
+    const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float rx = ax / ang, ry = ay / ang, rz = az / ang;
+    const float sn = sinf(ang), cs = 1.f - cosf(ang);
+    const float K[3][3] = {{0.f, -rz, ry}, {rz, 0.f, -rx}, {-ry, rx, 0.f}};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const float kk = K[r][0] * K[0][cc] + K[r][1] * K[1][cc] + K[r][2] * K[2][cc];
+        R[r][cc] = (r == cc ? 1.f : 0.f) + sn * K[r][cc] + cs * kk;
+      }
+#pragma unroll
+    for (int l = 0; l < 10; ++l) beta[l] = x[75 + l];
+  } else {
   // rot6d_to_rotmat: a1 = x[0::2], a2 = x[1::2]
   const float a1[3] = {x[6 * j + 0], x[6 * j + 2], x[6 * j + 4]};
   const float a2[3] = {x[6 * j + 1], x[6 * j + 3], x[6 * j + 5]};
@@ -165,16 +188,15 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
   const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
   const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2],
                        b1[0] * b2[1] - b1[1] * b2[0]};
-  float R[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) { R[r][0] = b1[r]; R[r][1] = b2[r]; R[r][2] = b3[r]; }
-  float aa[3];
-  rotmat_to_aa(R, aa);
-
-  // rest joint of this lane and of its parent
-  float beta[10];
 #pragma unroll
   for (int l = 0; l < 10; ++l) beta[l] = x[kNPose + l];
+  }
+  float aa[3] = {0.f, 0.f, 0.f};
+  if (theta) rotmat_to_aa(R, aa);
+
+  // rest joint of this lane and of its parent
   float Jr[3];
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc) {
@@ -214,16 +236,18 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
   }
   if (act) {
     float* Ao = Amat + ((long)p * kNJ + j) * 12;
-    float* Ro = rotmat + ((long)p * kNJ + j) * 9;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       Ao[r * 4 + 0] = G[r][0]; Ao[r * 4 + 1] = G[r][1]; Ao[r * 4 + 2] = G[r][2];
       Ao[r * 4 + 3] = G[r][3] - (G[r][0] * Jr[0] + G[r][1] * Jr[1] + G[r][2] * Jr[2]);
-      posed[((long)p * kNJ + j) * 3 + r] = G[r][3];
-      Ro[r * 3 + 0] = R[r][0]; Ro[r * 3 + 1] = R[r][1]; Ro[r * 3 + 2] = R[r][2];
+      if (posed) posed[((long)p * kNJ + j) * 3 + r] = G[r][3];
+      if (rotmat) {
+        float* Ro = rotmat + ((long)p * kNJ + j) * 9;
+        Ro[r * 3 + 0] = R[r][0]; Ro[r * 3 + 1] = R[r][1]; Ro[r * 3 + 2] = R[r][2];
+      }
     }
-    float* th = theta + (long)p * kTheta;
-    th[3 + 3 * j + 0] = aa[0]; th[3 + 3 * j + 1] = aa[1]; th[3 + 3 * j + 2] = aa[2];
+    float* th = theta ? theta + (long)p * kTheta : nullptr;
+    if (th) { th[3 + 3 * j + 0] = aa[0]; th[3 + 3 * j + 1] = aa[1]; th[3 + 3 * j + 2] = aa[2]; }
     float* f = pf + (long)p * kBlendK;
     if (j >= 1) {
 #pragma unroll
@@ -233,10 +257,10 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
     } else {
       f[0] = 1.f;
 #pragma unroll
-      for (int l = 0; l < 10; ++l) { f[1 + l] = beta[l]; th[75 + l] = beta[l]; }
+      for (int l = 0; l < 10; ++l) { f[1 + l] = beta[l]; if (th) th[75 + l] = beta[l]; }
 #pragma unroll
       for (int l = 218; l < kBlendK; ++l) f[l] = 0.f;
-      th[0] = x[154]; th[1] = x[155]; th[2] = x[156];
+      if (th) { th[0] = x[154]; th[1] = x[155]; th[2] = x[156]; }
     }
   }
 }
@@ -361,8 +385,16 @@ hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const f
 hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
                             float* posed, float* rotmat, float* theta, hipStream_t s) {
   if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, xs, N, pf, Amat,
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, 0, xs, N, pf, Amat,
                      posed, rotmat, theta);
+  return hipGetLastError();
+}
+
+hipError_t launch_smpl_prep_aa(const SmplConsts& c, const float* theta_in, int N, float* pf, float* Amat,
+                               hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, 1, theta_in, N, pf,
+                     Amat, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   return hipGetLastError();
 }
 

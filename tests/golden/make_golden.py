@@ -207,6 +207,36 @@ def vibe_case(name, L, H, B, N, seed_w, seed_x):
     print('wrote', name, feat.shape, out['theta'].shape)
 
 
+def metrics_case():
+    """Reference metric code as evaluate.py:413-450 strings it together (eval_utils imports as-is)."""
+    from lib.utils.eval_utils import batch_compute_similarity_transform_torch, compute_error_accel_eval
+    from lib.data_utils._kp_utils import convert_kps
+    out = {}
+    for tag, J, mode in (('lsp14', 14, 0), ('mpii17', 17, 1)):
+        target = torch.from_numpy(synth.normal('met/t' + tag, (60, J, 3), std=0.35))
+        pred = target + torch.from_numpy(synth.normal('met/n' + tag, (60, J, 3), std=0.04))
+        pred[:, :, 1] *= 1.07                                   # scale + rotation the alignment must remove
+        pj, tj = pred.clone().float(), target.clone().float()
+        if mode == 1:
+            pp, tp = pj[:, [-3], :], tj[:, [-3], :]
+        else:
+            pp, tp = (pj[:, [2], :] + pj[:, [3], :]) / 2.0, (tj[:, [2], :] + tj[:, [3], :]) / 2.0
+        pj -= pp
+        tj -= tp
+        mpjpe = torch.sqrt(((pj - tj) ** 2).sum(dim=-1)).numpy().mean(axis=-1) * 1000
+        S1_hat = batch_compute_similarity_transform_torch(pj, tj)
+        pa = torch.sqrt(((S1_hat - tj) ** 2).sum(dim=-1)).numpy().mean(axis=-1) * 1000
+        accel = np.zeros(len(pj))
+        accel[1:-1] = compute_error_accel_eval(joints_pred=pj.numpy(), joints_gt=tj.numpy()) * 1000
+        out.update({tag + '_pred': pred.numpy(), tag + '_target': target.numpy(), tag + '_mpjpe': mpjpe,
+                    tag + '_pa': pa, tag + '_accel': accel})
+    code = np.arange(49, dtype=np.float64)[None, :, None].repeat(3, axis=2)
+    out['spin_to_common'] = convert_kps(code, src='spin', dst='common')[0, :, 0].astype(np.int64)
+    out['spin_to_mpii3d_test'] = convert_kps(code, src='spin', dst='mpii3d_test')[0, :, 0].astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, 'metrics.npz'), **out)
+    print('wrote metrics', out['spin_to_common'], out['spin_to_mpii3d_test'])
+
+
 def geometry_cases(G):
     """Edge vectors for R->aa (each quaternion branch, angle 0, angles near pi about
     each axis), rot6d->R (incl. degenerate input) and projection."""
@@ -257,6 +287,7 @@ def main():
     driver_case(T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
     vibe_case('vibe_L2H128_B2N20', 2, 128, 2, 20, 8, 901)
     vibe_case('vibe_L1H64_B1N5', 1, 64, 1, 5, 9, 902)
+    metrics_case()
     geometry_cases(G)
     # projection vector
     j = torch.from_numpy(synth.normal('geom/j', (4, 14, 3), std=0.5))

@@ -1,0 +1,69 @@
+"""GPU: metrics kernels against values from the reference's eval_utils (golden) and the oracle;
+tolerance 0.01 mm."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tepose_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.mark.parametrize('tag,pel', [('lsp14', 'lsp'), ('mpii17', 'mpii3d')])
+def test_joint_metrics_match_reference(tag, pel):
+    from tepose_amd.metrics import joint_metrics
+    g = np.load(os.path.join(GOLDEN, 'metrics.npz'))
+    m = joint_metrics(torch.from_numpy(g[tag + '_pred']).cuda(), torch.from_numpy(g[tag + '_target']).cuda(), pel)
+    assert np.abs(m['mpjpe'].cpu().numpy() - g[tag + '_mpjpe']).max() < 1e-2
+    assert np.abs(m['pa_mpjpe'].cpu().numpy() - g[tag + '_pa']).max() < 1e-2
+    assert np.abs(m['accel'].cpu().numpy() - g[tag + '_accel']).max() < 1e-2
+
+
+def test_procrustes_edge_cases_vs_oracle():
+    """Reflections, planar and near-degenerate point sets, identical inputs, single-frame clips."""
+    from oracle import tepose_ref as O
+    from tepose_amd.metrics import joint_metrics
+    t = torch.from_numpy(synth.normal('pe/t', (40, 14, 3), std=0.3)).double()
+    p = t.clone() + torch.from_numpy(synth.normal('pe/n', (40, 14, 3), std=0.02)).double()
+    p[0] = t[0]                                  # identical -> 0
+    p[1] = t[1] * torch.tensor([1., 1., -1.])    # mirrored: best proper rotation, not a reflection
+    t[2, :, 2] = 0.0; p[2, :, 2] = 0.0           # planar sets (rank-2 covariance)
+    p[3] = t[3] * 3.0 + 1.0                      # pure similarity -> PA error 0
+    m = joint_metrics(p.float().cuda(), t.float().cuda())
+    ref = O.joint_metrics(p, t)
+    assert abs(float(m['mpjpe'][0])) < 1e-4 and abs(float(m['pa_mpjpe'][3])) < 1e-2
+    assert np.abs(m['pa_mpjpe'].cpu().numpy() - ref['pa_mpjpe'].numpy()).max() < 1e-2
+    assert np.abs(m['mpjpe'].cpu().numpy() - ref['mpjpe'].numpy()).max() < 1e-2
+    one = joint_metrics(p[:1].float().cuda(), t[:1].float().cuda())
+    assert float(one['accel'][0]) == 0.0
+
+
+def test_mpvpe_and_clip_records():
+    from oracle import tepose_ref as O
+    from tepose_amd.metrics import clip_record, gt_vertices, joint_metrics, reduce_records, vertex_metric
+    from tepose_amd.testing import build_model
+    smpl_np = synth.synthetic_smpl(0)
+    model, _, _ = build_model(1, 64, seed=1, device='cuda', smpl_np=smpl_np)
+    theta = synth.synthetic_windows(1, 30, 31)[0, :29, 2048:]              # [29,85] plausible thetas
+    gt = gt_vertices(model, torch.from_numpy(theta).cuda())
+    ref = O.verts_from_theta(smpl_np, theta)
+    assert (gt.cpu() - ref).abs().max() < 1e-4
+    pred = gt + 0.01
+    mp = vertex_metric(pred, gt)
+    assert np.abs(mp.cpu().numpy() - 1000 * 0.01 * 3 ** 0.5).max() < 1e-2
+    # records -> frame-weighted means as evaluate.py:461
+    recs, all_mpjpe, all_acc = [], [], []
+    for cid, n in enumerate((12, 5, 29)):
+        t = torch.from_numpy(synth.normal('rec/t%d' % cid, (n, 14, 3), std=0.3)).cuda()
+        p = t + torch.from_numpy(synth.normal('rec/n%d' % cid, (n, 14, 3), std=0.03)).cuda()
+        m = joint_metrics(p, t)
+        recs.append(clip_record(cid, m, mpvpe=mp[:n]))
+        all_mpjpe.append(m['mpjpe'].cpu().numpy())
+        all_acc.append(m['accel'].cpu().numpy()[1:-1])
+    out = reduce_records(torch.stack(recs))
+    assert abs(out['mpjpe'] - np.mean(np.concatenate(all_mpjpe))) < 1e-3
+    assert abs(out['accel_err'] - np.mean(np.concatenate(all_acc))) < 1e-3
+    assert 'mpvpe' in out

@@ -151,3 +151,15 @@ def test_oracle_vibe_matches_reference_golden(name, smpl_np):
     assert np.abs(out['kp_3d'].numpy().reshape(B, N, 14, 3) - g['kp_3d']).max() < 2e-5
     assert np.abs(out['rotmat'].numpy().reshape(B, N, 24, 3, 3) - g['rotmat']).max() < 2e-5
     assert np.abs(out['verts'].numpy().reshape(B, N, 6890, 3)[:, :, ::53] - g['verts_sub']).max() < 2e-5
+
+
+def test_oracle_metrics_match_reference_golden():
+    g = np.load(os.path.join(GOLDEN, 'metrics.npz'))
+    from tepose_amd.metrics import SPIN_TO_COMMON, SPIN_TO_MPII3D_TEST
+    assert list(g['spin_to_common']) == SPIN_TO_COMMON
+    assert list(g['spin_to_mpii3d_test']) == SPIN_TO_MPII3D_TEST
+    for tag, pel in (('lsp14', 'lsp'), ('mpii17', 'mpii3d')):
+        m = O.joint_metrics(torch.from_numpy(g[tag + '_pred']), torch.from_numpy(g[tag + '_target']), pel)
+        assert np.abs(m['mpjpe'].numpy() - g[tag + '_mpjpe']).max() < 1e-3      # mm
+        assert np.abs(m['pa_mpjpe'].numpy() - g[tag + '_pa']).max() < 1e-2
+        assert np.abs(m['accel'].numpy() - g[tag + '_accel']).max() < 1e-3
