@@ -1,0 +1,65 @@
+"""Readers for the reference's on-disk formats on the evaluation path.
+
+No sample of these files exists in the reference repo (they are produced by its offline
+preprocessing or are licence-gated downloads), so the layouts follow the code that writes and
+reads them: `*_db.pt` = joblib dict of per-frame arrays (lib/data_utils/threedpw_utils.py:47-58,
+147-159), `*_pseudotheta.pt` = joblib [N,85] array (lib/data_utils/pseudo_theta.py:102-105),
+checkpoints = torch dict with 'gen_state_dict' (lib/core/trainer.py:393-404)."""
+from collections import OrderedDict
+
+import numpy as np
+
+
+def split_db_into_clips(db, pseudotheta, target_action='', mpii3d=False):
+    """evaluate.py:171-206: group frames by `vid_name` (np.unique order), keep `valid` frames,
+    force the pseudo-theta camera to [1,0,0].  Returns OrderedDict name -> dict of arrays."""
+    names = db['vid_name']
+    pse = np.array(pseudotheta, dtype=np.float32, copy=True)
+    pse[:, :3] = np.array([1., 0., 0.], dtype=np.float32)
+    clips = OrderedDict()
+    for u in np.unique(names):
+        if target_action != '' and target_action not in u:
+            continue
+        idx = names == u
+        valids = db['valid'][idx].astype(bool) if 'valid' in db else np.ones(int(idx.sum()), dtype=bool)
+        c = {'features': db['features'][idx][valids], 'joints3D': db['joints3D'][idx][valids],
+             'theta_pseu': pse[idx][valids]}
+        if mpii3d:
+            c['pose'] = np.zeros((len(valids), 72))
+            c['shape'] = np.zeros((len(valids), 10))
+            c['valid_i'] = db['valid_i'][idx][valids]
+        else:
+            c['pose'] = db['pose'][idx][valids]
+            c['shape'] = db['shape'][idx][valids]
+        clips[str(u)] = c
+    return clips
+
+
+def load_eval_db(db_path, pseudotheta_path, target_action=''):
+    import joblib
+    return split_db_into_clips(joblib.load(db_path), joblib.load(pseudotheta_path), target_action,
+                               mpii3d='mpii3d' in str(db_path))
+
+
+def load_generator_state_dict(path, map_location='cpu'):
+    """checkpoint['gen_state_dict'] with a DataParallel 'module.' prefix stripped
+    (evaluate.py:121-124, lib/utils/utils.py:40-45)."""
+    import torch
+    ckpt = torch.load(path, map_location=map_location)
+    sd = ckpt['gen_state_dict'] if 'gen_state_dict' in ckpt else ckpt
+    return OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in sd.items())
+
+
+def synthetic_eval_db(lengths, seed=0, joints=49):
+    """Synthetic stand-in with the schema of a 3DPW `*_db.pt` + `*_pseudotheta.pt` pair."""
+    from . import synth
+    n = int(sum(lengths))
+    names = np.concatenate([np.array(['clip_%02d' % i] * int(l)) for i, l in enumerate(lengths)])
+    w = synth.synthetic_windows(1, n, 9000 + seed)[0]
+    theta = synth.synthetic_windows(1, n + 1, 9100 + seed)[0, :n, 2048:]
+    db = {'vid_name': names, 'features': w[:, :2048].copy(),
+          'joints3D': synth.normal('db%d/j3d' % seed, (n, joints, 3), std=0.3),
+          'pose': theta[:, 3:75].copy(), 'shape': theta[:, 75:].copy(),
+          'valid': np.ones(n, dtype=np.float32)}
+    pse = synth.synthetic_windows(1, n + 1, 9200 + seed)[0, :n, 2048:].copy()
+    return db, pse

@@ -1,0 +1,66 @@
+"""Clip-sharded evaluation: the reference's evaluate.py:209-462 flow on one or more GPUs.
+
+Per clip (evaluate.py:214-269): frames 0..T-2 come from the VIBE bootstrap model run on the
+first T frames, frames T-1.. from the autoregressive TePose windows whose theta slots start
+from the pseudo-theta file; then joints are converted / pelvis-aligned and MPJPE, PA-MPJPE,
+acceleration error and MPVPE are taken per frame (evaluate.py:394-457).  Clips are independent:
+each rank processes its share (tepose_amd.distributed.partition_clips), all its clips in
+lock-step, and rank 0 gathers one fixed-size record per clip.
+"""
+import torch
+
+from . import distributed as D
+from . import metrics as M
+from .driver import run_clips
+
+
+@torch.no_grad()
+def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='3dpw', rank=0, world=1):
+    """clips: OrderedDict name -> dict(features[N,2048], joints3D[N,J,3], theta_pseu[N,85], pose, shape).
+    Returns ([n_local_clips, 8] float64 record tensor, list of local clip indices)."""
+    dev = next(model.parameters()).device
+    T = int(seqlen)
+    names = list(clips.keys())
+    lengths = [len(clips[n]['features']) for n in names]
+    mine = D.partition_clips(lengths, world)[rank]
+    mine = [i for i in mine if lengths[i] >= T]                       # evaluate.py:226-227
+    if not mine:
+        return torch.zeros(0, 8, dtype=torch.float64, device=dev), mine
+    feats = [torch.as_tensor(clips[names[i]]['features'], dtype=torch.float32, device=dev) for i in mine]
+    inits = [torch.as_tensor(clips[names[i]]['theta_pseu'][:T - 1], dtype=torch.float32, device=dev) for i in mine]
+    # bootstrap: VIBE over the first T frames of every clip, keep frames 0..T-2 (evaluate.py:233-245)
+    boot = model_vibe(torch.stack([f[:T] for f in feats]), J_regressor=J_regressor)[-1]
+    seq = run_clips(model, feats, inits, T, J_regressor=J_regressor, keep=('kp_3d', 'verts'))
+    recs = []
+    for s, i in enumerate(mine):
+        c = clips[names[i]]
+        pred_j3d = torch.cat([boot['kp_3d'][s, :T - 1], seq[s]['kp_3d']], dim=0)
+        pred_verts = torch.cat([boot['verts'][s, :T - 1], seq[s]['verts']], dim=0)
+        target = torch.as_tensor(c['joints3D'], dtype=torch.float32, device=dev)
+        valid_map = None
+        if dataset == 'mpii3d':
+            idx = torch.tensor(M.SPIN_TO_MPII3D_TEST, device=dev)
+            target, pred_j3d = target[:, idx], pred_j3d[:, idx]
+            vm = torch.as_tensor(c['valid_i'][:, 0]).nonzero()[:, 0]
+            valid_map = vm[vm < pred_j3d.shape[0]].to(dev)
+            if valid_map.numel() == 0:
+                continue
+        elif target.shape[1] == 49:
+            target = target[:, torch.tensor(M.SPIN_TO_COMMON, device=dev)]
+        m = M.joint_metrics(pred_j3d, target, 'mpii3d' if dataset == 'mpii3d' else 'lsp')
+        mpvpe = None
+        if dataset == '3dpw':
+            tt = torch.cat([torch.zeros(len(c['pose']), 3), torch.as_tensor(c['pose'], dtype=torch.float32),
+                            torch.as_tensor(c['shape'], dtype=torch.float32)], dim=1).to(dev)
+            mpvpe = M.vertex_metric(pred_verts, M.gt_vertices(model, tt))
+        recs.append(M.clip_record(i, m, mpvpe=mpvpe, valid_map=valid_map))
+    out = torch.stack(recs) if recs else torch.zeros(0, 8, dtype=torch.float64, device=dev)
+    return out, mine
+
+
+def gather_and_reduce(records):
+    """All ranks call; rank 0 gets the metric dict (evaluate.py:459-462), others None."""
+    allr = D.gather_records(records, dst=0)
+    if allr is None:
+        return None
+    return M.reduce_records(allr) if allr.shape[0] else {}
