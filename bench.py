@@ -102,6 +102,8 @@ def main():
     ap.add_argument('--batch', type=int, default=8192, help='windows per GPU per step')
     ap.add_argument('--seqlen', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the multi-process logic on a 1-GPU box)')
+    ap.add_argument('--share-device0', action='store_true', help='testing only: every rank uses cuda:0')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -109,12 +111,17 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    if args.share_device0:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from tepose_amd import synth
     from tepose_amd.testing import build_model
@@ -147,6 +154,10 @@ def main():
         if rank != 0:
             eng.adopt_blob(blob, model)
 
+    # every rank runs the same 4-window probe: identical results prove the broadcast blob is the model
+    with torch.no_grad():
+        probe = model(synthetic_windows_device(4, T, 7, device), J_regressor=J)[0]
+    probe_sum = float(probe['verts'].double().abs().sum().item())
     x = synthetic_windows_device(B, T, 1234 + rank, device)
     torch.cuda.synchronize()
 
@@ -175,7 +186,7 @@ def main():
     t_all = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        rec = torch.tensor([float(rank), elapsed, float(B * args.steps), float(finite)], device=device,
+        rec = torch.tensor([float(rank), elapsed, float(B * args.steps), float(finite), probe_sum], device=device,
                            dtype=torch.float64)
         gathered = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
         dist.gather(rec, gathered, dst=0)     # per-rank records -> rank 0
@@ -208,6 +219,8 @@ def main():
             res['weight_broadcast_ms'] = bcast_ms
             res['weight_blob_MB'] = eng.packed_bytes / 1e6
             res['per_rank'] = [[float(v) for v in g.tolist()] for g in gathered]
+            sums = [r[4] for r in res['per_rank']]
+            res['ranks_agree'] = bool(max(sums) - min(sums) <= 1e-6 * max(sums))
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(state, smpl_np, L, T)
         print(json.dumps(res))
