@@ -142,6 +142,12 @@ int tepose_metrics_joints(const float* pred, const float* target, int N, int J, 
  * pose2rot=True (eval_utils.py:155-169).  Workspace >= tepose_workspace_bytes(m, ceil(N/2), 1). */
 int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int N, float* verts,
                                  void* workspace, size_t ws_bytes, void* stream);
+/* Standalone SMPL forward as callers use the class directly (lib/utils/smooth_pose.py:35-64 with
+ * axis-angle, evaluate.py:279-286 with rotation matrices; lib/models/smpl.py:72-84):
+ * pose2rot != 0: pose[N,72] axis-angle (global orient first); == 0: pose[N,24,3,3].  betas[N,10].
+ * verts[N,6890,3]; joints49[N,49,3] (may be NULL).  Needs tepose_pack_smpl only.          */
+int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, const float* betas, int N,
+                    float* verts, float* joints49, void* workspace, size_t ws_bytes, void* stream);
 /* mpvpe[N] = mean_v |pred_verts - target_verts| in mm (eval_utils.py:173-175).             */
 int tepose_metrics_verts(const float* pred_verts, const float* target_verts, int N, float* mpvpe,
                          void* stream);

@@ -693,6 +693,37 @@ int tepose_metrics_verts(const float* pred_verts, const float* target_verts, int
   return 0;
 }
 
+namespace {
+SmplConsts smpl_consts(const tepose_model* m) {
+  const float* Bl = m->blob;
+  SmplConsts sc{};
+  sc.J0 = Bl + m->smpl.J0; sc.JS = Bl + m->smpl.JS; sc.blendW = Bl + m->smpl.blendW;
+  sc.lbsW = Bl + m->smpl.lbsW; sc.parents = (const int*)(Bl + m->smpl.parents);
+  sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
+  sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
+  sc.xr_val = Bl + m->smpl.xr_val;
+  return sc;
+}
+}  // namespace
+
+int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, const float* betas, int N, float* verts,
+                    float* joints49, void* workspace, size_t ws_bytes, void* stream) {
+  if (!m || !pose || !betas || !verts || !workspace || N < 1) return TEPOSE_E_ARG;
+  if (!m->smpl_packed) return TEPOSE_E_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(workspace, ws_bytes);
+  RegWs w;
+  carve_regressor(N, c, w);
+  if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
+  SmplConsts sc = smpl_consts(m);
+  CK(launch_smpl_prep_pose(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, N, w.pf, w.amat, w.posed, s));
+  GemmArgs gv = gemm(w.pf, kBlendK, sc.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
+  CK(launch_gemm(gv, s));
+  CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
+  if (joints49) CK(launch_smpl_joints(sc, nullptr, verts, w.posed, nullptr, N, joints49, nullptr, s));
+  return 0;
+}
+
 int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int N, float* verts, void* workspace,
                                  size_t ws_bytes, void* stream) {
   if (!m || !theta || !verts || !workspace || N < 1) return TEPOSE_E_ARG;
@@ -702,12 +733,8 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
   RegWs w;
   carve_regressor(N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
-  const float* Bl = m->blob;
-  SmplConsts sc{};
-  sc.J0 = Bl + m->smpl.J0; sc.JS = Bl + m->smpl.JS; sc.blendW = Bl + m->smpl.blendW;
-  sc.lbsW = Bl + m->smpl.lbsW; sc.parents = (const int*)(Bl + m->smpl.parents);
-  sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
-  CK(launch_smpl_prep_aa(sc, theta, N, w.pf, w.amat, s));
+  SmplConsts sc = smpl_consts(m);
+  CK(launch_smpl_prep_pose(sc, 1, theta + 3, kTheta, theta + 75, kTheta, N, w.pf, w.amat, nullptr, s));
   GemmArgs gv = gemm(w.pf, kBlendK, sc.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
   CK(launch_gemm(gv, s));
   CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));

@@ -89,8 +89,9 @@ struct JregPacked {              // CSR of the optional 17-row evaluation regres
 };
 hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
                             float* posed, float* rotmat, float* theta, hipStream_t s);
-hipError_t launch_smpl_prep_aa(const SmplConsts& c, const float* theta_in, int N, float* pf, float* Amat,
-                               hipStream_t s);
+hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pose, int pose_ld,
+                                 const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
+                                 hipStream_t s);
 hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
                             float* verts, hipStream_t s);
 hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const float* verts,

@@ -145,8 +145,14 @@ __device__ __forceinline__ void rotmat_to_aa(const float R[3][3], float aa[3]) {
 // mode 0: xs row = regressor state (6D pose, rot6d_to_rotmat).  mode 1: xs row = theta[85]
 // (cam3 | axis-angle 72 | betas 10) and R = Rodrigues(aa) as smplx does for pose2rot=True
 // (GT meshes of MPVPE, lib/utils/eval_utils.py:155-169).
-__global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth, int mode,
-                                                        const float* __restrict__ xs, int N,
+// mode 2: pose row = 24 rotation matrices (pose2rot=False callers: evaluate.py:279-286).
+struct PrepIn {
+  const float* pose; int pose_ld;     // mode 0: 144 (6D) | mode 1: 72 (axis-angle) | mode 2: 216 (rotmats)
+  const float* betas; int betas_ld;   // 10 per row
+  const float* cam; int cam_ld;       // 3 per row or nullptr (only copied into theta)
+  int mode;
+};
+__global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth, PrepIn in, int N,
                                                         float* __restrict__ pf, float* __restrict__ Amat,
                                                         float* __restrict__ posed,
                                                         float* __restrict__ rotmat,
@@ -154,14 +160,23 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= N) return;                       // wave-uniform
-  const float* x = xs + (long)p * (mode == 0 ? kState : kTheta);
+  const float* x = in.pose + (long)p * in.pose_ld;
+  const float* bx = in.betas + (long)p * in.betas_ld;
+  const int mode = in.mode;
   const int j = lane < kNJ ? lane : 0;
   const bool act = lane < kNJ;
   float R[3][3];
   float beta[10];
-  if (mode == 1) {
+#pragma unroll
+  for (int l = 0; l < 10; ++l) beta[l] = bx[l];
+  if (mode == 2) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) R[r][cc] = x[9 * j + 3 * r + cc];
+  } else if (mode == 1) {
     // smplx.lbs.batch_rodrigues: angle = |aa + 1e-8|, R = I + sin K + (1 - cos) K^2
-    const float ax = x[3 + 3 * j], ay = x[4 + 3 * j], az = x[5 + 3 * j];
+    const float ax = x[3 * j], ay = x[3 * j + 1], az = x[3 * j + 2];
     const float ex = ax + 1e-8f, ey = ay + 1e-8f, ez = az + 1e-8f;
     const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
     const float rx = ax / ang, ry = ay / ang, rz = az / ang;
@@ -174,8 +189,6 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
         const float kk = K[r][0] * K[0][cc] + K[r][1] * K[1][cc] + K[r][2] * K[2][cc];
         R[r][cc] = (r == cc ? 1.f : 0.f) + sn * K[r][cc] + cs * kk;
       }
-#pragma unroll
-    for (int l = 0; l < 10; ++l) beta[l] = x[75 + l];
   } else {
   // rot6d_to_rotmat: a1 = x[0::2], a2 = x[1::2]
   const float a1[3] = {x[6 * j + 0], x[6 * j + 2], x[6 * j + 4]};
@@ -190,8 +203,6 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
                        b1[0] * b2[1] - b1[1] * b2[0]};
 #pragma unroll
   for (int r = 0; r < 3; ++r) { R[r][0] = b1[r]; R[r][1] = b2[r]; R[r][2] = b3[r]; }
-#pragma unroll
-  for (int l = 0; l < 10; ++l) beta[l] = x[kNPose + l];
   }
   float aa[3] = {0.f, 0.f, 0.f};
   if (theta) rotmat_to_aa(R, aa);
@@ -260,7 +271,7 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
       for (int l = 0; l < 10; ++l) { f[1 + l] = beta[l]; if (th) th[75 + l] = beta[l]; }
 #pragma unroll
       for (int l = 218; l < kBlendK; ++l) f[l] = 0.f;
-      if (th) { th[0] = x[154]; th[1] = x[155]; th[2] = x[156]; }
+      if (th && in.cam) { const float* cm = in.cam + (long)p * in.cam_ld; th[0] = cm[0]; th[1] = cm[1]; th[2] = cm[2]; }
     }
   }
 }
@@ -363,12 +374,14 @@ __global__ void __launch_bounds__(256) smpl_joints_kernel(SmplConsts c, JregPack
     float* o3 = kp3d + ((long)p * nj + k) * 3;
     o3[0] = q[0]; o3[1] = q[1]; o3[2] = q[2];
     // spin.py:307-351: t = [cam1, cam2, 2*5000/(224*cam0 + 1e-9)], R = I, centre 0
-    const float* cam = xs + (long)p * kState + 154;
-    const float tz = 10000.f / (224.f * cam[0] + 1e-9f);
-    const float px = q[0] + cam[1], py = q[1] + cam[2], pz = q[2] + tz;
-    float* o2 = kp2d + ((long)p * nj + k) * 2;
-    o2[0] = (5000.f * (px / pz)) / 112.f;
-    o2[1] = (5000.f * (py / pz)) / 112.f;
+    if (kp2d) {
+      const float* cam = xs + (long)p * kState + 154;
+      const float tz = 10000.f / (224.f * cam[0] + 1e-9f);
+      const float px = q[0] + cam[1], py = q[1] + cam[2], pz = q[2] + tz;
+      float* o2 = kp2d + ((long)p * nj + k) * 2;
+      o2[0] = (5000.f * (px / pz)) / 112.f;
+      o2[1] = (5000.f * (py / pz)) / 112.f;
+    }
   }
 }
 
@@ -385,16 +398,20 @@ hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const f
 hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
                             float* posed, float* rotmat, float* theta, hipStream_t s) {
   if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, 0, xs, N, pf, Amat,
+  PrepIn in{xs, kState, xs + kNPose, kState, xs + 154, kState, 0};
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, in, N, pf, Amat,
                      posed, rotmat, theta);
   return hipGetLastError();
 }
 
-hipError_t launch_smpl_prep_aa(const SmplConsts& c, const float* theta_in, int N, float* pf, float* Amat,
-                               hipStream_t s) {
+// mode 1: pose = axis-angle [N,72]; mode 2: pose = rotation matrices [N,24,3,3]
+hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pose, int pose_ld,
+                                 const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
+                                 hipStream_t s) {
   if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, 1, theta_in, N, pf,
-                     Amat, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  PrepIn in{pose, pose_ld, betas, betas_ld, nullptr, 0, mode};
+  hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, in, N, pf, Amat, posed,
+                     (float*)nullptr, (float*)nullptr);
   return hipGetLastError();
 }
 

@@ -123,7 +123,10 @@ class Engine:
             _lib.check(self.lib.tepose_pack_regressor(self.handle, arr, len(keep), self._stream()),
                        'tepose_pack_regressor')
             self._sig_reg = sig
-        smpl = reg.smpl
+        self.pack_smpl(reg.smpl, device)
+
+    def pack_smpl(self, smpl, device):
+        self._ensure_blob(device)
         ts = self._smpl_tensors(smpl)
         sig = (id(smpl),) + _sig(ts)
         if sig != self._sig_smpl:
@@ -206,6 +209,17 @@ class Engine:
             out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
             self._stream()), 'tepose_forward')
         return out
+
+    def smpl_fwd(self, pose, betas, pose2rot):
+        """pose [N,72] (axis-angle) or [N,24,3,3]; betas [N,10] -> verts [N,6890,3], joints [N,49,3]."""
+        N, dev = pose.shape[0], pose.device
+        ws = self.workspace(max(1, (N + 1) // 2), 1, dev)
+        verts = torch.empty((N, NUM_VERTS, 3), dtype=torch.float32, device=dev)
+        joints = torch.empty((N, 49, 3), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.tepose_smpl_fwd(self.handle, 1 if pose2rot else 0, pose.data_ptr(), betas.data_ptr(), N,
+                                            verts.data_ptr(), joints.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            self._stream()), 'tepose_smpl_fwd')
+        return verts, joints
 
     # ------------------------------------------------------------------ VIBE bootstrap encoder
     def pack_vibe_encoder(self, enc, device):

@@ -9,6 +9,7 @@ runs LBS in libtepose_hip.so (tepose_amd/csrc/smpl.hip).
 import os
 import os.path as osp
 import pickle
+from collections import namedtuple
 
 import numpy as np
 import torch
@@ -47,6 +48,8 @@ H36M_TO_J17 = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10, 0, 7, 9]
 H36M_TO_J14 = H36M_TO_J17[:14]
 
 _TABLES = ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights')
+
+SMPLOutput = namedtuple('SMPLOutput', 'vertices global_orient body_pose joints betas full_pose')
 
 
 class _ChStub(object):
@@ -157,9 +160,38 @@ class SMPL(nn.Module):
             else:
                 state_dict.pop(k)   # unknown smplx-owned key: accepted and ignored
 
-    def forward(self, *args, **kwargs):
-        raise RuntimeError('tepose_amd.SMPL is a parameter container; LBS runs inside the model forward '
-                           '(libtepose_hip.so). Use tepose_amd.spin.smpl_forward for a standalone call.')
+    def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=True, **kwargs):
+        """Standalone call as the reference makes it (lib/utils/smooth_pose.py:35-64,
+        evaluate.py:279-286, lib/utils/eval_utils.py:155-169): returns an SMPLOutput with
+        .vertices [N,6890,3] and the wrapper's 49 .joints (lib/models/smpl.py:72-84).
+        LBS runs in libtepose_hip.so on the module's cuda device (or the current one when the
+        module and inputs live on the CPU; results come back on the inputs' device)."""
+        from .engine import Engine
+        ref = next(t for t in (betas, body_pose, global_orient) if t is not None)
+        out_dev = ref.device
+        dev = self.v_template.device if self.v_template.is_cuda else (
+            out_dev if out_dev.type == 'cuda' else torch.device('cuda', torch.cuda.current_device()))
+        n = ref.shape[0]
+
+        def prep(t, default):
+            t = default[:1].expand(n, -1) if t is None else t
+            return t.detach().to(dev, torch.float32)
+        betas_d = prep(betas, self.betas).reshape(n, 10).contiguous()
+        if pose2rot:
+            full = torch.cat([prep(global_orient, self.global_orient).reshape(n, 3),
+                              prep(body_pose, self.body_pose).reshape(n, 69)], dim=1).contiguous()
+        else:
+            full = torch.cat([global_orient.detach().to(dev, torch.float32).reshape(n, 1, 3, 3),
+                              body_pose.detach().to(dev, torch.float32).reshape(n, 23, 3, 3)], dim=1).contiguous()
+        eng = self.__dict__.get('_engine')
+        if eng is None:
+            eng = Engine(1, 64)
+            object.__setattr__(self, '_engine', eng)
+        with torch.cuda.device(dev):
+            eng.pack_smpl(self, dev)
+            verts, joints = eng.smpl_fwd(full, betas_d, bool(pose2rot))
+        return SMPLOutput(vertices=verts.to(out_dev), global_orient=global_orient, body_pose=body_pose,
+                          joints=joints.to(out_dev), betas=betas, full_pose=full.to(out_dev))
 
 
 def get_smpl_faces():

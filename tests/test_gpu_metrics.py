@@ -67,3 +67,27 @@ def test_mpvpe_and_clip_records():
     assert abs(out['mpjpe'] - np.mean(np.concatenate(all_mpjpe))) < 1e-3
     assert abs(out['accel_err'] - np.mean(np.concatenate(all_acc))) < 1e-3
     assert 'mpvpe' in out
+
+
+def test_smpl_module_is_callable_like_the_reference_class():
+    """SMPL(betas, body_pose, global_orient, pose2rot) as smooth_pose.py:35-64 (axis-angle, CPU
+    tensors) and evaluate.py:279-286 (rotation matrices) call it."""
+    from oracle import tepose_ref as O
+    from tepose_amd.smpl import SMPL
+    smpl_np = synth.synthetic_smpl(0)
+    smpl = SMPL.from_tables(smpl_np)                       # stays on the CPU like in smooth_pose.py
+    theta = synth.synthetic_windows(1, 8, 77)[0, :7, 2048:]
+    pose = torch.from_numpy(theta[:, 3:75].copy()).view(7, 24, 3)
+    betas = torch.from_numpy(theta[:, 75:].copy())
+    out = smpl(betas=betas, body_pose=pose[:, 1:], global_orient=pose[:, 0:1])
+    assert out.vertices.device.type == 'cpu' and out.vertices.shape == (7, 6890, 3) and out.joints.shape == (7, 49, 3)
+    s = O.smpl_tensors(smpl_np)
+    R = O.batch_rodrigues(pose.reshape(-1, 3)).view(7, 24, 3, 3)
+    v_ref, posed = O.lbs(s, betas, R)
+    j_ref = O.smpl_joints49(s, v_ref, posed)
+    assert (out.vertices - v_ref).abs().max() < 1e-4
+    assert (out.joints - j_ref).abs().max() < 1e-4
+    out2 = smpl.cuda()(betas=betas.cuda(), body_pose=R[:, 1:].cuda(), global_orient=R[:, 0:1].cuda(), pose2rot=False)
+    assert out2.vertices.is_cuda
+    assert (out2.vertices.cpu() - v_ref).abs().max() < 1e-4
+    assert (out2.joints.cpu() - j_ref).abs().max() < 1e-4
