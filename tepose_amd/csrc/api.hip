@@ -525,7 +525,7 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
     float* sf = w.sf[l & 1];
     float* sr = w.sr[l & 1];
     const float *gf, *grr, *grf;     // gate pre-activation sources of this layer
-    long ldg, stepg_f, stepg_r;      // row stride; per-step offsets are computed below
+    long ldg;                        // row stride of the gate pre-activations
     if (l == 0) {
       gf = w.g0; grr = w.g0 + H3; grf = L >= 2 ? w.g0 + 2 * H3 : w.g0c;
       ldg = (long)T * ld0;
@@ -542,7 +542,6 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
       gf = w.gf; grr = w.grr; grf = w.grf;
       ldg = H3;
     }
-    (void)stepg_f; (void)stepg_r;
     // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
     auto goff = [&](int q) -> long { return l == 0 ? (long)q * ld0 : (long)q * B * H3; };
 
