@@ -26,11 +26,11 @@ constexpr int BM = 128;
 #ifndef TEPOSE_BK
 #define TEPOSE_BK 32
 #endif
-constexpr int BK = TEPOSE_BK;          // K-tile (floats): 32 -> 64/80 KB LDS per block, 16 -> 32/40 KB
-constexpr int SLOTS = BK / 4;          // 16-byte slots per tile row
-constexpr int RPI = 64 / SLOTS;        // tile rows moved by one wave-wide DMA instruction
-constexpr int SWZ_SH = BK == 32 ? 1 : 2;  // rows per 256-B LDS bank row = 2 (BK 32) or 4 (BK 16)
-static_assert(BK == 16 || BK == 32, "K-tile must be 16 or 32");
+#ifndef TEPOSE_BK_GRU
+#define TEPOSE_BK_GRU TEPOSE_BK
+#endif
+constexpr int BK_GEMM = TEPOSE_BK;     // K-tile (floats) of the plain GEMM: 32 -> 64 KB LDS per block
+constexpr int BK_GRU = TEPOSE_BK_GRU;  // K-tile of the GRU step: 32 -> 80 KB, 16 -> 40 KB per block
 #ifndef TEPOSE_GEMM_OCC
 #define TEPOSE_GEMM_OCC 2
 #endif
@@ -66,10 +66,14 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int tilesM, int 
   tn = rem / gm;
 }
 
-template <int WN, bool RELU>
+template <int WN, bool RELU, int BK>
 __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, int M, int m0,
                                          const float* __restrict__ W, int Kp, int n0, float* lds,
                                          f32x16 (&acc)[2][WN]) {
+  static_assert(BK == 16 || BK == 32, "K-tile must be 16 or 32");
+  constexpr int SLOTS = BK / 4;              // 16-byte slots per tile row
+  constexpr int RPI = 64 / SLOTS;            // tile rows moved by one wave-wide DMA instruction
+  constexpr int SWZ_SH = BK == 32 ? 1 : 2;   // rows per 256-B LDS bank row = 2 (BK 32) or 4 (BK 16)
   constexpr int BN = 64 * WN;
   constexpr int NAQ = BM / RPI / 4;          // A-tile DMA instructions per wave
   constexpr int NWQ = BN / RPI / 4;          // W-tile DMA instructions per wave
@@ -186,7 +190,7 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
 // ------------------------------------------------------------------------------ plain GEMM
 template <bool RELU>
 __global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs a, int tilesM, int tilesN) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + 128) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + 128) * BK_GEMM];
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
   const int m0 = tm * BM, n0 = tn * 128;
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  mainloop<2, RELU>(a.A, a.lda, a.M, m0, a.W, a.Kp, n0, lds, acc);
+  mainloop<2, RELU, BK_GEMM>(a.A, a.lda, a.M, m0, a.W, a.Kp, n0, lds, acc);
 #if TEPOSE_ABL == 4
   if (a.scale != 123.f) {
     float sacc = 0.f;
@@ -277,7 +281,7 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 __global__ void __launch_bounds__(256, TEPOSE_GRU_OCC) gru_step_kernel(GruArgs a, int tilesM, int tilesJ) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + 192) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + 192) * BK_GRU];
   const GruDir& d = a.d[blockIdx.y];
   int tm, tj;
   tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesJ, tm, tj);
@@ -289,7 +293,17 @@ __global__ void __launch_bounds__(256, TEPOSE_GRU_OCC) gru_step_kernel(GruArgs a
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][g][e] = 0.f;
-  if (!a.first) mainloop<3, false>(d.hprev, d.ldh, a.M, m0, d.Whh, a.Hp, tj * 192, lds, acc);
+#if TEPOSE_ABL != 5
+  if (!a.first) mainloop<3, false, BK_GRU>(d.hprev, d.ldh, a.M, m0, d.Whh, a.Hp, tj * 192, lds, acc);
+#endif
+#if TEPOSE_ABL == 4
+  {
+    float sacc = 0.f;
+    for (int i = 0; i < 2; ++i) for (int g = 0; g < 3; ++g) for (int e = 0; e < 16; ++e) sacc += acc[i][g][e];
+    if (sacc == 1.2345f) d.hout[0] = sacc;
+    return;
+  }
+#endif
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;

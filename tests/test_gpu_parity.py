@@ -235,3 +235,36 @@ def test_empty_batch_is_rejected(smpl_np):
     model, _, _ = _model(1, 64, 1, smpl_np)
     with pytest.raises(ValueError):
         model(torch.zeros(0, 6, 2133, device='cuda'))
+
+
+def test_input_variants_noncontiguous_half_and_jreg_device(smpl_np):
+    """Callers hand over slice-assigned / float16-round-tripped tensors (lib/dataset/threedpw_test.py:95-96,137)
+    and a CPU J_regressor (evaluate.py:109); all must give the same result as the plain call."""
+    model, _, _ = _model(1, 128, 6, smpl_np)
+    x = _dev(synth.synthetic_windows(5, 6, 50))
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    with torch.no_grad():
+        base = model(x, J_regressor=J)[0]
+        big = torch.zeros(5, 12, 2133, device='cuda')
+        big[:, ::2] = x
+        nc = model(big[:, ::2], J_regressor=J.cuda())[0]            # strided view + GPU regressor
+        xh = x.half()
+        h = model(xh, J_regressor=J)[0]                             # fp16 storage -> .float() inside
+        href = model(xh.float(), J_regressor=J)[0]
+    for k in base:
+        assert torch.equal(base[k], nc[k]), k
+        assert torch.equal(h[k], href[k]), k
+
+
+def test_two_models_in_one_process_do_not_share_state(smpl_np):
+    from oracle import tepose_ref as O
+    a, sa, _ = _model(1, 64, 21, smpl_np)
+    b, sb, _ = _model(2, 128, 22, smpl_np)
+    x = synth.synthetic_windows(3, 4, 60)
+    with torch.no_grad():
+        oa1 = a(_dev(x))[0]['verts'].clone()
+        ob = b(_dev(x))[0]['verts'].clone()
+        oa2 = a(_dev(x))[0]['verts']
+    assert torch.equal(oa1, oa2)
+    assert (ob.cpu() - O.tepose_fwd(sb, smpl_np, x, 2)['verts']).abs().max() < TOL
+    assert (oa1.cpu() - O.tepose_fwd(sa, smpl_np, x, 1)['verts']).abs().max() < TOL
