@@ -18,7 +18,7 @@ struct DirW {                     // one GRU layer/direction inside the blob (fl
 };
 
 struct SmplOff {
-  size_t J0, JS, blendW, lbsW, parents, depth, xr_ptr, xr_idx, xr_val;
+  size_t J0, JS, blendW, lbsW, lbs_cidx, lbs_cval, lbs_nnz, parents, depth, xr_ptr, xr_idx, xr_val;
 };
 
 }  // namespace
@@ -40,6 +40,7 @@ struct tepose_model {
   size_t w1a = 0, b1 = 0, w1b = 0, w2 = 0, b2 = 0, wdec = 0, bdec = 0, init = 0;
   SmplOff smpl{};
   int maxdepth = 0;
+  int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -118,6 +119,9 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
   m->smpl.JS = take(cur, 720);
   m->smpl.blendW = take(cur, (size_t)kBlendN * kBlendK);
   m->smpl.lbsW = take(cur, (size_t)kNV * kNJ);
+  m->smpl.lbs_cidx = take(cur, (size_t)kNV * 4);
+  m->smpl.lbs_cval = take(cur, (size_t)kNV * 4);
+  m->smpl.lbs_nnz = take(cur, 16);
   m->smpl.parents = take(cur, 32);
   m->smpl.depth = take(cur, 32);
   m->smpl.xr_ptr = take(cur, 16);
@@ -255,6 +259,9 @@ int tepose_adopt_blob(tepose_model* m) {
   if (!m->blob) return TEPOSE_E_STATE;
   m->enc_packed = m->reg_packed = m->smpl_packed = m->vibe_packed = true;
   m->maxdepth = kNJ - 1;   // upper bound; chain levels past the real depth are no-ops
+  int max_nnz = kNJ;
+  CK(hipMemcpy(&max_nnz, m->blob + m->smpl.lbs_nnz, sizeof(int), hipMemcpyDeviceToHost));   // set-up time only
+  m->lbs_sparse = max_nnz <= 4 ? 1 : 0;
   return 0;
 }
 
@@ -426,6 +433,11 @@ int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shap
   CK(launch_smpl_consts(v_template, shapedirs, posedirs, J_regressor, B + m->smpl.J0, B + m->smpl.JS,
                         B + m->smpl.blendW, s));
   CK((hipError_t)pack(lbs_weights, kNJ, kNV, kNJ, B + m->smpl.lbsW, kNV, kNJ, 0, 0, 0, 1, s));
+  CK(launch_lbs_compact(lbs_weights, (int*)(B + m->smpl.lbs_cidx), B + m->smpl.lbs_cval, (int*)(B + m->smpl.lbs_nnz), s));
+  int max_nnz = 0;
+  CK(hipMemcpyAsync(&max_nnz, B + m->smpl.lbs_nnz, sizeof(int), hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));                 // pack time only
+  m->lbs_sparse = max_nnz <= 4 ? 1 : 0;
   CK(launch_csr_build(J_regressor_extra, 9, kNV, (int*)(B + m->smpl.xr_ptr), (int*)(B + m->smpl.xr_idx),
                       B + m->smpl.xr_val, 9 * kNV, s));
   m->smpl_packed = true;
@@ -645,7 +657,8 @@ int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_
   }
   SmplConsts sc{};
   sc.J0 = Bl + m->smpl.J0; sc.JS = Bl + m->smpl.JS; sc.blendW = Bl + m->smpl.blendW;
-  sc.lbsW = Bl + m->smpl.lbsW; sc.parents = (const int*)(Bl + m->smpl.parents);
+  sc.lbsW = Bl + m->smpl.lbsW; sc.lbs_cidx = (const int*)(Bl + m->smpl.lbs_cidx); sc.lbs_cval = Bl + m->smpl.lbs_cval;
+  sc.lbs_sparse = m->lbs_sparse; sc.parents = (const int*)(Bl + m->smpl.parents);
   sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
   sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
   sc.xr_val = Bl + m->smpl.xr_val;
@@ -697,7 +710,8 @@ SmplConsts smpl_consts(const tepose_model* m) {
   const float* Bl = m->blob;
   SmplConsts sc{};
   sc.J0 = Bl + m->smpl.J0; sc.JS = Bl + m->smpl.JS; sc.blendW = Bl + m->smpl.blendW;
-  sc.lbsW = Bl + m->smpl.lbsW; sc.parents = (const int*)(Bl + m->smpl.parents);
+  sc.lbsW = Bl + m->smpl.lbsW; sc.lbs_cidx = (const int*)(Bl + m->smpl.lbs_cidx); sc.lbs_cval = Bl + m->smpl.lbs_cval;
+  sc.lbs_sparse = m->lbs_sparse; sc.parents = (const int*)(Bl + m->smpl.parents);
   sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
   sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
   sc.xr_val = Bl + m->smpl.xr_val;

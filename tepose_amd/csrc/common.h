@@ -77,6 +77,9 @@ struct SmplConsts {              // device pointers into the packed blob
   const float* JS;               // [24][3][10]  J_regressor * shapedirs
   const float* blendW;           // [kBlendN][kBlendK]  rows (v,c): [v_template | shapedirs | posedirs^T]
   const float* lbsW;             // [6890][24]
+  const int* lbs_cidx;           // [6890][4] compacted skin weights (joint index)
+  const float* lbs_cval;         // [6890][4]
+  int lbs_sparse;                // 1: every vertex has <= 4 non-zero weights -> compact kernel
   const int* parents;            // [24]
   const int* depth;              // [24]
   int maxdepth;                  // deepest level of the tree (host-computed)
@@ -92,6 +95,7 @@ hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* 
 hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pose, int pose_ld,
                                  const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
                                  hipStream_t s);
+hipError_t launch_lbs_compact(const float* lbsW, int* cidx, float* cval, int* max_nnz, hipStream_t s);
 hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
                             float* verts, hipStream_t s);
 hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const float* verts,

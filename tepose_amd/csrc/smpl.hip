@@ -314,11 +314,83 @@ __global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict_
   }
 }
 
+// Compacted skin weights: the official SMPL model has at most 4 non-zero weights per vertex.
+// compact[v] = 4 x (joint, weight) in ascending joint order (the dense sum's order with its
+// exact zeros removed, so the result is bit-identical); *max_nnz tells the host whether the
+// table qualifies.
+__global__ void __launch_bounds__(256) lbs_compact_kernel(const float* __restrict__ lbsW, int* __restrict__ cidx,
+                                                          float* __restrict__ cval, int* __restrict__ max_nnz) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= kNV) return;
+  int n = 0;
+  for (int j = 0; j < kNJ; ++j) {
+    const float w = lbsW[(long)v * kNJ + j];
+    if (w != 0.f) {
+      if (n < 4) { cidx[v * 4 + n] = j; cval[v * 4 + n] = w; }
+      ++n;
+    }
+  }
+  for (int k = n; k < 4; ++k) { cidx[v * 4 + k] = 0; cval[v * 4 + k] = 0.f; }
+  atomicMax(max_nnz, n);
+}
+
+hipError_t launch_lbs_compact(const float* lbsW, int* cidx, float* cval, int* max_nnz, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(max_nnz, 0, sizeof(int), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lbs_compact_kernel, dim3((kNV + 255) / 256), dim3(256), 0, s, lbsW, cidx, cval, max_nnz);
+  return hipGetLastError();
+}
+
+// thread = vertex with its <= 4 (joint, weight) pairs in registers; persons looped; the 4 joint
+// transforms are gathered from the LDS copy of A (3 x 16-byte reads per joint).  HBM-bound:
+// 12 B in + 12 B out per (person, vertex).
+__global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__ cidx,
+                                                         const float* __restrict__ cval,
+                                                         const float* __restrict__ vposed,
+                                                         const float* __restrict__ Amat, int N,
+                                                         float* __restrict__ verts) {
+  __shared__ __attribute__((aligned(16))) float As[kNJ * 12];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = v < kNV;
+  int jx[4];
+  float wv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { jx[k] = ok ? cidx[v * 4 + k] * 12 : 0; wv[k] = ok ? cval[v * 4 + k] : 0.f; }
+  const int p0 = blockIdx.y * kSkinPG;
+  const int p1 = min(p0 + kSkinPG, N);
+  for (int p = p0; p < p1; ++p) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kNJ * 12; i += 256) As[i] = Amat[(long)p * kNJ * 12 + i];
+    __syncthreads();
+    float t[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) t[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f4 r0 = *(const f4*)(As + jx[k]), r1 = *(const f4*)(As + jx[k] + 4), r2 = *(const f4*)(As + jx[k] + 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t[e] += wv[k] * r0[e]; t[4 + e] += wv[k] * r1[e]; t[8 + e] += wv[k] * r2[e]; }
+    }
+    if (ok) {
+      const float* vp = vposed + (long)p * kVertLd + 3 * v;
+      const float x = vp[0], y = vp[1], z = vp[2];
+      float* o = verts + ((long)p * kNV + v) * 3;
+      o[0] = t[0] * x + t[1] * y + t[2] * z + t[3];
+      o[1] = t[4] * x + t[5] * y + t[6] * z + t[7];
+      o[2] = t[8] * x + t[9] * y + t[10] * z + t[11];
+    }
+  }
+}
+
 hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
                             float* verts, hipStream_t s) {
   if (N <= 0) return hipSuccess;
   dim3 grid((kNV + 255) / 256, (N + kSkinPG - 1) / kSkinPG);
-  hipLaunchKernelGGL(smpl_skin_kernel, grid, dim3(256), 0, s, c.lbsW, vposed, Amat, N, verts);
+  if (c.lbs_sparse)
+    hipLaunchKernelGGL(smpl_skin4_kernel, grid, dim3(256), 0, s, c.lbs_cidx, c.lbs_cval, vposed, Amat, N, verts);
+  else
+    hipLaunchKernelGGL(smpl_skin_kernel, grid, dim3(256), 0, s, c.lbsW, vposed, Amat, N, verts);
   return hipGetLastError();
 }
 

@@ -80,7 +80,7 @@ def _sparse_rows(tag, rows, cols, nnz):
     return m.astype(np.float32)
 
 
-def synthetic_smpl(seed=0):
+def synthetic_smpl(seed=0, skin_nnz=4):
     """Synthetic SMPL tables with the real model's shapes and structure.
 
     v_template[6890,3], shapedirs[6890,3,10], posedirs[207,20670] (smplx layout,
@@ -96,9 +96,9 @@ def synthetic_smpl(seed=0):
     jreg = _sparse_rows(t + 'J', NUM_JOINTS, NUM_VERTS, 40)
     # skin weights: up to 4 joints per vertex
     w = np.zeros((NUM_VERTS, NUM_JOINTS), dtype=np.float64)
-    jidx = (uniform01(t + 'Wj', NUM_VERTS * 4) * NUM_JOINTS).astype(np.int64).reshape(NUM_VERTS, 4)
-    jval = uniform01(t + 'Wv', NUM_VERTS * 4).reshape(NUM_VERTS, 4) ** 2 + 1e-3
-    for k in range(4):
+    jidx = (uniform01(t + 'Wj', NUM_VERTS * skin_nnz) * NUM_JOINTS).astype(np.int64).reshape(NUM_VERTS, skin_nnz)
+    jval = uniform01(t + 'Wv', NUM_VERTS * skin_nnz).reshape(NUM_VERTS, skin_nnz) ** 2 + 1e-3
+    for k in range(skin_nnz):
         np.add.at(w, (np.arange(NUM_VERTS), jidx[:, k]), jval[:, k])
     w /= w.sum(axis=1, keepdims=True)
     return OrderedDict(

@@ -268,3 +268,20 @@ def test_two_models_in_one_process_do_not_share_state(smpl_np):
     assert torch.equal(oa1, oa2)
     assert (ob.cpu() - O.tepose_fwd(sb, smpl_np, x, 2)['verts']).abs().max() < TOL
     assert (oa1.cpu() - O.tepose_fwd(sa, smpl_np, x, 1)['verts']).abs().max() < TOL
+
+
+def test_dense_skin_weight_fallback(smpl_np):
+    """Tables with more than 4 non-zero skin weights per vertex take the dense skinning kernel;
+    the official model's <= 4 take the compacted one.  Both against the oracle."""
+    from oracle import tepose_ref as O
+    from tepose_amd.testing import build_model
+    wide = synth.synthetic_smpl(0, skin_nnz=7)
+    assert int((wide['lbs_weights'] != 0).sum(1).max()) > 4 and int((smpl_np['lbs_weights'] != 0).sum(1).max()) <= 4
+    x = synth.synthetic_windows(3, 4, 71)
+    for tables in (wide, smpl_np):
+        model, state, _ = build_model(1, 64, seed=2, device='cuda', smpl_np=tables)
+        with torch.no_grad():
+            out = model(_dev(x))[0]
+        ref = O.tepose_fwd(state, tables, x, 1)
+        assert (out['verts'].cpu() - ref['verts']).abs().max() < TOL
+        assert (out['kp_3d'].cpu() - ref['kp_3d']).abs().max() < TOL
