@@ -221,6 +221,23 @@ def main():
             res['per_rank'] = [[float(v) for v in g.tolist()] for g in gathered]
             sums = [r[4] for r in res['per_rank']]
             res['ranks_agree'] = bool(max(sums) - min(sums) <= 1e-6 * max(sums))
+        if world == 1:
+            # the other BASELINE.json shapes, outside the timed region (informational, not `value`)
+            extra = {}
+            for name, (b, t, reps) in {'b64_T16': (64, 16, 50), 'b1_T16': (1, 16, 200), 'b1_T32_stream': (1, 32, 200),
+                                       'b1_T6': (1, 6, 200)}.items():
+                xe = synthetic_windows_device(b, t, 77, device)
+                with torch.no_grad():
+                    for _ in range(5):
+                        model(xe, J_regressor=J)
+                    torch.cuda.synchronize()
+                    te = time.perf_counter()
+                    for _ in range(reps):
+                        model(xe, J_regressor=J)
+                    torch.cuda.synchronize()
+                ms = (time.perf_counter() - te) / reps * 1e3
+                extra[name] = {'ms_per_forward': ms, 'windows_per_s': b / ms * 1e3}
+            res['other_shapes'] = extra
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(state, smpl_np, L, T)
         print(json.dumps(res))

@@ -131,6 +131,18 @@ __global__ void __launch_bounds__(256) skinny_gru_kernel(GruArgs a) {
   const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
   const int r16 = lane & 15, q = lane >> 4;
   const int Hp = a.Hp;
+  // epilogue operands first: their latency hides under the weight stream below
+  const int e = threadIdx.x >> 6;
+  const int j = j0 + r16;
+  const float br = d.bhh[j], bz = d.bhh[Hp + j], bn = d.bhh[2 * Hp + j];
+  float gr[MT], gz[MT], gn[MT], hp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = min(m0 + i * 16 + q * 4 + e, a.M - 1);
+    const float* gi = d.gi + (long)row * d.ldgi + j;
+    gr[i] = gi[0]; gz[i] = gi[Hp]; gn[i] = gi[2 * Hp];
+    hp[i] = a.first ? 0.f : d.hprev[(long)row * d.ldh + j];
+  }
   if (!a.first) {
     const float* ap[MT];
     const float* wp[3];
@@ -148,12 +160,9 @@ __global__ void __launch_bounds__(256) skinny_gru_kernel(GruArgs a) {
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[((wave * MT * 3 + i * 3 + g) * 4 + e) * 64 + lane] = core.acc[i][g][e];
+        for (int ee = 0; ee < 4; ++ee) red[((wave * MT * 3 + i * 3 + g) * 4 + ee) * 64 + lane] = core.acc[i][g][ee];
   }
   __syncthreads();
-  const int e = threadIdx.x >> 6;
-  const int j = j0 + r16;
-  const float br = d.bhh[j], bz = d.bhh[Hp + j], bn = d.bhh[2 * Hp + j];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float hr = 0.f, hz = 0.f, hn = 0.f;
@@ -167,12 +176,10 @@ __global__ void __launch_bounds__(256) skinny_gru_kernel(GruArgs a) {
     }
     const int row = m0 + i * 16 + q * 4 + e;
     if (row < a.M) {
-      const float* gi = d.gi + (long)row * d.ldgi + j;
-      const float rg = sk_sigmoid(gi[0] + (hr + br));
-      const float zg = sk_sigmoid(gi[Hp] + (hz + bz));
-      const float ng = sk_tanh(gi[2 * Hp] + rg * (hn + bn));
-      const float hp = a.first ? 0.f : d.hprev[(long)row * d.ldh + j];
-      d.hout[(long)row * d.ldo + j] = (1.f - zg) * ng + zg * hp;
+      const float rg = sk_sigmoid(gr[i] + (hr + br));
+      const float zg = sk_sigmoid(gz[i] + (hz + bz));
+      const float ng = sk_tanh(gn[i] + rg * (hn + bn));
+      d.hout[(long)row * d.ldo + j] = (1.f - zg) * ng + zg * hp[i];
     }
   }
 }
