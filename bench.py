@@ -102,6 +102,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8192, help='windows per GPU per step')
     ap.add_argument('--seqlen', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the informational small-batch shapes (use under rocprofv3 --pmc)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the multi-process logic on a 1-GPU box)')
     ap.add_argument('--share-device0', action='store_true', help='testing only: every rank uses cuda:0')
     args = ap.parse_args()
@@ -221,7 +222,7 @@ def main():
             res['per_rank'] = [[float(v) for v in g.tolist()] for g in gathered]
             sums = [r[4] for r in res['per_rank']]
             res['ranks_agree'] = bool(max(sums) - min(sums) <= 1e-6 * max(sums))
-        if world == 1:
+        if world == 1 and not args.no_extra:
             # the other BASELINE.json shapes, outside the timed region (informational, not `value`)
             extra = {}
             for name, (b, t, reps) in {'b64_T16': (64, 16, 50), 'b1_T16': (1, 16, 200), 'b1_T32_stream': (1, 32, 200),
