@@ -1,0 +1,91 @@
+"""End-to-end clip-sharded evaluation (the reference's evaluate.py:209-462 flow) on MI355X.
+
+    python tools/evaluate_clips.py                       # synthetic 3DPW-like database, 1 GPU
+    python -m torch.distributed.run --nproc-per-node 8 tools/evaluate_clips.py
+    python tools/evaluate_clips.py --db data/preprocessed_data/3dpw_test_db.pt \
+        --pseudotheta data/preprocessed_data/3dpw_test_pseudotheta.pt --ckpt <tepose.pth.tar> --vibe-ckpt <vibe.pth.tar>
+
+Real files are licence-gated and absent from this repo; without them the run uses random-init
+weights of the published architecture (n_layers=2, hidden=1024, seqlen=6 as evaluate.py:141
+hard-codes) and a synthetic database with the `*_db.pt` schema, so the numbers that mean
+something are the throughput ones.  Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tepose_amd import synth  # noqa: E402
+from tepose_amd.data import load_eval_db, load_generator_state_dict, split_db_into_clips, synthetic_eval_db  # noqa: E402
+from tepose_amd.evaluate import evaluate_clips, gather_and_reduce  # noqa: E402
+from tepose_amd.smpl import SMPL  # noqa: E402
+from tepose_amd.testing import build_model  # noqa: E402
+from tepose_amd.vibe import VIBE  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--db'); ap.add_argument('--pseudotheta'); ap.add_argument('--ckpt'); ap.add_argument('--vibe-ckpt')
+    ap.add_argument('--dataset', default='3dpw', choices=['3dpw', 'h36m', 'mpii3d'])
+    ap.add_argument('--seqlen', type=int, default=6)
+    ap.add_argument('--clips', type=int, default=37, help='synthetic database: number of clips')
+    ap.add_argument('--min-len', type=int, default=300); ap.add_argument('--max-len', type=int, default=1800)
+    ap.add_argument('--backend', default='nccl')
+    args = ap.parse_args()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, device_id=dev) if args.backend == 'nccl' else dist.init_process_group(args.backend)
+    T = args.seqlen
+    smpl_np = synth.synthetic_smpl(0)
+    if args.db:
+        clips = load_eval_db(args.db, args.pseudotheta)
+    else:
+        lens = (args.min_len + (args.max_len - args.min_len) * synth.uniform01('evalclips', args.clips)).astype(int)
+        db, pse = synthetic_eval_db(list(lens), seed=0)
+        clips = split_db_into_clips(db, pse)
+    model, _, _ = build_model(2, 1024, seed=0, device=dev, smpl_np=smpl_np, seqlen=T)
+    vstate = synth.synthetic_vibe_state_dict(2, 1024, 1)
+    mean = {'pose': vstate['regressor.init_pose'][0], 'shape': vstate['regressor.init_shape'][0],
+            'cam': vstate['regressor.init_cam'][0]}
+    vibe = VIBE(seqlen=T, n_layers=2, hidden_size=1024, add_linear=True, use_residual=True, pretrained='',
+                smpl=SMPL.from_tables(smpl_np), smpl_mean_params=mean)
+    sd = vibe.state_dict()
+    for k, v in vstate.items():
+        sd[k] = torch.from_numpy(v)
+    vibe.load_state_dict(sd)
+    if args.ckpt:
+        model.load_state_dict(load_generator_state_dict(args.ckpt), strict=True)          # evaluate.py:121-124
+    if args.vibe_ckpt:
+        vibe.load_state_dict(load_generator_state_dict(args.vibe_ckpt), strict=False)     # evaluate.py:103-105
+    vibe = vibe.to(dev).eval()
+    J = torch.from_numpy(smpl_np['J_regressor_h36m']) if args.dataset != 'mpii3d' else None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=rank, world=world)
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    res = gather_and_reduce(recs)
+    if rank == 0:
+        frames = int(sum(len(c['features']) for c in clips.values()))
+        out = {'clips': len(clips), 'frames': frames, 'seqlen': T, 'n_gpus': world, 'seconds': float(el.item()),
+               'frames_per_s': frames / float(el.item()), 'metrics_mm': res,
+               'data': 'real' if args.db else 'synthetic db + random-init weights (metric values are meaningless)'}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
