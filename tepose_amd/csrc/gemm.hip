@@ -243,9 +243,17 @@ int skinny_max_m() {
   return v;
 }
 
+static int skinny_max_m_gemm() {
+  static const int v = [] {
+    const char* e = getenv("TEPOSE_SKINNY_MAX_M_GEMM");
+    return e ? atoi(e) : skinny_max_m();
+  }();
+  return v;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (a.M <= skinny_max_m()) return launch_skinny_gemm(a, s);
+  if (a.M <= skinny_max_m_gemm()) return launch_skinny_gemm(a, s);
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + 127) / 128;
   dim3 grid(tilesM * tilesN), block(256);
   if (a.relu_a)

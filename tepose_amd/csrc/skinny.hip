@@ -77,14 +77,19 @@ struct SkinnyCore {
   }
 };
 
+#ifndef TEPOSE_SK_NW1
+#define TEPOSE_SK_NW1 4
+#endif
+constexpr int SK_NW1 = TEPOSE_SK_NW1;   // waves per block of the M <= 16 kernels (K split that many ways)
+
 struct SkinnyGemmArgs {
   GemmArgs g;
   int n_alloc;   // packed W rows that may be read (round_up(N,128))
 };
 
-template <int MT, int U>
-__global__ void __launch_bounds__(256) skinny_gemm_kernel(SkinnyGemmArgs sa) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MT * 3 * 256];
+template <int MT, int U, int NW>
+__global__ void __launch_bounds__(64 * NW) skinny_gemm_kernel(SkinnyGemmArgs sa) {
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
   const GemmArgs& a = sa.g;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 48, m0 = blockIdx.y * 16 * MT;
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(SkinnyGemmArgs sa) {
   for (int t = 0; t < 3; ++t) wp[t] = a.W + (long)min(n0 + t * 16 + r16, sa.n_alloc - 1) * a.Kp + 4 * q;
   const int NC = a.Kp / 16;
   SkinnyCore<MT, U> core;
-  core.run(ap, wp, (wave * NC) / 4, ((wave + 1) * NC) / 4, a.relu_a != 0);
+  core.run(ap, wp, (wave * NC) / NW, ((wave + 1) * NC) / NW, a.relu_a != 0);
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -105,6 +110,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(SkinnyGemmArgs sa) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[((wave * MT * 3 + i * 3 + t) * 4 + e) * 64 + lane] = core.acc[i][t][e];
   __syncthreads();
+  if (NW > 4 && threadIdx.x >= 256) return;   // 4 x 64 threads finish the 16x16 tiles
   const int e = threadIdx.x >> 6;          // accumulator register of the element this thread finishes
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -112,7 +118,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(SkinnyGemmArgs sa) {
     for (int t = 0; t < 3; ++t) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += red[((w * MT * 3 + i * 3 + t) * 4 + e) * 64 + lane];
+      for (int w = 0; w < NW; ++w) v += red[((w * MT * 3 + i * 3 + t) * 4 + e) * 64 + lane];
       const int row = m0 + i * 16 + q * 4 + e, col = n0 + t * 16 + r16;
       if (row < a.M && col < a.N) {
         if (a.bias) v += a.bias[col];
@@ -123,16 +129,16 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(SkinnyGemmArgs sa) {
   }
 }
 
-template <int MT, int U>
-__global__ void __launch_bounds__(256) skinny_gru_kernel(GruArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MT * 3 * 256];
+template <int MT, int U, int NW>
+__global__ void __launch_bounds__(64 * NW) skinny_gru_kernel(GruArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
   const GruDir& d = a.d[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
   const int r16 = lane & 15, q = lane >> 4;
   const int Hp = a.Hp;
   // epilogue operands first: their latency hides under the weight stream below
-  const int e = threadIdx.x >> 6;
+  const int e = (threadIdx.x >> 6) & 3;
   const int j = j0 + r16;
   const float br = d.bhh[j], bz = d.bhh[Hp + j], bn = d.bhh[2 * Hp + j];
   float gr[MT], gz[MT], gn[MT], hp[MT];
@@ -154,7 +160,7 @@ __global__ void __launch_bounds__(256) skinny_gru_kernel(GruArgs a) {
     for (int g = 0; g < 3; ++g) wp[g] = d.Whh + (long)(rbase + g * 32 + r16) * Hp + 4 * q;
     const int NC = Hp / 16;
     SkinnyCore<MT, U> core;
-    core.run(ap, wp, (wave * NC) / 4, ((wave + 1) * NC) / 4, false);
+    core.run(ap, wp, (wave * NC) / NW, ((wave + 1) * NC) / NW, false);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -163,12 +169,13 @@ __global__ void __launch_bounds__(256) skinny_gru_kernel(GruArgs a) {
         for (int ee = 0; ee < 4; ++ee) red[((wave * MT * 3 + i * 3 + g) * 4 + ee) * 64 + lane] = core.acc[i][g][ee];
   }
   __syncthreads();
+  if (NW > 4 && threadIdx.x >= 256) return;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float hr = 0.f, hz = 0.f, hn = 0.f;
     if (!a.first) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < NW; ++w) {
         hr += red[((w * MT * 3 + i * 3 + 0) * 4 + e) * 64 + lane];
         hz += red[((w * MT * 3 + i * 3 + 1) * 4 + e) * 64 + lane];
         hn += red[((w * MT * 3 + i * 3 + 2) * 4 + e) * 64 + lane];
@@ -188,11 +195,11 @@ hipError_t launch_skinny_gemm(const GemmArgs& g, hipStream_t s) {
   SkinnyGemmArgs sa{g, round_up(g.N, 128)};
   const int nt = (g.N + 47) / 48;
   if (g.M <= 16) {
-    hipLaunchKernelGGL((skinny_gemm_kernel<1, 4>), dim3(nt, 1), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, SK_NW1>), dim3(nt, 1), dim3(64 * SK_NW1), 0, s, sa);
   } else if (g.M <= 32) {
-    hipLaunchKernelGGL((skinny_gemm_kernel<2, 2>), dim3(nt, 1), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL((skinny_gemm_kernel<2, 2, 4>), dim3(nt, 1), dim3(256), 0, s, sa);
   } else {
-    hipLaunchKernelGGL((skinny_gemm_kernel<4, 1>), dim3(nt, (g.M + 63) / 64), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL((skinny_gemm_kernel<4, 1, 4>), dim3(nt, (g.M + 63) / 64), dim3(256), 0, s, sa);
   }
   return hipGetLastError();
 }
@@ -200,11 +207,11 @@ hipError_t launch_skinny_gemm(const GemmArgs& g, hipStream_t s) {
 hipError_t launch_skinny_gru(const GruArgs& a, hipStream_t s) {
   const int jt = a.Hp / 16;
   if (a.M <= 16) {
-    hipLaunchKernelGGL((skinny_gru_kernel<1, 4>), dim3(jt, 1, a.ndir), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_gru_kernel<1, 4, SK_NW1>), dim3(jt, 1, a.ndir), dim3(64 * SK_NW1), 0, s, a);
   } else if (a.M <= 32) {
-    hipLaunchKernelGGL((skinny_gru_kernel<2, 2>), dim3(jt, 1, a.ndir), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_gru_kernel<2, 2, 4>), dim3(jt, 1, a.ndir), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((skinny_gru_kernel<4, 1>), dim3(jt, (a.M + 63) / 64, a.ndir), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_gru_kernel<4, 1, 4>), dim3(jt, (a.M + 63) / 64, a.ndir), dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }

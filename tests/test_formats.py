@@ -1,0 +1,81 @@
+"""CPU: readers of the reference's on-disk formats on fabricated files with the
+schemas the reference code writes/reads (no real sample exists in the reference repo)."""
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tepose_amd import synth
+
+
+def test_smpl_pkl_reader_needs_no_chumpy(tmp_path, monkeypatch):
+    """Official SMPL pickles hold chumpy.ch.Ch objects and a scipy-sparse J_regressor; the reader
+    must recover the plain arrays without importing chumpy."""
+    import scipy.sparse as sp
+    t = synth.synthetic_smpl(0)
+    mod = types.ModuleType('chumpy')
+    sub = types.ModuleType('chumpy.ch')
+
+    class Ch(object):                       # pickled by reference (module, name), state = {'x': array}
+        def __init__(self, x):
+            self.x = x
+    Ch.__module__ = 'chumpy.ch'
+    Ch.__qualname__ = 'Ch'
+    sub.Ch = Ch
+    mod.ch = sub
+    monkeypatch.setitem(sys.modules, 'chumpy', mod)
+    monkeypatch.setitem(sys.modules, 'chumpy.ch', sub)
+    posedirs_raw = t['posedirs'].T.reshape(6890, 3, 207).astype(np.float64)      # file layout [V,3,207]
+    shapedirs_raw = np.concatenate([t['shapedirs'], np.zeros((6890, 3, 290), np.float32)], axis=2)
+    kintree = np.stack([np.where(t['parents'] < 0, 2 ** 32 - 1, t['parents']), np.arange(24)]).astype(np.uint32)
+    d = {'v_template': Ch(t['v_template'].astype(np.float64)), 'shapedirs': Ch(shapedirs_raw),
+         'posedirs': Ch(posedirs_raw), 'J_regressor': sp.csc_matrix(t['J_regressor'].astype(np.float64)),
+         'weights': Ch(t['lbs_weights'].astype(np.float64)), 'kintree_table': kintree,
+         'f': np.zeros((13776, 3), np.uint32)}
+    path = tmp_path / 'SMPL_NEUTRAL.pkl'
+    with open(path, 'wb') as f:
+        pickle.dump(d, f, protocol=2)
+    monkeypatch.delitem(sys.modules, 'chumpy')
+    monkeypatch.delitem(sys.modules, 'chumpy.ch')
+    from tepose_amd.smpl import load_smpl_pkl
+    out = load_smpl_pkl(str(path))
+    assert 'chumpy' not in sys.modules
+    np.testing.assert_allclose(out['v_template'], t['v_template'], rtol=0, atol=0)
+    np.testing.assert_allclose(out['posedirs'], t['posedirs'], rtol=0, atol=0)
+    np.testing.assert_allclose(out['shapedirs'], t['shapedirs'], rtol=0, atol=0)
+    np.testing.assert_allclose(out['J_regressor'], t['J_regressor'], rtol=0, atol=0)
+    np.testing.assert_allclose(out['lbs_weights'], t['lbs_weights'], rtol=0, atol=0)
+    assert list(out['parents'][1:]) == list(t['parents'][1:])
+    assert out['posedirs'].shape == (207, 20670) and out['shapedirs'].shape == (6890, 3, 10)
+
+
+def test_smpl_constructor_paths(tmp_path):
+    from tepose_amd.smpl import SMPL
+    with pytest.raises(FileNotFoundError):
+        SMPL(str(tmp_path), batch_size=64, create_transl=False, gender='male')
+    m = SMPL.from_tables(synth.synthetic_smpl(0))
+    assert int(m.parents[0]) == -1 and m.joint_map.shape == (49,)
+    assert set(k.split('.')[0] for k in m.state_dict()) >= {'v_template', 'shapedirs', 'posedirs', 'J_regressor',
+                                                            'lbs_weights', 'J_regressor_extra', 'betas'}
+
+
+def test_db_split_and_checkpoint_roundtrip(tmp_path):
+    import joblib
+    from tepose_amd.data import load_eval_db, load_generator_state_dict, synthetic_eval_db
+    db, pse = synthetic_eval_db([7, 4, 9], seed=3)
+    db['valid'][2] = 0                                      # an invalid frame is dropped (evaluate.py:186-189)
+    joblib.dump(db, tmp_path / 'x_db.pt')
+    joblib.dump(pse, tmp_path / 'x_pseudotheta.pt')
+    clips = load_eval_db(tmp_path / 'x_db.pt', tmp_path / 'x_pseudotheta.pt')
+    assert [len(c['features']) for c in clips.values()] == [6, 4, 9]
+    assert all((c['theta_pseu'][:, :3] == [1, 0, 0]).all() for c in clips.values())
+    only = load_eval_db(tmp_path / 'x_db.pt', tmp_path / 'x_pseudotheta.pt', target_action='clip_01')
+    assert list(only) == ['clip_01']
+    # checkpoint dict of lib/core/trainer.py:393-401 with a DataParallel prefix
+    sd = {'module.encoder.linear_fwd.bias': torch.ones(3), 'regressor.fc1.bias': torch.zeros(2)}
+    torch.save({'epoch': 1, 'gen_state_dict': sd, 'performance': 50.0}, tmp_path / 'model_best.pth.tar')
+    got = load_generator_state_dict(tmp_path / 'model_best.pth.tar')
+    assert list(got) == ['encoder.linear_fwd.bias', 'regressor.fc1.bias']
