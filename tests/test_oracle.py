@@ -163,3 +163,50 @@ def test_oracle_metrics_match_reference_golden():
         assert np.abs(m['mpjpe'].numpy() - g[tag + '_mpjpe']).max() < 1e-3      # mm
         assert np.abs(m['pa_mpjpe'].numpy() - g[tag + '_pa']).max() < 1e-2
         assert np.abs(m['accel'].numpy() - g[tag + '_accel']).max() < 1e-3
+
+
+def test_lbs_is_affine_in_betas_at_fixed_pose(smpl_np):
+    """verts(beta) = verts(0) + sum_l beta_l * (verts(e_l) - verts(0)): shape blend shapes and the
+    regressed rest joints enter linearly, the pose does not depend on beta."""
+    s = O.smpl_tensors(smpl_np, torch.float64)
+    R = _rand_rot(24, 11).view(1, 24, 3, 3)
+    z = torch.zeros(1, 10, dtype=torch.float64)
+    v0, j0 = O.lbs(s, z, R)
+    beta = torch.from_numpy(synth.normal('aff', (1, 10), std=0.7)).double()
+    v, j = O.lbs(s, beta, R)
+    acc_v, acc_j = v0.clone(), j0.clone()
+    for l in range(10):
+        e = z.clone()
+        e[0, l] = 1.0
+        vl, jl = O.lbs(s, e, R)
+        acc_v += beta[0, l] * (vl - v0)
+        acc_j += beta[0, l] * (jl - j0)
+    assert (acc_v - v).abs().max() < 1e-9 and (acc_j - j).abs().max() < 1e-9
+
+
+def test_lbs_joint_rotation_is_local_to_its_subtree(smpl_np):
+    """Changing R_j moves only vertices with skin weight on j or its descendants (the pose blend
+    shape term aside, which is removed by zeroing posedirs) and only those posed joints."""
+    s = O.smpl_tensors(smpl_np, torch.float64)
+    s['posedirs'] = torch.zeros_like(s['posedirs'])
+    parents = [int(p) for p in smpl_np['parents']]
+    j = 16                                                   # left shoulder: subtree {16,18,20,22}
+    sub = {j}
+    for k in range(24):
+        if parents[k] in sub:
+            sub.add(k)
+    assert sub == {16, 18, 20, 22}
+    betas = torch.from_numpy(synth.normal('loc', (1, 10), std=0.5)).double()
+    R = _rand_rot(24, 12).view(1, 24, 3, 3)
+    v0, p0 = O.lbs(s, betas, R)
+    R2 = R.clone()
+    R2[0, j] = _rand_rot(1, 13)[0]
+    v1, p1 = O.lbs(s, betas, R2)
+    w_sub = s['lbs_weights'][:, sorted(sub)].sum(1)
+    untouched = w_sub == 0
+    assert untouched.any() and (~untouched).any()
+    assert (v1[0, untouched] - v0[0, untouched]).abs().max() < 1e-12
+    assert (v1[0, ~untouched] - v0[0, ~untouched]).abs().max() > 1e-3
+    others = [k for k in range(24) if k not in sub]
+    assert (p1[0, others] - p0[0, others]).abs().max() < 1e-12
+    assert (p1[0, j] - p0[0, j]).abs().max() < 1e-12        # the joint's own position is set by its parent chain
