@@ -80,6 +80,14 @@ struct SkinnyCore {
 #ifndef TEPOSE_SK_NW1
 #define TEPOSE_SK_NW1 4
 #endif
+#ifndef TEPOSE_SK_U4
+#define TEPOSE_SK_U4 1
+#endif
+#ifndef TEPOSE_SK_U2
+#define TEPOSE_SK_U2 2
+#endif
+constexpr int SK_U4 = TEPOSE_SK_U4;     // 16-k chunks per super-chunk of the MT=4 kernels (two super-chunks in flight)
+constexpr int SK_U2 = TEPOSE_SK_U2;     // same for MT=2
 constexpr int SK_NW1 = TEPOSE_SK_NW1;   // waves per block of the M <= 16 kernels (K split that many ways)
 
 struct SkinnyGemmArgs {
@@ -197,9 +205,9 @@ hipError_t launch_skinny_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.M <= 16) {
     hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, SK_NW1>), dim3(nt, 1), dim3(64 * SK_NW1), 0, s, sa);
   } else if (g.M <= 32) {
-    hipLaunchKernelGGL((skinny_gemm_kernel<2, 2, 4>), dim3(nt, 1), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL((skinny_gemm_kernel<2, SK_U2, 4>), dim3(nt, 1), dim3(256), 0, s, sa);
   } else {
-    hipLaunchKernelGGL((skinny_gemm_kernel<4, 1, 4>), dim3(nt, (g.M + 63) / 64), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL((skinny_gemm_kernel<4, SK_U4, 4>), dim3(nt, (g.M + 63) / 64), dim3(256), 0, s, sa);
   }
   return hipGetLastError();
 }
@@ -209,9 +217,9 @@ hipError_t launch_skinny_gru(const GruArgs& a, hipStream_t s) {
   if (a.M <= 16) {
     hipLaunchKernelGGL((skinny_gru_kernel<1, 4, SK_NW1>), dim3(jt, 1, a.ndir), dim3(64 * SK_NW1), 0, s, a);
   } else if (a.M <= 32) {
-    hipLaunchKernelGGL((skinny_gru_kernel<2, 2, 4>), dim3(jt, 1, a.ndir), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_gru_kernel<2, SK_U2, 4>), dim3(jt, 1, a.ndir), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((skinny_gru_kernel<4, 1, 4>), dim3(jt, (a.M + 63) / 64, a.ndir), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_gru_kernel<4, SK_U4, 4>), dim3(jt, (a.M + 63) / 64, a.ndir), dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }
