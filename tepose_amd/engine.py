@@ -267,3 +267,16 @@ def check_input(x):
     if x.dtype != torch.float32:
         x = x.float()
     return x.contiguous()
+
+
+# trailing shape of every output of the regressor, per row
+_OUT_TAIL = {'theta': (-1,), 'verts': (-1, 3), 'kp_2d': (-1, 2), 'kp_3d': (-1, 3), 'rotmat': (-1, 3, 3)}
+
+
+def regroup_outputs(out, lead):
+    """View the regressor's per-row outputs [N, ...] as [*lead, ...] (N = prod(lead)): what the
+    reference does key by key after its regressor call (lib/models/tepose.py:130-145,
+    lib/models/vibe.py:110-115)."""
+    for key, tail in _OUT_TAIL.items():
+        out[key] = out[key].reshape(tuple(lead) + tail)
+    return out

@@ -56,6 +56,19 @@ class Regressor(nn.Module):
             return [eng.regressor_fwd(x, n_iter, use_j)]
 
 
+def warm_start_from_spin(regressor, ckpt_path):
+    """Initialise the regressor from a SPIN checkpoint's 'model' entry, non-strictly, when the file
+    exists -- what TePose.__init__ / VIBE.__init__ do with `pretrained`
+    (lib/models/tepose.py:115-118, lib/models/vibe.py:97-101)."""
+    import os
+    if not ckpt_path or not os.path.isfile(ckpt_path):
+        return False
+    weights = torch.load(ckpt_path, map_location='cpu')['model']
+    regressor.load_state_dict(weights, strict=False)
+    print("=> loaded pretrained model from '%s'" % ckpt_path)
+    return True
+
+
 def projection(pred_joints, pred_camera):
     """lib/models/spin.py:307-320 with R = I and zero camera centre (host-side helper for
     callers; the model forward computes kp_2d on the GPU)."""

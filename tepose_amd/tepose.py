@@ -12,9 +12,9 @@ import os.path as osp
 import torch
 import torch.nn as nn
 
-from .engine import Engine, check_input
+from .engine import Engine, check_input, regroup_outputs
 from .smpl import BASE_DATA_DIR
-from .spin import Regressor
+from .spin import Regressor, warm_start_from_spin
 
 
 class TemporalEncoder(nn.Module):
@@ -51,10 +51,7 @@ class TePose(nn.Module):
                                        _engine=engine)
         kw = {} if smpl_mean_params is None else {'smpl_mean_params': smpl_mean_params}
         self.regressor = Regressor(smpl=smpl, _engine=engine, **kw)
-        if pretrained and os.path.isfile(pretrained):
-            pretrained_dict = torch.load(pretrained)['model']
-            self.regressor.load_state_dict(pretrained_dict, strict=False)
-            print(f'=> loaded pretrained model from \'{pretrained}\'')
+        warm_start_from_spin(self.regressor, pretrained)
 
     def forward(self, input, is_train=False, J_regressor=None):
         x = check_input(input)
@@ -69,10 +66,5 @@ class TePose(nn.Module):
                 return [eng.forward(x, J_regressor)]
             feature = eng.encoder_fwd(x, True).reshape(-1, 2048)
             out = eng.regressor_fwd(feature, 3, None, ws_hint=eng.workspace(batch_size, x.shape[1], x.device))
-        repeat_num = 2
-        out['theta'] = out['theta'].reshape(batch_size, repeat_num, -1)
-        out['verts'] = out['verts'].reshape(batch_size, repeat_num, -1, 3)
-        out['kp_2d'] = out['kp_2d'].reshape(batch_size, repeat_num, -1, 2)
-        out['kp_3d'] = out['kp_3d'].reshape(batch_size, repeat_num, -1, 3)
-        out['rotmat'] = out['rotmat'].reshape(batch_size, repeat_num, -1, 3, 3)
-        return [out]
+        # two predictions per window: y_fwd and y_rec (lib/models/tepose.py:138-145)
+        return [regroup_outputs(out, (batch_size, 2))]

@@ -8,8 +8,8 @@ import os
 import torch
 import torch.nn as nn
 
-from .engine import Engine
-from .spin import Regressor
+from .engine import Engine, regroup_outputs
+from .spin import Regressor, warm_start_from_spin
 
 
 class TemporalEncoder(nn.Module):
@@ -50,20 +50,9 @@ class VIBE(nn.Module):
                                        add_linear=add_linear, use_residual=use_residual, _engine=engine)
         kw = {} if smpl_mean_params is None else {'smpl_mean_params': smpl_mean_params}
         self.regressor = Regressor(smpl=smpl, _engine=engine, **kw)
-        if pretrained and os.path.isfile(pretrained):
-            pretrained_dict = torch.load(pretrained)['model']
-            self.regressor.load_state_dict(pretrained_dict, strict=False)
-            print(f'=> loaded pretrained model from \'{pretrained}\'')
+        warm_start_from_spin(self.regressor, pretrained)
 
     def forward(self, input, J_regressor=None):
-        batch_size, seqlen = input.shape[:2]
-        feature = self.encoder(input)
-        feature = feature.reshape(-1, feature.size(-1))
-        smpl_output = self.regressor(feature, J_regressor=J_regressor)
-        for s in smpl_output:
-            s['theta'] = s['theta'].reshape(batch_size, seqlen, -1)
-            s['verts'] = s['verts'].reshape(batch_size, seqlen, -1, 3)
-            s['kp_2d'] = s['kp_2d'].reshape(batch_size, seqlen, -1, 2)
-            s['kp_3d'] = s['kp_3d'].reshape(batch_size, seqlen, -1, 3)
-            s['rotmat'] = s['rotmat'].reshape(batch_size, seqlen, -1, 3, 3)
-        return smpl_output
+        n_clips, n_frames = input.shape[:2]
+        per_frame = self.encoder(input).reshape(n_clips * n_frames, 2048)
+        return [regroup_outputs(o, (n_clips, n_frames)) for o in self.regressor(per_frame, J_regressor=J_regressor)]
