@@ -152,6 +152,16 @@ int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, cons
 int tepose_metrics_verts(const float* pred_verts, const float* target_verts, int N, float* mpvpe,
                          void* stream);
 
+/* ---- temporal post-filters over one sequence (evaluate.py --filter, demo smoothing) ----------
+ * OneEuro filter (lib/utils/one_euro_filter.py as lib/utils/smooth_pose.py:24-67 drives it:
+ * timestamps = frame indices, x0 = first frame, dx0 = 0): x[N,D] filtered in place.        */
+int tepose_filter_one_euro(float* x, int N, int D, float min_cutoff, float beta, float d_cutoff,
+                           void* stream);
+/* Quaternion slerp smoothing of joint rotations (evaluate.py:32-59): rotmat_in[N,J,3,3] ->
+ * rotmat_out (may alias): sign-continuous quaternions, q_t = slerp(q_{t-1}, q_t, ratio).    */
+int tepose_filter_slerp(const float* rotmat_in, float* rotmat_out, int N, int J, double ratio,
+                        void* stream);
+
 /* ---- building blocks exported for tests and bench.py --------------------------------- */
 /* C[M,N] = (relu_a ? relu(A) : A)[M,K] * W[N,K]^T (+ bias[N]) with the library's own
  * fp32-MFMA kernel.  A rows must be 16-byte aligned (lda % 4 == 0); W is packed on the

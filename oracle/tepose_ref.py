@@ -373,3 +373,86 @@ def verts_from_theta(smpl_np, theta, dtype=torch.float32):
     theta = _t(theta, dtype)
     R = batch_rodrigues(theta[:, 3:75].reshape(-1, 3)).view(-1, 24, 3, 3)
     return lbs(smpl, theta[:, 75:], R)[0]
+
+
+# ---- temporal post-filters (lib/utils/one_euro_filter.py; evaluate.py:32-59) ---------------------
+def one_euro_filter(x, min_cutoff=0.004, beta=0.7, d_cutoff=1.0):
+    """OneEuroFilter driven as lib/utils/smooth_pose.py:28-58 does: t = frame index, x0 = x[0]."""
+    import math
+    import numpy as np
+    x = np.asarray(x, dtype=np.float32)
+    out = x.copy()
+    x_prev, dx_prev = x[0], np.float32(0.0)
+    t_e = np.float32(1.0)
+    for i in range(1, len(x)):
+        r = np.float32(2 * math.pi * d_cutoff) * t_e
+        a_d = r / (r + 1)
+        dx = (x[i] - x_prev) / t_e
+        dx_hat = a_d * dx + (1 - a_d) * dx_prev
+        cutoff = np.float32(min_cutoff) + np.float32(beta) * np.abs(dx_hat)
+        r = np.float32(2 * math.pi) * cutoff * t_e
+        a = r / (r + 1)
+        x_hat = a * x[i] + (1 - a) * x_prev
+        out[i] = x_hat
+        x_prev, dx_prev = x_hat, dx_hat
+    return out
+
+
+def slerp_smooth(R, ratio=0.3):
+    """smooth_pose_mat (evaluate.py:48-59): per joint, sign-continuous quaternions, then
+    q_t = slerp(q_{t-1}, q_t, ratio), back to matrices.  R [N,J,3,3] (numpy, any float)."""
+    import numpy as np
+    R = np.asarray(R, dtype=np.float64)
+    N, J = R.shape[:2]
+    out = np.zeros_like(R)
+    for j in range(J):
+        q = np.zeros((N, 4))
+        for t in range(N):
+            m = R[t, j]
+            tr = np.trace(m)
+            if tr > 0:
+                s = np.sqrt(tr + 1.0) * 2
+                q[t] = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
+            elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+                s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+                q[t] = [(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s]
+            elif m[1, 1] > m[2, 2]:
+                s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+                q[t] = [(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s]
+            else:
+                s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+                q[t] = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
+            # best-fit quaternion = dominant eigenvector of K(R) (transformations.quaternion_from_matrix,
+            # isprecise=False): two power steps on K/3 + I/3 from the direct estimate
+            K = np.array([[m[0, 0] - m[1, 1] - m[2, 2], m[0, 1] + m[1, 0], m[0, 2] + m[2, 0], m[2, 1] - m[1, 2]],
+                          [m[0, 1] + m[1, 0], m[1, 1] - m[0, 0] - m[2, 2], m[1, 2] + m[2, 1], m[0, 2] - m[2, 0]],
+                          [m[0, 2] + m[2, 0], m[1, 2] + m[2, 1], m[2, 2] - m[0, 0] - m[1, 1], m[1, 0] - m[0, 1]],
+                          [m[2, 1] - m[1, 2], m[0, 2] - m[2, 0], m[1, 0] - m[0, 1], m[0, 0] + m[1, 1] + m[2, 2]]])
+            A = K / 3.0 + np.eye(4) / 3.0
+            v = q[t][[1, 2, 3, 0]]
+            for _ in range(2):
+                v = A @ v
+                v /= np.linalg.norm(v)
+            q[t] = v[[3, 0, 1, 2]]
+        for t in range(1, N):                                   # quat_correct
+            if np.linalg.norm(q[t - 1] - q[t]) > np.linalg.norm(q[t - 1] + q[t]):
+                q[t] = -q[t]
+        for t in range(1, N):                                   # quat_smooth
+            q0, q1 = q[t - 1] / np.linalg.norm(q[t - 1]), q[t] / np.linalg.norm(q[t])
+            d = float(np.dot(q0, q1))
+            if abs(abs(d) - 1.0) < 8.881784197001252e-16:
+                q[t] = q0
+                continue
+            if d < 0:
+                d, q1 = -d, -q1
+            ang = np.arccos(d)
+            if abs(ang) < 8.881784197001252e-16:
+                q[t] = q0
+                continue
+            q[t] = (q0 * np.sin((1 - ratio) * ang) + q1 * np.sin(ratio * ang)) / np.sin(ang)
+        for t in range(N):
+            w, x, y, z = q[t] * np.sqrt(2.0 / np.dot(q[t], q[t]))
+            out[t, j] = [[1 - y * y - z * z, x * y - z * w, x * z + y * w],
+                         [x * y + z * w, 1 - x * x - z * z, y * z - x * w],
+                         [x * z - y * w, y * z + x * w, 1 - x * x - y * y]]
+    return out

@@ -754,6 +754,18 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
   return 0;
 }
 
+int tepose_filter_one_euro(float* x, int N, int D, float min_cutoff, float beta, float d_cutoff, void* stream) {
+  if (!x || N < 1 || D < 1) return TEPOSE_E_ARG;
+  CK(launch_one_euro(x, N, D, min_cutoff, beta, d_cutoff, (hipStream_t)stream));
+  return 0;
+}
+
+int tepose_filter_slerp(const float* rotmat_in, float* rotmat_out, int N, int J, double ratio, void* stream) {
+  if (!rotmat_in || !rotmat_out || N < 1 || J < 1) return TEPOSE_E_ARG;
+  CK(launch_slerp_smooth(rotmat_in, rotmat_out, N, J, ratio, (hipStream_t)stream));
+  return 0;
+}
+
 size_t tepose_gemm_workspace_bytes(int N, int K) {
   if (N < 1 || K < 1) return 0;
   return (size_t)round_up(N, 128) * round_up(K, 32) * sizeof(float) + 256;

@@ -113,4 +113,8 @@ hipError_t launch_metrics_joints(const float* pred, const float* target, int N, 
                                  float* mpjpe, float* pa, float* accel, hipStream_t s);
 hipError_t launch_metrics_verts(const float* pred, const float* target, int N, float* mpvpe, hipStream_t s);
 
+// ---------------------------------------------------------------- filters.hip
+hipError_t launch_one_euro(float* x, int N, int D, float min_cutoff, float beta, float d_cutoff, hipStream_t s);
+hipError_t launch_slerp_smooth(const float* in, float* out, int N, int J, double ratio, hipStream_t s);
+
 }  // namespace tepose

@@ -237,6 +237,54 @@ def metrics_case():
     print('wrote metrics', out['spin_to_common'], out['spin_to_mpii3d_test'])
 
 
+def filter_cases():
+    """Reference OneEuroFilter driven as lib/utils/smooth_pose.py:28-58 drives it, and the reference's
+    quaternion utilities strung together as evaluate.py:32-59 (smooth_pose_mat) does."""
+    from lib.utils.one_euro_filter import OneEuroFilter
+    import lib.utils.slerp_filter_utils as SF
+
+    class _Numpy1(object):
+        """The reference's bundled transformations.py calls numpy.array(x, copy=False), which meant
+        "copy only if needed" in the NumPy 1.x it was written for and raises in NumPy 2: give that
+        module (only) the old meaning."""
+
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        @staticmethod
+        def array(obj, *a, **k):
+            if k.get('copy', True) is False:
+                k.pop('copy')
+                return np.asarray(obj, *a, **k)
+            return np.array(obj, *a, **k)
+
+    SF.numpy = _Numpy1()
+    quaternion_from_matrix, quaternion_matrix, quaternion_slerp = (SF.quaternion_from_matrix, SF.quaternion_matrix,
+                                                                   SF.quaternion_slerp)
+    pose = (synth.normal('flt/pose', (50, 24, 3), std=0.4) +
+            0.3 * np.sin(np.arange(50, dtype=np.float32) / 6.0)[:, None, None]).astype(np.float32)
+    f = OneEuroFilter(np.zeros_like(pose[0]), pose[0], min_cutoff=0.004, beta=0.7)
+    hat = np.zeros_like(pose)
+    hat[0] = pose[0]
+    for idx, p in enumerate(pose[1:]):
+        idx += 1
+        hat[idx] = f(np.ones_like(p) * idx, p)
+    R = O.batch_rodrigues(torch.from_numpy(pose.reshape(-1, 3))).view(50, 24, 3, 3).numpy().astype(np.float32)
+    R[7] = R[7] + synth.normal('flt/noise', (24, 3, 3), std=1e-4)          # not exactly orthonormal
+    allq = []
+    for j in range(R.shape[1]):
+        quats = np.array([quaternion_from_matrix(R[i, j, :, :]) for i in range(R.shape[0])])
+        for q in range(1, quats.shape[0]):
+            if np.linalg.norm(quats[q - 1] - quats[q], axis=0) > np.linalg.norm(quats[q - 1] + quats[q], axis=0):
+                quats[q] = -quats[q]
+        for q in range(1, quats.shape[0]):
+            quats[q] = quaternion_slerp(quats[q - 1], quats[q], 0.3)
+        allq.append(np.array([quaternion_matrix(i)[:3, :3] for i in quats]))
+    np.savez_compressed(os.path.join(HERE, 'filters.npz'), pose=pose, pose_hat=hat, R=R,
+                        R_smooth=np.stack(allq, axis=1))
+    print('wrote filters', hat.shape, np.stack(allq, axis=1).shape)
+
+
 def geometry_cases(G):
     """Edge vectors for R->aa (each quaternion branch, angle 0, angles near pi about
     each axis), rot6d->R (incl. degenerate input) and projection."""
@@ -288,6 +336,7 @@ def main():
     vibe_case('vibe_L2H128_B2N20', 2, 128, 2, 20, 8, 901)
     vibe_case('vibe_L1H64_B1N5', 1, 64, 1, 5, 9, 902)
     metrics_case()
+    filter_cases()
     geometry_cases(G)
     # projection vector
     j = torch.from_numpy(synth.normal('geom/j', (4, 14, 3), std=0.5))

@@ -210,3 +210,11 @@ def test_lbs_joint_rotation_is_local_to_its_subtree(smpl_np):
     others = [k for k in range(24) if k not in sub]
     assert (p1[0, others] - p0[0, others]).abs().max() < 1e-12
     assert (p1[0, j] - p0[0, j]).abs().max() < 1e-12        # the joint's own position is set by its parent chain
+
+
+def test_oracle_filters_match_reference_golden():
+    g = np.load(os.path.join(GOLDEN, 'filters.npz'))
+    hat = O.one_euro_filter(g['pose'])
+    assert np.abs(hat - g['pose_hat']).max() < 1e-5
+    Rs = O.slerp_smooth(g['R'], 0.3)
+    assert np.abs(Rs - g['R_smooth']).max() < 1e-5         # direct vs eigen-based matrix->quaternion
