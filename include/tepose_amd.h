@@ -116,6 +116,25 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
                    float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
                    void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- sliding-window driver with cached layer-0 projections ---------------
+ * Consecutive windows of a clip share T-1 frames, and a frame's layer-0 gate pre-activations
+ * x W_ih^T + b_ih (all three directions, 9*Hp floats) do not change once its theta is known
+ * (evaluate.py:248-269).  The caller keeps, per clip, a ring of `ring` >= T-1 frame slots
+ * (slot = frame % ring) plus one row for the newest frame (theta = 0).
+ * tepose_project_frames: one frame per clip: feat row b at feat + b*feat_ld (2048 floats),
+ * theta row at theta + b*theta_ld (85 floats) or theta == NULL for zeros  ->  out + b*out_ld.
+ * workspace >= B*2144*4 bytes.                                                              */
+int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld, const float* theta,
+                          long theta_ld, int B, float* out, long out_ld, void* workspace,
+                          size_t ws_bytes, void* stream);
+/* TePose.forward for the window whose first frame sits in ring slot `first_slot`; clip b's ring
+ * starts at ring_base + b*clip_stride; newest frame's row at newest + b*newest_ld.  Outputs and
+ * workspace as tepose_forward.  Saves the T-fold re-projection (42 % of the FLOPs at T = 16).  */
+int tepose_forward_cached(const tepose_model* m, const float* ring_base, int ring, int first_slot,
+                          long clip_stride, const float* newest, long newest_ld, int B, int T,
+                          const void* jreg_packed, float* theta, float* verts, float* kp_3d,
+                          float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- VIBE bootstrap encoder (lib/models/vibe.py:27-117; used by evaluate.py:89-107,233-245
  * and demo.py:104-130,229-237 to predict the first seqlen-1 frames) ----------------------
  * A handle made by tepose_create_vibe holds: uni-directional GRU(2048 -> hidden, n_layers),

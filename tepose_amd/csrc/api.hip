@@ -488,6 +488,133 @@ int tepose_profile_read(tepose_model* m, double* total_ms, int* n_launches, doub
   return 0;
 }
 
+namespace {
+
+// Where the layer-0 gate pre-activations (x W_ih^T + b_ih, 9Hp columns: fwd | rec_reverse | rec) of a
+// window's frames live.  Regular forward: one buffer, frame t at base + t*frame_stride.  Cached driver:
+// frame t of the window sits in slot (first + t) % ring of a per-clip ring, except the newest frame
+// (theta slots still zero), which has its own buffer.
+struct G0Src {
+  const float* base; long frame_stride, row_stride;
+  int first, ring;                 // ring == 0: no wrap
+  const float* last; long last_ld; // newest frame's projections or nullptr
+  const float* single; long single_ld;   // L == 1: source of the one consumed rec.l0 forward step
+};
+
+int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_train, float* feat, EncWs& w,
+                 hipStream_t s) {
+  const int L = m->L, Hp = m->Hp;
+  const float* Bl = m->blob;
+  const long BT = (long)B * T;
+  const int H3 = 3 * Hp;
+  auto gi0 = [&](int t, int dir, const float*& p, long& ld) {
+    if (src.last && t == T - 1) { p = src.last + (long)dir * H3; ld = src.last_ld; return; }
+    const int slot = src.ring ? (src.first + t) % src.ring : t;
+    p = src.base + (long)slot * src.frame_stride + (long)dir * H3;
+    ld = src.row_stride;
+  };
+  for (int l = 0; l < L; ++l) {
+    const bool top = l == L - 1;
+    float* sf = w.sf[l & 1];
+    float* sr = w.sr[l & 1];
+    const float *gf, *grr, *grf;     // gate pre-activation sources of this layer
+    long ldg;                        // row stride of the gate pre-activations
+    if (l == 0) {
+      gf = grr = grf = nullptr; ldg = 0;      // layer 0 reads through gi0()
+    } else {
+      const float* inf = w.sf[(l - 1) & 1];
+      const float* inr = w.sr[(l - 1) & 1];
+      GemmArgs g1 = gemm(inf, Hp, Bl + m->fwd[l].wih, Hp, w.gf, H3, Bl + m->fwd[l].bih, (int)BT, H3);
+      CK(launch_gemm(g1, s));
+      GemmArgs g2 = gemm(inr, 2 * Hp, Bl + m->rec_r[l].wih, 2 * Hp, w.grr, H3, Bl + m->rec_r[l].bih, (int)BT, H3);
+      CK(launch_gemm(g2, s));
+      GemmArgs g3 = gemm(inr, 2 * Hp, Bl + m->rec_f[l].wih, 2 * Hp, w.grf, H3, Bl + m->rec_f[l].bih,
+                         top ? B : (int)BT, H3);
+      CK(launch_gemm(g3, s));
+      gf = w.gf; grr = w.grr; grf = w.grf;
+      ldg = H3;
+    }
+    // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
+    auto goff = [&](int q) -> long { return (long)q * B * H3; };
+
+    for (int st = 0; st < T; ++st) {
+      GruArgs a{};
+      a.M = B; a.Hp = Hp; a.first = st == 0;
+      int nd = 0;
+      {  // gru_fwd layer l, frame t = st
+        GruDir& d = a.d[nd++];
+        d.Whh = Bl + m->fwd[l].whh; d.bhh = Bl + m->fwd[l].bhh;
+        if (l == 0) gi0(st, 0, d.gi, d.ldgi);
+        else { d.gi = gf + goff(st); d.ldgi = ldg; }
+        if (!top) {
+          d.hprev = sf + (long)(st - 1) * B * Hp; d.ldh = Hp;
+          d.hout = sf + (long)st * B * Hp; d.ldo = Hp;
+        } else {
+          d.hprev = w.pf[(st + 1) & 1]; d.ldh = Hp;
+          d.hout = w.pf[st & 1]; d.ldo = Hp;
+        }
+      }
+      {  // gru_rec layer l, reverse direction: flipped index i = T-1-st (frame st for layer 0)
+        GruDir& d = a.d[nd++];
+        const int i = T - 1 - st;
+        d.Whh = Bl + m->rec_r[l].whh; d.bhh = Bl + m->rec_r[l].bhh;
+        if (l == 0) gi0(st, 1, d.gi, d.ldgi);
+        else { d.gi = grr + goff(i); d.ldgi = ldg; }
+        if (!top) {
+          d.hprev = sr + (long)(i + 1) * B * 2 * Hp + Hp; d.ldh = 2 * Hp;
+          d.hout = sr + (long)i * B * 2 * Hp + Hp; d.ldo = 2 * Hp;
+        } else {
+          d.hprev = w.pr[(st + 1) & 1]; d.ldh = Hp;
+          if (st == T - 1) { d.hout = w.ytop + Hp; d.ldo = 2 * Hp; }
+          else { d.hout = w.pr[st & 1]; d.ldo = Hp; }
+        }
+      }
+      if (!top) {  // gru_rec layer l, forward direction: flipped index i = st (frame T-1-st)
+        GruDir& d = a.d[nd++];
+        d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
+        if (l == 0) gi0(T - 1 - st, 2, d.gi, d.ldgi);
+        else { d.gi = grf + goff(st); d.ldgi = ldg; }
+        d.hprev = sr + (long)(st - 1) * B * 2 * Hp; d.ldh = 2 * Hp;
+        d.hout = sr + (long)st * B * 2 * Hp; d.ldo = 2 * Hp;
+      }
+      a.ndir = nd;
+      CK(launch_gru_step(a, s));
+    }
+    if (top) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
+      GruArgs a{};
+      a.M = B; a.Hp = Hp; a.first = 1; a.ndir = 1;
+      GruDir& d = a.d[0];
+      d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
+      if (l == 0) { d.gi = src.single; d.ldgi = src.single_ld; }
+      else { d.gi = grf; d.ldgi = H3; }
+      d.hprev = w.ytop; d.ldh = 2 * Hp;
+      d.hout = w.ytop; d.ldo = 2 * Hp;
+      CK(launch_gru_step(a, s));
+    }
+  }
+  // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
+  const float* hlast = w.pf[(T - 1) & 1];
+  if (!is_train) {
+    GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, w.y1, kFeat, Bl + m->blf, B, kFeat);
+    g1.relu_a = 1;
+    CK(launch_gemm(g1, s));
+    GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat, kFeat, Bl + m->blr, B, kFeat);
+    g2.relu_a = 1; g2.addend = w.y1; g2.ldadd = kFeat; g2.scale = 0.5f;
+    CK(launch_gemm(g2, s));
+  } else {
+    GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat);
+    g1.relu_a = 1;
+    CK(launch_gemm(g1, s));
+    GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat + kFeat, 2 * kFeat, Bl + m->blr, B, kFeat);
+    g2.relu_a = 1;
+    CK(launch_gemm(g2, s));
+  }
+  return 0;
+}
+
+}  // namespace
+
+
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {
   if (!m || m->kind != 0 || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
@@ -532,101 +659,45 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
     CK(launch_gemm(g, s));
   }
 
-  for (int l = 0; l < L; ++l) {
-    const bool top = l == L - 1;
-    float* sf = w.sf[l & 1];
-    float* sr = w.sr[l & 1];
-    const float *gf, *grr, *grf;     // gate pre-activation sources of this layer
-    long ldg;                        // row stride of the gate pre-activations
-    if (l == 0) {
-      gf = w.g0; grr = w.g0 + H3; grf = L >= 2 ? w.g0 + 2 * H3 : w.g0c;
-      ldg = (long)T * ld0;
-    } else {
-      const float* inf = w.sf[(l - 1) & 1];
-      const float* inr = w.sr[(l - 1) & 1];
-      GemmArgs g1 = gemm(inf, Hp, Bl + m->fwd[l].wih, Hp, w.gf, H3, Bl + m->fwd[l].bih, (int)BT, H3);
-      CK(launch_gemm(g1, s));
-      GemmArgs g2 = gemm(inr, 2 * Hp, Bl + m->rec_r[l].wih, 2 * Hp, w.grr, H3, Bl + m->rec_r[l].bih, (int)BT, H3);
-      CK(launch_gemm(g2, s));
-      GemmArgs g3 = gemm(inr, 2 * Hp, Bl + m->rec_f[l].wih, 2 * Hp, w.grf, H3, Bl + m->rec_f[l].bih,
-                         top ? B : (int)BT, H3);
-      CK(launch_gemm(g3, s));
-      gf = w.gf; grr = w.grr; grf = w.grf;
-      ldg = H3;
-    }
-    // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
-    auto goff = [&](int q) -> long { return l == 0 ? (long)q * ld0 : (long)q * B * H3; };
+  G0Src src{w.g0, ld0, (long)T * ld0, 0, 0, nullptr, 0, w.g0c, H3};
+  return encoder_core(m, src, B, T, is_train, feat, w, s);
+}
 
-    for (int st = 0; st < T; ++st) {
-      GruArgs a{};
-      a.M = B; a.Hp = Hp; a.first = st == 0;
-      int nd = 0;
-      {  // gru_fwd layer l, frame t = st
-        GruDir& d = a.d[nd++];
-        d.Whh = Bl + m->fwd[l].whh; d.bhh = Bl + m->fwd[l].bhh;
-        d.gi = gf + goff(st); d.ldgi = ldg;
-        if (!top) {
-          d.hprev = sf + (long)(st - 1) * B * Hp; d.ldh = Hp;
-          d.hout = sf + (long)st * B * Hp; d.ldo = Hp;
-        } else {
-          d.hprev = w.pf[(st + 1) & 1]; d.ldh = Hp;
-          d.hout = w.pf[st & 1]; d.ldo = Hp;
-        }
-      }
-      {  // gru_rec layer l, reverse direction: flipped index i = T-1-st (frame st for layer 0)
-        GruDir& d = a.d[nd++];
-        const int i = T - 1 - st;
-        d.Whh = Bl + m->rec_r[l].whh; d.bhh = Bl + m->rec_r[l].bhh;
-        d.gi = grr + goff(l == 0 ? st : i); d.ldgi = ldg;
-        if (!top) {
-          d.hprev = sr + (long)(i + 1) * B * 2 * Hp + Hp; d.ldh = 2 * Hp;
-          d.hout = sr + (long)i * B * 2 * Hp + Hp; d.ldo = 2 * Hp;
-        } else {
-          d.hprev = w.pr[(st + 1) & 1]; d.ldh = Hp;
-          if (st == T - 1) { d.hout = w.ytop + Hp; d.ldo = 2 * Hp; }
-          else { d.hout = w.pr[st & 1]; d.ldo = Hp; }
-        }
-      }
-      if (!top) {  // gru_rec layer l, forward direction: flipped index i = st (frame T-1-st)
-        GruDir& d = a.d[nd++];
-        d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
-        d.gi = grf + goff(l == 0 ? T - 1 - st : st); d.ldgi = ldg;
-        d.hprev = sr + (long)(st - 1) * B * 2 * Hp; d.ldh = 2 * Hp;
-        d.hout = sr + (long)st * B * 2 * Hp; d.ldo = 2 * Hp;
-      }
-      a.ndir = nd;
-      CK(launch_gru_step(a, s));
-    }
-    if (top) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
-      GruArgs a{};
-      a.M = B; a.Hp = Hp; a.first = 1; a.ndir = 1;
-      GruDir& d = a.d[0];
-      d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
-      if (l == 0) { d.gi = w.g0c; d.ldgi = H3; }
-      else { d.gi = grf; d.ldgi = H3; }
-      d.hprev = w.ytop; d.ldh = 2 * Hp;
-      d.hout = w.ytop; d.ldo = 2 * Hp;
-      CK(launch_gru_step(a, s));
-    }
-  }
-  // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
-  const float* hlast = w.pf[(T - 1) & 1];
-  if (!is_train) {
-    GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, w.y1, kFeat, Bl + m->blf, B, kFeat);
-    g1.relu_a = 1;
-    CK(launch_gemm(g1, s));
-    GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat, kFeat, Bl + m->blr, B, kFeat);
-    g2.relu_a = 1; g2.addend = w.y1; g2.ldadd = kFeat; g2.scale = 0.5f;
-    CK(launch_gemm(g2, s));
-  } else {
-    GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat);
-    g1.relu_a = 1;
-    CK(launch_gemm(g1, s));
-    GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat + kFeat, 2 * kFeat, Bl + m->blr, B, kFeat);
-    g2.relu_a = 1;
-    CK(launch_gemm(g2, s));
-  }
+int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld, const float* theta, long theta_ld,
+                          int B, float* out, long out_ld, void* workspace, size_t ws_bytes, void* stream) {
+  if (!m || m->kind != 0 || !feat || !out || !workspace || B < 1) return TEPOSE_E_ARG;
+  if (!m->enc_packed) return TEPOSE_E_STATE;
+  if (ws_bytes < (size_t)B * kInputP * sizeof(float)) return TEPOSE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* xp = (float*)workspace;
+  CK(launch_pad_rows(feat, feat_ld, theta, theta_ld, xp, B, s));
+  GemmArgs g = gemm(xp, kInputP, m->blob + m->wih0, kInputP, out, out_ld, m->blob + m->bih0, B, 9 * m->Hp);
+  CK(launch_gemm(g, s));
   return 0;
+}
+
+int tepose_forward_cached(const tepose_model* m, const float* ring_base, int ring, int first_slot, long clip_stride,
+                          const float* newest, long newest_ld, int B, int T, const void* jreg_packed, float* theta,
+                          float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
+                          void* stream) {
+  if (!m || m->kind != 0 || !ring_base || !newest || !workspace || B < 1 || T < 1 || ring < T - 1 || ring < 1 ||
+      first_slot < 0 || first_slot >= ring)
+    return TEPOSE_E_ARG;
+  if (!m->enc_packed) return TEPOSE_E_STATE;
+  if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* feat = (float*)workspace;
+  char* rest = (char*)workspace + align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
+  const size_t rest_bytes = ws_bytes - (size_t)(rest - (char*)workspace);
+  Carver c(rest, rest_bytes);
+  EncWs w;
+  carve_encoder(m, B, T, c, w);
+  if (c.cur > rest_bytes) return TEPOSE_E_WORKSPACE;
+  const int ld0 = 9 * m->Hp;
+  G0Src src{ring_base, ld0, clip_stride, first_slot, ring, newest, newest_ld, newest + 6 * m->Hp, newest_ld};
+  int rc = encoder_core(m, src, B, T, 0, feat, w, s);
+  if (rc) return rc;
+  return tepose_regressor_fwd(m, feat, B, 3, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest, rest_bytes, stream);
 }
 
 int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter, const void* jreg_packed,

@@ -68,6 +68,8 @@ struct PackArgs {
 };
 hipError_t launch_pack(const PackArgs& a, hipStream_t s);
 hipError_t launch_pad_input(const float* x, float* xp, long rows, hipStream_t s);
+hipError_t launch_pad_rows(const float* feat, long feat_ld, const float* theta, long theta_ld, float* xp,
+                           long rows, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s);
 

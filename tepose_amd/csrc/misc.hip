@@ -68,6 +68,32 @@ hipError_t launch_pad_input(const float* x, float* xp, long rows, hipStream_t s)
   return hipGetLastError();
 }
 
+// One padded GEMM row per clip from separately strided feature / theta rows (theta == nullptr ->
+// zeros: the newest frame of a window, evaluate.py:248-252).
+__global__ void __launch_bounds__(256) pad_rows_kernel(const float* __restrict__ feat, long feat_ld,
+                                                       const float* __restrict__ theta, long theta_ld,
+                                                       float* __restrict__ xp, long rows) {
+  const long total = rows * kInputP;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / kInputP;
+    const int k = (int)(idx - row * kInputP);
+    float v = 0.f;
+    if (k < kFeat) v = feat[row * feat_ld + k];
+    else if (k < kInput && theta) v = theta[row * theta_ld + (k - kFeat)];
+    xp[idx] = v;
+  }
+}
+
+hipError_t launch_pad_rows(const float* feat, long feat_ld, const float* theta, long theta_ld, float* xp,
+                           long rows, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  const long total = rows * kInputP;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, s, feat, feat_ld, theta, theta_ld, xp, rows);
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float* p, size_t n, float v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)

@@ -13,10 +13,17 @@ import torch
 
 
 @torch.no_grad()
-def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('theta', 'kp_3d', 'verts', 'rotmat')):
+def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('theta', 'kp_3d', 'verts', 'rotmat'),
+              cache_projections='auto'):
     """features: list of [N_i, 2048] tensors (one per clip); theta_init: list of [seqlen-1, 85]
     (theta of the first seqlen-1 frames: pseudo-theta with cam=[1,0,0] in evaluate.py:177,219,
     VIBE output in demo.py:237).  Clips shorter than seqlen are skipped (evaluate.py:226-227).
+
+    cache_projections: keep every frame's layer-0 gate pre-activations (x W_ih^T + b_ih, 3 directions) in a
+    per-clip ring, so a window step projects 2 frames per clip (the newest one with zero theta and the
+    previous one with its now-known theta) instead of all `seqlen` (saves up to 42 % of the
+    FLOPs).  'auto' turns it on from 4 concurrent clips (below that the two extra small launches per
+    step cost more than the re-projection they save).
 
     Returns a list (same order as the input) of dicts key -> [N_i - seqlen + 1, ...] tensors:
     the prediction for the last frame of every window, i.e. frames seqlen-1 .. N_i-1."""
@@ -36,13 +43,39 @@ def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('thet
     steps = [n[i] - T + 1 for i in order]                 # windows per clip, non-increasing
     outs = {k: [None] * C for k in keep}
     bufs = {}
-    inp = torch.zeros(C, T, 2133, device=dev)
+    use_cache = (C >= 4) if cache_projections == 'auto' else bool(cache_projections)     # measured crossover
+    if use_cache:
+        eng = model._engine
+        with torch.cuda.device(dev):
+            eng.pack_encoder(model.encoder, dev)
+            eng.pack_regressor(model.regressor, dev)
+        ring_n = max(T - 1, 1)
+        ring = torch.empty(C, ring_n, eng.gate_width, device=dev)
+        newest = torch.empty(C, eng.gate_width, device=dev)
+        pws = torch.empty(C * 2144 * 4, dtype=torch.uint8, device=dev)
+
+        def project(frame, theta, b):
+            out = newest if theta is None else ring[:, frame % ring_n]
+            eng.project_frames(F[:, frame].data_ptr(), F.stride(0), None if theta is None else TH[:, frame].data_ptr(),
+                               TH.stride(0), b, out.data_ptr(), out.stride(0), pws)
+        with torch.cuda.device(dev):
+            for t in range(T - 1):
+                project(t, True, C)
+    else:
+        inp = torch.zeros(C, T, 2133, device=dev)
     for j in range(steps[0]):
         b = sum(1 for s in steps if s > j)                # active clips form the prefix [0, b)
-        x = inp[:b]
-        x[:, :, :2048] = F[:b, j:j + T]
-        x[:, :T - 1, 2048:] = TH[:b, j:j + T - 1]         # last frame's theta stays zero
-        pred = model(x, J_regressor=J_regressor)[0]
+        if use_cache:
+            with torch.cuda.device(dev):
+                if j > 0:
+                    project(j + T - 2, True, b)           # previous newest frame, theta now known
+                project(j + T - 1, None, b)               # newest frame, theta slots zero
+                pred = eng.forward_cached(ring, j % ring_n, newest, b, T, J_regressor)
+        else:
+            x = inp[:b]
+            x[:, :, :2048] = F[:b, j:j + T]
+            x[:, :T - 1, 2048:] = TH[:b, j:j + T - 1]     # last frame's theta stays zero
+            pred = model(x, J_regressor=J_regressor)[0]
         TH[:b, j + T - 1] = pred['theta']                 # feeds the next windows
         for k in keep:
             if k not in bufs:

@@ -221,6 +221,37 @@ class Engine:
                                             self._stream()), 'tepose_smpl_fwd')
         return verts, joints
 
+    # ------------------------------------------------------------------ cached layer-0 projections
+    @property
+    def gate_width(self):
+        """Floats per frame of cached layer-0 gate pre-activations (3 directions x 3 gates x Hp)."""
+        return 9 * ((self.hidden + 63) // 64 * 64)
+
+    def project_frames(self, feat_ptr, feat_ld, theta_ptr, theta_ld, B, out_ptr, out_ld, ws):
+        _lib.check(self.lib.tepose_project_frames(self.handle, feat_ptr, feat_ld, theta_ptr, theta_ld, B, out_ptr,
+                                                  out_ld, ws.data_ptr(), ws.numel(), self._stream()),
+                   'tepose_project_frames')
+
+    def forward_cached(self, ring, first_slot, newest, B, T, J_regressor):
+        """ring [C, R, 9Hp], newest [C, 9Hp] (rows [0,B) used) -> output dict like forward()."""
+        dev = ring.device
+        ws = self.workspace(B, T, dev)
+        _, jp = self.jreg(J_regressor, dev)
+        nj = 14 if J_regressor is not None else 49
+        out = {
+            'theta': torch.empty((B, 85), dtype=torch.float32, device=dev),
+            'verts': torch.empty((B, NUM_VERTS, 3), dtype=torch.float32, device=dev),
+            'kp_2d': torch.empty((B, nj, 2), dtype=torch.float32, device=dev),
+            'kp_3d': torch.empty((B, nj, 3), dtype=torch.float32, device=dev),
+            'rotmat': torch.empty((B, 24, 3, 3), dtype=torch.float32, device=dev),
+        }
+        _lib.check(self.lib.tepose_forward_cached(
+            self.handle, ring.data_ptr(), ring.shape[1], int(first_slot), ring.stride(0), newest.data_ptr(),
+            newest.stride(0), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(), out['kp_3d'].data_ptr(),
+            out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+            'tepose_forward_cached')
+        return out
+
     # ------------------------------------------------------------------ VIBE bootstrap encoder
     def pack_vibe_encoder(self, enc, device):
         ts = []

@@ -70,3 +70,28 @@ def test_ragged_clips_in_lockstep_equal_per_clip_runs(smpl_np):
         assert (res[i]['verts'].cpu() - ref['verts']).abs().max() < 1e-4
         assert (res[i]['kp_3d'].cpu() - ref['kp_3d']).abs().max() < 1e-4
         assert (res[i]['rotmat'].cpu() - ref['rotmat']).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('L,H,T', [(2, 128, 6), (1, 64, 4), (2, 64, 2)])
+def test_cached_projections_equal_uncached(L, H, T, smpl_np):
+    """The projection cache (ring of layer-0 gate pre-activations) is an exact re-association of the
+    same GEMM rows: per-clip results must agree with the uncached driver to rounding."""
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    model, _, _ = build_model(L, H, seed=13, device='cuda', smpl_np=smpl_np)
+    lens = [T + 9, T, T + 3, T - 1 if T > 1 else 1, T + 14]
+    feats, inits = [], []
+    for i, n in enumerate(lens):
+        w = synth.synthetic_windows(1, max(n, T) + 1, 800 + i)[0]
+        feats.append(torch.from_numpy(w[:n, :2048].copy()))
+        inits.append(torch.from_numpy(w[:T - 1, 2048:].copy()))
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    a = run_clips(model, feats, inits, T, J_regressor=J, cache_projections=False)
+    b = run_clips(model, feats, inits, T, J_regressor=J, cache_projections=True)
+    for ra, rb in zip(a, b):
+        assert (ra is None) == (rb is None)
+        if ra is None:
+            continue
+        for k in ra:
+            assert ra[k].shape == rb[k].shape
+            assert (ra[k] - rb[k]).abs().max() < 2e-5, k
