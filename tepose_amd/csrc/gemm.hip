@@ -66,10 +66,11 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int tilesM, int 
   tn = rem / gm;
 }
 
-template <int WN, bool RELU, int BK>
+template <int WN, bool RELU, int BK, int WMF>
 __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, int M, int m0,
                                          const float* __restrict__ W, int Kp, int n0, float* lds,
-                                         f32x16 (&acc)[2][WN]) {
+                                         f32x16 (&acc)[WMF][WN]) {
+  constexpr int BM = 64 * WMF;               // block rows: 2 waves along M x WMF 32-row fragments each
   static_assert(BK == 16 || BK == 32, "K-tile must be 16 or 32");
   constexpr int SLOTS = BK / 4;              // 16-byte slots per tile row
   constexpr int RPI = 64 / SLOTS;            // tile rows moved by one wave-wide DMA instruction
@@ -108,32 +109,32 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
 
   // ---- fragment read offsets (floats) ---------------------------------------------------
   const int sw = (r >> SWZ_SH) & (SLOTS - 1);
-  int aoff[2], boff[WN];
+  int aoff[WMF], boff[WN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + i * 32 + r) * BK;
+  for (int i = 0; i < WMF; ++i) aoff[i] = (wm * 32 * WMF + i * 32 + r) * BK;
 #pragma unroll
   for (int j = 0; j < WN; ++j) boff[j] = BM * BK + (wn * 32 * WN + j * 32 + r) * BK;
 
   const int KT = Kp / BK;
   constexpr int NC = BK / 8;                 // 8-k chunks per K-tile
-  auto load_frags = [&](const float* st, int c, f32x4 (&a)[2], f32x4 (&b)[WN]) {
+  auto load_frags = [&](const float* st, int c, f32x4 (&a)[WMF], f32x4 (&b)[WN]) {
     const int sx = 4 * ((2 * c + h) ^ sw);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = *(const f32x4*)(st + aoff[i] + sx);
+    for (int i = 0; i < WMF; ++i) a[i] = *(const f32x4*)(st + aoff[i] + sx);
 #pragma unroll
     for (int j = 0; j < WN; ++j) b[j] = *(const f32x4*)(st + boff[j] + sx);
   };
-  auto mma = [&](f32x4 (&a)[2], f32x4 (&b)[WN]) {
+  auto mma = [&](f32x4 (&a)[WMF], f32x4 (&b)[WN]) {
     if (RELU) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WMF; ++i)
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[i][m] = fmaxf(a[i][m], 0.f);
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WMF; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
@@ -142,7 +143,7 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
   // Software pipeline: fragments of chunk c+1 are read while chunk c's MFMAs run; the
   // stage barrier sits in front of the LAST chunk's MFMAs, so the first fragments of the
   // next stage are fetched underneath them and no ds_read latency is exposed per K-tile.
-  f32x4 fa[2][2], fb[2][WN];
+  f32x4 fa[2][WMF], fb[2][WN];
   issue(0, 0);
   __syncthreads();
   load_frags(lds, 0, fa[0], fb[0]);
@@ -178,7 +179,7 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
     const float* st = lds + buf * STAGE;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      f32x4 a[2], b[WN];
+      f32x4 a[WMF], b[WN];
       load_frags(st, c, a, b);
       mma(a, b);
     }
@@ -188,24 +189,25 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, long lda, 
 }
 
 // ------------------------------------------------------------------------------ plain GEMM
-template <bool RELU>
-__global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs a, int tilesM, int tilesN) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + 128) * BK_GEMM];
+template <bool RELU, int WMF>
+__global__ void __launch_bounds__(256, WMF == 2 ? TEPOSE_GEMM_OCC : 3) gemm_f32_kernel(GemmArgs a, int tilesM, int tilesN) {
+  constexpr int BMT = 64 * WMF;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BMT + 128) * BK_GEMM];
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
-  const int m0 = tm * BM, n0 = tn * 128;
-  f32x16 acc[2][2];
+  const int m0 = tm * BMT, n0 = tn * 128;
+  f32x16 acc[WMF][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WMF; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  mainloop<2, RELU, BK_GEMM>(a.A, a.lda, a.M, m0, a.W, a.Kp, n0, lds, acc);
+  mainloop<2, RELU, BK_GEMM, WMF>(a.A, a.lda, a.M, m0, a.W, a.Kp, n0, lds, acc);
 #if TEPOSE_ABL == 4
   if (a.scale != 123.f) {
     float sacc = 0.f;
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+    for (int i = 0; i < WMF; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
     if (sacc == 1.2345f) a.C[0] = sacc;
     return;
   }
@@ -219,10 +221,10 @@ __global__ void __launch_bounds__(256, TEPOSE_GEMM_OCC) gemm_f32_kernel(GemmArgs
     if (col >= a.N) continue;
     const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WMF; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (row < a.M) {
           float v = acc[i][j][e] + bv;
           if (a.addend) v += a.addend[(long)row * a.ldadd + col];
@@ -254,12 +256,28 @@ static int skinny_max_m_gemm() {
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.M <= skinny_max_m_gemm()) return launch_skinny_gemm(a, s);
-  const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + 127) / 128;
-  dim3 grid(tilesM * tilesN), block(256);
+  const int tilesN = (a.N + 127) / 128;
+  // 64-row tiles (3 blocks per CU) when 128-row tiles would not fill the 512 block slots twice:
+  // finer quantisation for the mid-size batches (TEPOSE_GEMM_HALF_MAX_BLOCKS overrides the bound)
+  static const int half_max_blocks = [] {
+    const char* e = getenv("TEPOSE_GEMM_HALF_MAX_BLOCKS");
+    return e ? atoi(e) : 1024;      // measured: +4-6 % at B = 64-128, +4.5 % at B = 1024, neutral at B = 8192
+  }();
+  const int tiles128 = (a.M + 127) / 128;
+  if (tiles128 * tilesN <= half_max_blocks) {
+    const int tilesM = (a.M + 63) / 64;
+    dim3 grid(tilesM * tilesN), block(256);
+    if (a.relu_a)
+      hipLaunchKernelGGL((gemm_f32_kernel<true, 1>), grid, block, 0, s, a, tilesM, tilesN);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel<false, 1>), grid, block, 0, s, a, tilesM, tilesN);
+    return hipGetLastError();
+  }
+  dim3 grid(tiles128 * tilesN), block(256);
   if (a.relu_a)
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, 0, s, a, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, 2>), grid, block, 0, s, a, tiles128, tilesN);
   else
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, 0, s, a, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, 2>), grid, block, 0, s, a, tiles128, tilesN);
   return hipGetLastError();
 }
 
@@ -302,7 +320,7 @@ __global__ void __launch_bounds__(256, TEPOSE_GRU_OCC) gru_step_kernel(GruArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][g][e] = 0.f;
 #if TEPOSE_ABL != 5
-  if (!a.first) mainloop<3, false, BK_GRU>(d.hprev, d.ldh, a.M, m0, d.Whh, a.Hp, tj * 192, lds, acc);
+  if (!a.first) mainloop<3, false, BK_GRU, 2>(d.hprev, d.ldh, a.M, m0, d.Whh, a.Hp, tj * 192, lds, acc);
 #endif
 #if TEPOSE_ABL == 4
   {
