@@ -72,7 +72,7 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0):
     # not always it: at B=256 the CPU GRU saturates well below 128 threads)
     all_cores = os.cpu_count() or torch.get_num_threads()
     best = (0.0, all_cores)
-    for nt in sorted({all_cores, max(1, all_cores // 2), min(32, all_cores), min(16, all_cores)}):
+    for nt in sorted({min(64, all_cores), min(32, all_cores), min(16, all_cores)}):    # >64 threads only oversubscribe
         torch.set_num_threads(nt)
         O.tepose_fwd(state, smpl_np, x[:16], L, J_regressor=J, nn_gru=True)  # warm-up
         t0 = time.perf_counter()
@@ -92,6 +92,13 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0):
     return {'value': n / el, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
             'sample': '%d windows of [%d,2133] in batches of %d, torch %s CPU, nn.GRU op sequence, %.1f s'
                       % (n, T, Bc, torch.__version__, el)}
+
+
+def _t(msg, t0=[time.perf_counter()]):
+    """phase timing on stderr (rank 0 only prints JSON on stdout)"""
+    now = time.perf_counter()
+    sys.stderr.write('[bench %7.1f s] %s\n' % (now - t0[0], msg))
+    sys.stderr.flush()
 
 
 def main():
@@ -161,6 +168,7 @@ def main():
     probe_sum = float(probe['verts'].double().abs().sum().item())
     x = synthetic_windows_device(B, T, 1234 + rank, device)
     torch.cuda.synchronize()
+    _t('model packed, inputs resident')
 
     def step():
         with torch.no_grad():
@@ -180,6 +188,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    _t('timed region done')
     k_ms, k_n, k_flops = eng.profile_read()
     eng.profile_enable(False)
     finite = bool(torch.isfinite(out['verts']).all().item() and torch.isfinite(out['theta']).all().item())
@@ -239,8 +248,10 @@ def main():
                 ms = (time.perf_counter() - te) / reps * 1e3
                 extra[name] = {'ms_per_forward': ms, 'windows_per_s': b / ms * 1e3}
             res['other_shapes'] = extra
+            _t('other shapes done')
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(state, smpl_np, L, T)
+            _t('cpu baseline done')
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
