@@ -190,6 +190,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _t('timed region done')
     k_ms, k_n, k_flops = eng.profile_read()
+    g_ms, g_n, g_flops = eng.profile_read_gru()
     eng.profile_enable(False)
     finite = bool(torch.isfinite(out['verts']).all().item() and torch.isfinite(out['theta']).all().item())
 
@@ -225,6 +226,13 @@ def main():
                                'kernel': 'gemm_f32_kernel<false> (layer-0 input projection, M=%d N=9216 K=2133)'
                                          % (B * T),
                                'launches': k_n, 'avg_ms': k_ms / k_n}
+        if g_n > 0:
+            gach = g_flops / (g_ms / g_n * 1e-3) / 1e12
+            res['roofline_gru_steps'] = {'bound': 'mfma', 'achieved': gach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                         'unit': 'TFLOP/s', 'frac': gach / PEAK_F32_MFMA_TFLOPS,
+                                         'kernel': 'gru_step_kernel: the %d step launches of one forward (5T+1 consumed cell '
+                                                   'steps, first-step matmuls skipped but counted)' % (2 * T + 1),
+                                         'ms_per_forward': g_ms / g_n}
         if bcast_ms is not None:
             res['weight_broadcast_ms'] = bcast_ms
             res['weight_blob_MB'] = eng.packed_bytes / 1e6

@@ -196,6 +196,9 @@ int tepose_gemm_f32(const float* A, long lda, const float* W, long ldw, const fl
  * object; off by default.                                                            */
 int tepose_profile_enable(tepose_model* m, int on);
 int tepose_profile_read(tepose_model* m, double* total_ms, int* n_launches, double* flops_per_launch);
+/* Same switch, second kernel class: total time of the GRU-step launch sequences (one interval per layer
+ * per forward) and the algorithmic FLOPs of the consumed cell steps of one forward.          */
+int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward);
 
 #ifdef __cplusplus
 }

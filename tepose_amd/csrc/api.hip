@@ -46,6 +46,9 @@ struct tepose_model {
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
   double prof_flops = 0.0;
+  std::vector<hipEvent_t> ev_gru;               // pairs around each layer's sequence of GRU-step launches
+  size_t ev_gru_used = 0;
+  double prof_gru_flops = 0.0;                  // algorithmic FLOPs of all GRU steps of one forward
 };
 
 namespace {
@@ -231,6 +234,7 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
 void tepose_destroy(tepose_model* m) {
   if (!m) return;
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : m->ev_gru) (void)hipEventDestroy(e);
   delete m;
 }
 
@@ -469,6 +473,8 @@ int tepose_profile_enable(tepose_model* m, int on) {
   m->prof = on != 0;
   m->ev_used = 0;
   m->prof_flops = 0.0;
+  m->ev_gru_used = 0;
+  m->prof_gru_flops = 0.0;
   return 0;
 }
 
@@ -501,8 +507,19 @@ struct G0Src {
   const float* single; long single_ld;   // L == 1: source of the one consumed rec.l0 forward step
 };
 
+int prof_mark(tepose_model* mm, hipStream_t s) {     // next event of the GRU-interval list
+  if (mm->ev_gru.size() < mm->ev_gru_used + 1) {
+    hipEvent_t e;
+    CK(hipEventCreate(&e));
+    mm->ev_gru.push_back(e);
+  }
+  CK(hipEventRecord(mm->ev_gru[mm->ev_gru_used++], s));
+  return 0;
+}
+
 int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_train, float* feat, EncWs& w,
                  hipStream_t s) {
+  tepose_model* mm = const_cast<tepose_model*>(m);
   const int L = m->L, Hp = m->Hp;
   const float* Bl = m->blob;
   const long BT = (long)B * T;
@@ -537,6 +554,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
     auto goff = [&](int q) -> long { return (long)q * B * H3; };
 
+    if (m->prof) { int rc = prof_mark(mm, s); if (rc) return rc; }
     for (int st = 0; st < T; ++st) {
       GruArgs a{};
       a.M = B; a.Hp = Hp; a.first = st == 0;
@@ -591,6 +609,12 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       d.hout = w.ytop; d.ldo = 2 * Hp;
       CK(launch_gru_step(a, s));
     }
+    if (m->prof) {
+      int rc = prof_mark(mm, s);
+      if (rc) return rc;
+      // consumed cell steps of this layer: fwd T + rec_reverse T + rec forward (T, or 1 on the top layer)
+      mm->prof_gru_flops += 2.0 * B * 3.0 * m->H * m->H * (2.0 * T + (top ? 1 : T));
+    }
   }
   // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
   const float* hlast = w.pf[(T - 1) & 1];
@@ -614,6 +638,24 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
 
 }  // namespace
 
+
+int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward) {
+  if (!m || !total_ms || !n_forwards || !flops_per_forward) return TEPOSE_E_ARG;
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < m->ev_gru_used; i += 2) {
+    CK(hipEventSynchronize(m->ev_gru[i + 1]));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, m->ev_gru[i], m->ev_gru[i + 1]));
+    tot += ms;
+  }
+  const int nf = (int)(m->ev_gru_used / (2 * (size_t)m->L));
+  *total_ms = tot;
+  *n_forwards = nf;
+  *flops_per_forward = nf > 0 ? m->prof_gru_flops / nf : 0.0;
+  m->ev_gru_used = 0;
+  m->prof_gru_flops = 0.0;
+  return 0;
+}
 
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {

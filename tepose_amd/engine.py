@@ -288,6 +288,12 @@ class Engine:
                    'tepose_profile_read')
         return ms.value, n.value, fl.value
 
+    def profile_read_gru(self):
+        ms, n, fl = c_double(), c_int(), c_double()
+        _lib.check(self.lib.tepose_profile_read_gru(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
+                   'tepose_profile_read_gru')
+        return ms.value, n.value, fl.value
+
 
 def check_input(x):
     if not torch.is_tensor(x) or x.dim() != 3 or x.shape[2] != 2133:
