@@ -35,9 +35,10 @@ def main():
     ap.add_argument('--clips', type=int, default=37, help='synthetic database: number of clips')
     ap.add_argument('--min-len', type=int, default=300); ap.add_argument('--max-len', type=int, default=1800)
     ap.add_argument('--backend', default='nccl')
+    ap.add_argument('--share-device0', action='store_true', help='testing only: every rank uses cuda:0 (with --backend gloo)')
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = 0 if args.share_device0 else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
