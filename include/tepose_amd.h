@@ -190,6 +190,12 @@ int tepose_gemm_f32(const float* A, long lda, const float* W, long ldw, const fl
                     float* C, long ldc, int M, int N, int K, int relu_a, void* workspace,
                     size_t ws_bytes, void* stream);
 
+/* Same product on the split-precision kernel (fp16 hi/lo planes, three fp16 MFMAs per k-step, fp32
+ * accumulate; csrc/gemm_h3.hip).  K % 32 == 0.  workspace >= tepose_gemm_h3_workspace_bytes(M,N,K).  */
+size_t tepose_gemm_h3_workspace_bytes(int M, int N, int K);
+int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
+                       long ldc, int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);
+
 /* Per-launch timing of the dominant kernel (the layer-0 input-projection GEMM) with
  * hipEvents on the launch stream: enable, run forwards, then read back.  Reading
  * synchronises on the recorded events only.  Used by bench.py for the `roofline`

@@ -18,7 +18,7 @@ SYMBOLS = [
     'tepose_encoder_fwd', 'tepose_regressor_fwd', 'tepose_forward', 'tepose_gemm_workspace_bytes',
     'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read', 'tepose_create_vibe',
     'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
-    'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru',
+    'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
 ]
 
 _lib = None
@@ -79,6 +79,9 @@ def load():
     lib.tepose_project_frames.argtypes = [c_void_p, fp, c_long, fp, c_long, c_int, fp, c_long, fp, c_size_t, c_void_p]
     lib.tepose_forward_cached.argtypes = [c_void_p, fp, c_int, c_int, c_long, fp, c_long, c_int, c_int, fp, fp, fp, fp,
                                           fp, fp, fp, c_size_t, c_void_p]
+    lib.tepose_gemm_h3_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    lib.tepose_gemm_h3_workspace_bytes.restype = c_size_t
+    lib.tepose_gemm_h3_f32.argtypes = [fp, c_long, fp, c_long, fp, fp, c_long, c_int, c_int, c_int, fp, c_size_t, c_void_p]
     lib.tepose_profile_enable.argtypes = [c_void_p, c_int]
     lib.tepose_profile_read.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     lib.tepose_profile_read_gru.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]

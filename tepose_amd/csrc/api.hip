@@ -3,6 +3,8 @@
 // misc.hip, smpl.hip.  Nothing here allocates device memory or synchronises the device.
 #include "../../include/tepose_amd.h"
 
+#include <stdlib.h>
+
 #include <new>
 #include <vector>
 
@@ -15,6 +17,7 @@ namespace {
 struct DirW {                     // one GRU layer/direction inside the blob (float offsets)
   size_t wih = 0, bih = 0;        // input projection (layer-0 ones live in the stacked block)
   size_t whh = 0, bhh = 0;
+  size_t wih_p = 0, whh_p = 0;    // hi|lo fp16 planes of the same matrices (natural gate order), float offsets
 };
 
 struct SmplOff {
@@ -34,6 +37,7 @@ struct tepose_model {
   bool enc_packed = false, reg_packed = false, smpl_packed = false;
   // encoder offsets
   size_t wih0 = 0, bih0 = 0;                    // stacked [9Hp][2144]: fwd | rec_reverse | rec
+  size_t wih0_p = 0;                            // its hi|lo planes
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   // regressor offsets
@@ -41,6 +45,7 @@ struct tepose_model {
   SmplOff smpl{};
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
+  bool split = true;                            // large batches run their GRU matmuls on the fp16x3 split kernel
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -106,6 +111,17 @@ void layout(tepose_model* m) {
   m->blf = take(cur, kFeat);
   m->wlr = take(cur, (size_t)kFeat * 2 * Hp);
   m->blr = take(cur, kFeat);
+  // split-precision copies (hi plane then lo plane, fp16): same float count as the fp32 matrix
+  m->wih0_p = take(cur, (size_t)round_up(9 * (int)Hp, 128) * kInputP);
+  for (size_t l = 0; l < L; ++l) {
+    const size_t n128 = round_up(3 * (int)Hp, 128);
+    if (l > 0) {
+      m->fwd[l].wih_p = take(cur, n128 * Hp);
+      m->rec_f[l].wih_p = take(cur, n128 * 2 * Hp);
+      m->rec_r[l].wih_p = take(cur, n128 * 2 * Hp);
+    }
+    for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) d->whh_p = take(cur, n128 * Hp);
+  }
   layout_tail(m, cur);
 }
 
@@ -141,7 +157,15 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
 
 int pack(const float* src, long ld, int N, int K, float* dst, int Np, int Kp, int rowmap, int colmap,
          int H, int Hp, hipStream_t s) {
-  PackArgs a{src, ld, N, K, dst, Np, Kp, rowmap, colmap, H, Hp};
+  PackArgs a{src, ld, N, K, dst, Np, Kp, nullptr, nullptr, rowmap, colmap, H, Hp};
+  return (int)launch_pack(a, s);
+}
+
+// same mapping, written as hi / lo fp16 planes (lo plane follows the hi plane: Np*Kp halfs each)
+int pack_planes(const float* src, long ld, int N, int K, float* dst_planes, int Np, int Kp, int rowmap, int colmap,
+                int H, int Hp, hipStream_t s) {
+  half_t* hi = (half_t*)dst_planes;
+  PackArgs a{src, ld, N, K, nullptr, Np, Kp, hi, hi + (size_t)Np * Kp, rowmap, colmap, H, Hp};
   return (int)launch_pack(a, s);
 }
 
@@ -158,6 +182,11 @@ struct Carver {
 // Buffers of one encoder forward (shared between sizing and execution).
 struct EncWs {
   float *xp, *g0, *g0c, *gf, *grr, *grf, *sf[2], *sr[2], *pf[2], *pr[2], *ytop, *y1;
+  // split-precision path: every state buffer between state_base and ytop's end has fp16 hi / lo mirrors at
+  // the same element offset; gh = recurrent products of up to 3 directions
+  float* state_base; size_t state_floats; half_t *state_hi, *state_lo; float* gh;
+  half_t* hi_of(const float* p) const { return state_hi + (p - state_base); }
+  half_t* lo_of(const float* p) const { return state_lo + (p - state_base); }
 };
 
 void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
@@ -169,6 +198,8 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   w.gf = c.f(L >= 2 ? BT * 3 * Hp : 0);
   w.grr = c.f(L >= 2 ? BT * 3 * Hp : 0);
   w.grf = c.f(L >= 3 ? BT * 3 * Hp : (L == 2 ? (size_t)B * 3 * Hp : 0));
+  const size_t state_begin = c.cur;
+  w.state_base = c.f(0);
   for (int i = 0; i < 2; ++i) {
     const bool need = (i == 0 && L >= 2) || (i == 1 && L >= 3);
     w.sf[i] = c.f(need ? BT * Hp : 0);
@@ -177,7 +208,12 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
     w.pr[i] = c.f((size_t)B * Hp);
   }
   w.ytop = c.f((size_t)B * 2 * Hp);
+  w.state_floats = (c.cur - state_begin) / sizeof(float);
   w.y1 = c.f((size_t)B * kFeat);
+  const bool h3 = m->split && B > skinny_max_m();
+  w.state_hi = (half_t*)c.f(h3 ? w.state_floats / 2 + 64 : 0);
+  w.state_lo = (half_t*)c.f(h3 ? w.state_floats / 2 + 64 : 0);
+  w.gh = c.f(h3 ? (size_t)3 * B * 3 * Hp : 0);
 }
 
 struct RegWs {
@@ -226,6 +262,10 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
   tepose_model* m = new (std::nothrow) tepose_model();
   if (!m) return TEPOSE_E_ARG;
   m->L = n_layers; m->H = hidden; m->Hp = round_up(hidden, 64);
+  {
+    const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
+    m->split = !(e && atoi(e) != 0);
+  }
   layout(m);
   *out = m;
   return 0;
@@ -360,6 +400,17 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
     CK((hipError_t)pack(l0b[d], 1, 3 * H, 1, B + m->bih0 + (size_t)d * 3 * Hp, 3 * Hp, 1, ROW_GATES,
                         COL_PLAIN, H, Hp, s));
   }
+  {  // planes of the stacked layer-0 block: pack each direction's rows into the hi and the lo plane
+    const size_t rows0 = (size_t)round_up(9 * Hp, 128);
+    CK(launch_fill(B + m->wih0_p, rows0 * kInputP, 0.f, s));
+    half_t* hi = (half_t*)(B + m->wih0_p);
+    half_t* lo = hi + rows0 * kInputP;
+    for (int d = 0; d < 3; ++d) {
+      PackArgs a{l0[d], kInput, 3 * H, kInput, nullptr, 3 * Hp, kInputP, hi + (size_t)d * 3 * Hp * kInputP,
+                 lo + (size_t)d * 3 * Hp * kInputP, ROW_GATES, COL_PLAIN, H, Hp};
+      CK(launch_pack(a, s));
+    }
+  }
   for (int l = 0; l < L; ++l) {
     struct { DirW* d; const float *ih, *hh, *bih, *bhh; bool split; } dirs[3] = {
         {&m->fwd[l], fwd_w(l, 0), fwd_w(l, 1), fwd_w(l, 2), fwd_w(l, 3), false},
@@ -371,7 +422,10 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
         CK((hipError_t)pack(d.ih, K, 3 * H, K, B + d.d->wih, n128, Kp, ROW_GATES,
                             d.split ? COL_SPLIT2 : COL_PLAIN, H, Hp, s));
         CK((hipError_t)pack(d.bih, 1, 3 * H, 1, B + d.d->bih, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+        CK((hipError_t)pack_planes(d.ih, K, 3 * H, K, B + d.d->wih_p, n128, Kp, ROW_GATES,
+                                   d.split ? COL_SPLIT2 : COL_PLAIN, H, Hp, s));
       }
+      CK((hipError_t)pack_planes(d.hh, H, 3 * H, H, B + d.d->whh_p, n128, Hp, ROW_GATES, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.hh, H, 3 * H, H, B + d.d->whh, 3 * Hp, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.bhh, 1, 3 * H, 1, B + d.d->bhh, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
     }
@@ -524,6 +578,40 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const float* Bl = m->blob;
   const long BT = (long)B * T;
   const int H3 = 3 * Hp;
+  const bool h3 = m->split && B > skinny_max_m();
+  const size_t n128 = (size_t)round_up(H3, 128);
+  // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
+  auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t bias, float* out, int M) -> int {
+    if (!h3) {
+      GemmArgs g = gemm(in, K, Bl + w_f32, K, out, H3, Bl + bias, M, H3);
+      return (int)launch_gemm(g, s);
+    }
+    H3Batch b{};
+    const half_t* wh = (const half_t*)(Bl + w_planes);
+    b.p[0] = H3Args{w.hi_of(in), w.lo_of(in), (long)K, wh, wh + n128 * K, K, out, (long)H3, Bl + bias, M, H3};
+    b.n = 1;
+    return (int)launch_gemm_h3(b, s);
+  };
+  // one GRU step of up to 3 directions: fused fp32 kernel, or split product + gate kernel
+  auto step = [&](const GruArgs& a, const size_t (&whh_planes)[3]) -> int {
+    if (!h3) return (int)launch_gru_step(a, s);
+    if (!a.first) {
+      H3Batch b{};
+      for (int d = 0; d < a.ndir; ++d) {
+        const half_t* wh = (const half_t*)(Bl + whh_planes[d]);
+        b.p[d] = H3Args{w.hi_of(a.d[d].hprev), w.lo_of(a.d[d].hprev), a.d[d].ldh, wh, wh + n128 * Hp, Hp,
+                        w.gh + (size_t)d * B * H3, (long)H3, nullptr, B, H3};
+      }
+      b.n = a.ndir;
+      hipError_t e = launch_gemm_h3(b, s);
+      if (e != hipSuccess) return (int)e;
+    }
+    GateBatch gb{};
+    for (int d = 0; d < a.ndir; ++d)
+      gb.d[d] = GateDir{a.d[d].gi, a.d[d].ldgi, w.gh + (size_t)d * B * H3, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh,
+                        a.d[d].hout, w.hi_of(a.d[d].hout), w.lo_of(a.d[d].hout), a.d[d].ldo};
+    return (int)launch_gru_gates(gb, a.ndir, B, Hp, a.first, s);
+  };
   auto gi0 = [&](int t, int dir, const float*& p, long& ld) {
     if (src.last && t == T - 1) { p = src.last + (long)dir * H3; ld = src.last_ld; return; }
     const int slot = src.ring ? (src.first + t) % src.ring : t;
@@ -541,13 +629,9 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     } else {
       const float* inf = w.sf[(l - 1) & 1];
       const float* inr = w.sr[(l - 1) & 1];
-      GemmArgs g1 = gemm(inf, Hp, Bl + m->fwd[l].wih, Hp, w.gf, H3, Bl + m->fwd[l].bih, (int)BT, H3);
-      CK(launch_gemm(g1, s));
-      GemmArgs g2 = gemm(inr, 2 * Hp, Bl + m->rec_r[l].wih, 2 * Hp, w.grr, H3, Bl + m->rec_r[l].bih, (int)BT, H3);
-      CK(launch_gemm(g2, s));
-      GemmArgs g3 = gemm(inr, 2 * Hp, Bl + m->rec_f[l].wih, 2 * Hp, w.grf, H3, Bl + m->rec_f[l].bih,
-                         top ? B : (int)BT, H3);
-      CK(launch_gemm(g3, s));
+      CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, (int)BT));
+      CK((hipError_t)proj(inr, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].bih, w.grr, (int)BT));
+      CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].bih, w.grf, top ? B : (int)BT));
       gf = w.gf; grr = w.grr; grf = w.grf;
       ldg = H3;
     }
@@ -596,7 +680,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         d.hout = sr + (long)st * B * 2 * Hp; d.ldo = 2 * Hp;
       }
       a.ndir = nd;
-      CK(launch_gru_step(a, s));
+      const size_t wp[3] = {m->fwd[l].whh_p, m->rec_r[l].whh_p, m->rec_f[l].whh_p};
+      CK((hipError_t)step(a, wp));
     }
     if (top) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
       GruArgs a{};
@@ -607,7 +692,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       else { d.gi = grf; d.ldgi = H3; }
       d.hprev = w.ytop; d.ldh = 2 * Hp;
       d.hout = w.ytop; d.ldo = 2 * Hp;
-      CK(launch_gru_step(a, s));
+      const size_t wp[3] = {m->rec_f[l].whh_p, 0, 0};
+      CK((hipError_t)step(a, wp));
     }
     if (m->prof) {
       int rc = prof_mark(mm, s);
@@ -672,11 +758,17 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
   const long BT = (long)B * T;
   const int H3 = 3 * Hp;
 
-  CK(launch_pad_input(x, w.xp, BT, s));
   // ---- layer-0 input projections: one GEMM for every direction that runs all T steps --------
   const int ld0 = (L >= 2 ? 9 : 6) * Hp;
+  const bool h3 = m->split && B > skinny_max_m();
+  half_t* xh = (half_t*)w.xp;                       // hi / lo planes share the padded-input buffer
+  half_t* xl = xh + (size_t)BT * kInputP;
+  const size_t rows0 = (size_t)round_up(9 * Hp, 128);
+  const half_t* w0h = (const half_t*)(Bl + m->wih0_p);
+  const half_t* w0l = w0h + rows0 * kInputP;
+  if (h3) CK(launch_pad_input_planes(x, xh, xl, BT, s));
+  else CK(launch_pad_input(x, w.xp, BT, s));
   {
-    GemmArgs g = gemm(w.xp, kInputP, Bl + m->wih0, kInputP, w.g0, ld0, Bl + m->bih0, (int)BT, ld0);
     tepose_model* mm = const_cast<tepose_model*>(m);
     if (m->prof) {
       if (mm->ev.size() < mm->ev_used + 2) {
@@ -688,7 +780,15 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
       }
       CK(hipEventRecord(mm->ev[mm->ev_used], s));
     }
-    CK(launch_gemm(g, s));
+    if (h3) {
+      H3Batch b{};
+      b.p[0] = H3Args{xh, xl, (long)kInputP, w0h, w0l, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT, ld0};
+      b.n = 1;
+      CK(launch_gemm_h3(b, s));
+    } else {
+      GemmArgs g = gemm(w.xp, kInputP, Bl + m->wih0, kInputP, w.g0, ld0, Bl + m->bih0, (int)BT, ld0);
+      CK(launch_gemm(g, s));
+    }
     if (m->prof) {
       CK(hipEventRecord(mm->ev[mm->ev_used + 1], s));
       mm->ev_used += 2;
@@ -696,9 +796,18 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
     }
   }
   if (L == 1) {  // rec.l0 forward direction: only flipped index 0 (= frame T-1) is consumed
-    GemmArgs g = gemm(w.xp + (long)(T - 1) * kInputP, (long)T * kInputP, Bl + m->wih0 + (size_t)6 * Hp * kInputP,
-                      kInputP, w.g0c, H3, Bl + m->bih0 + 6 * Hp, B, H3);
-    CK(launch_gemm(g, s));
+    if (h3) {
+      H3Batch b{};
+      b.p[0] = H3Args{xh + (long)(T - 1) * kInputP, xl + (long)(T - 1) * kInputP, (long)T * kInputP,
+                      w0h + (size_t)6 * Hp * kInputP, w0l + (size_t)6 * Hp * kInputP, kInputP, w.g0c, (long)H3,
+                      Bl + m->bih0 + 6 * Hp, B, H3};
+      b.n = 1;
+      CK(launch_gemm_h3(b, s));
+    } else {
+      GemmArgs g = gemm(w.xp + (long)(T - 1) * kInputP, (long)T * kInputP, Bl + m->wih0 + (size_t)6 * Hp * kInputP,
+                        kInputP, w.g0c, H3, Bl + m->bih0 + 6 * Hp, B, H3);
+      CK(launch_gemm(g, s));
+    }
   }
 
   G0Src src{w.g0, ld0, (long)T * ld0, 0, 0, nullptr, 0, w.g0c, H3};
@@ -876,6 +985,20 @@ int tepose_filter_one_euro(float* x, int N, int D, float min_cutoff, float beta,
 int tepose_filter_slerp(const float* rotmat_in, float* rotmat_out, int N, int J, double ratio, void* stream) {
   if (!rotmat_in || !rotmat_out || N < 1 || J < 1) return TEPOSE_E_ARG;
   CK(launch_slerp_smooth(rotmat_in, rotmat_out, N, J, ratio, (hipStream_t)stream));
+  return 0;
+}
+
+size_t tepose_gemm_h3_workspace_bytes(int M, int N, int K) {
+  if (M < 1 || N < 1 || K < 1) return 0;
+  return gemm_h3_ws_bytes(M, N, K);
+}
+
+int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
+                       int M, int N, int K, void* workspace, size_t ws_bytes, void* stream) {
+  if (!A || !W || !C || !workspace || M < 1 || N < 1 || K < 1) return TEPOSE_E_ARG;
+  if (K % 32 != 0) return TEPOSE_E_SHAPE;
+  if (ws_bytes < gemm_h3_ws_bytes(M, N, K)) return TEPOSE_E_WORKSPACE;
+  CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream));
   return 0;
 }
 

@@ -6,6 +6,8 @@
 
 namespace tepose {
 
+typedef _Float16 half_t;
+
 constexpr int kFeat = 2048;
 constexpr int kTheta = 85;
 constexpr int kInput = 2133;
@@ -62,7 +64,8 @@ enum RowMap { ROW_PLAIN = 0, ROW_GATES = 1, ROW_GATES_TILED = 2 };
 enum ColMap { COL_PLAIN = 0, COL_SPLIT2 = 1 };
 struct PackArgs {
   const float* src; long ld_src; int N, K;   // logical source [N][K] (col offset folded into src)
-  float* dst; int Np, Kp;
+  float* dst; int Np, Kp;                     // fp32 destination, or nullptr with dst_hi / dst_lo set
+  half_t* dst_hi; half_t* dst_lo;             // split-precision planes (gemm_h3.hip)
   int rowmap, colmap;
   int H, Hp;                                  // for the gate / split maps
 };
@@ -118,5 +121,30 @@ hipError_t launch_metrics_verts(const float* pred, const float* target, int N, f
 // ---------------------------------------------------------------- filters.hip
 hipError_t launch_one_euro(float* x, int N, int D, float min_cutoff, float beta, float d_cutoff, hipStream_t s);
 hipError_t launch_slerp_smooth(const float* in, float* out, int N, int J, double ratio, hipStream_t s);
+
+// ---------------------------------------------------------------- gemm_h3.hip (split-precision fp16x3 GEMM)
+struct H3Args {
+  const half_t *Ah, *Al; long lda;    // [M][Kp] hi / lo planes (lda in halfs, multiple of 8)
+  const half_t *Wh, *Wl; int Kp;      // [Np][Kp] planes, Np multiple of 128, Kp multiple of 32
+  float* C; long ldc;
+  const float* bias;                  // [N] or nullptr
+  int M, N;
+};
+struct H3Batch { H3Args p[3]; int n; };
+hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
+hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s);
+struct GateDir {
+  const float* gi; long ldgi;         // x W_ih^T + b_ih, [row*ldgi + g*Hp + j]
+  const float* gh;                    // h W_hh^T, [row][3Hp] (ignored when first)
+  const float* bhh;                   // [3Hp]
+  const float* hprev; long ldh;       // fp32 previous state (ignored when first)
+  float* hout; half_t* hout_hi; half_t* hout_lo; long ldo;   // same row stride for the three outputs
+};
+struct GateBatch { GateDir d[3]; };
+hipError_t launch_gru_gates(const GateBatch& gb, int ndir, int M, int Hp, int first, hipStream_t s);
+hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, void* hi, void* lo, hipStream_t s);
+hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
+                              long ldc, int M, int N, int K, void* ws, hipStream_t s);
+size_t gemm_h3_ws_bytes(int M, int N, int K);
 
 }  // namespace tepose

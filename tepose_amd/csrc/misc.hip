@@ -35,7 +35,14 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
         k = a.H + (kp - a.Hp);
       }
     }
-    a.dst[idx] = (n >= 0 && k >= 0) ? a.src[(long)n * a.ld_src + k] : 0.f;
+    const float v = (n >= 0 && k >= 0) ? a.src[(long)n * a.ld_src + k] : 0.f;
+    if (a.dst) {
+      a.dst[idx] = v;
+    } else {                              // hi / lo fp16 planes for the split-precision GEMM
+      const half_t hv = (half_t)v;
+      a.dst_hi[idx] = hv;
+      a.dst_lo[idx] = (half_t)(v - (float)hv);
+    }
   }
 }
 
