@@ -7,6 +7,13 @@
 namespace tepose {
 
 typedef _Float16 half_t;
+// split-precision operands: a = hi + lo / kLoScale with hi = fp16(a), lo = fp16((a - hi) * kLoScale); the power-of-two
+// scale keeps the low half out of the fp16 subnormal range for every |a| >= ~1e-7 (22 significant bits)
+constexpr float kLoScale = 2048.f;
+__host__ __device__ inline void split_hi_lo(float a, half_t& hi, half_t& lo) {
+  hi = (half_t)a;
+  lo = (half_t)((a - (float)hi) * kLoScale);
+}
 
 constexpr int kFeat = 2048;
 constexpr int kTheta = 85;

@@ -14,15 +14,17 @@
 // on the read keeps ds_read_b128 conflict-free with a lane-linear LDS image.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace tepose {
 
+#ifndef TEPOSE_H3_ABL
+#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds: 1 no DMA in the loop, 2 no barrier, 3 no fragment reads
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int HM = 256, HN = 128, HK = 32;
-constexpr int H_ROWB = HK * 2;                       // bytes per tile row of one plane
-constexpr int H_STAGE = (2 * HM + 2 * HN) * H_ROWB;  // 49152 B
-constexpr int H_NSTAGE = 3;                          // ring of 3 stages = 144 KB: two K-tiles of DMA in flight
+constexpr int HM = 256;                               // block rows: 4 waves along M x 2 fragments of 32
 
 __device__ __forceinline__ void glds16b(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -38,9 +40,7 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
     const long r = idx / Kp;
     const int k = (int)(idx - r * Kp);
     const float a = k < K ? src[r * ld + k] : 0.f;
-    const _Float16 h = (_Float16)a;
-    hi[idx] = h;
-    lo[idx] = (_Float16)(a - (float)h);
+    split_hi_lo(a, hi[idx], lo[idx]);
   }
 }
 
@@ -67,9 +67,35 @@ __device__ __forceinline__ void h3_tile_of_block(int bid, int nwg, int tilesM, i
   tn = rem / gm;
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vm() {          // s_waitcnt vmcnt(N) with a literal count
+  static_assert(N >= 0 && N <= 24, "vmcnt immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N == 0, "add the literal");
+}
+
+// WNT: 32-column MFMA tiles per wave along N (block columns = 64 * WNT); HK: K-tile (32 | 16);
+// NST: stages in the LDS ring (NST - 1 K-tiles of DMA in flight).
+template <int WNT, int HK, int NST>
 __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tilesM, int tilesN) {
+  constexpr int HN = 64 * WNT;
+  constexpr int RB = HK * 2;                          // bytes per tile row of one plane
+  constexpr int SL = RB / 16;                         // 16-byte slots per row
+  constexpr int RPB = 256 / RB;                       // rows per 256-byte LDS bank row
+  constexpr int RPI = 1024 / RB;                      // rows moved by one wave-wide DMA instruction
+  constexpr int STAGE = (2 * HM + 2 * HN) * RB;
+  constexpr int NDMA = STAGE / 1024 / 8;              // DMA instructions per wave per stage
+  constexpr int KS = HK / 16;                         // 16-deep MFMA steps per stage
+  static_assert(STAGE % 8192 == 0 && NST * STAGE <= 160 * 1024, "stage geometry");
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
   const H3Args& a = batch.p[blockIdx.y];
-  __shared__ __attribute__((aligned(16))) char lds[H_NSTAGE * H_STAGE];
   int tm, tn;
   h3_tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
   const int m0 = tm * HM, n0 = tn * HN;
@@ -77,63 +103,65 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- DMA: 48 wave-instructions per stage (16 A_hi, 16 A_lo, 8 W_hi, 8 W_lo), 6 per wave -----------
-  const int lrow = lane >> 2, lslot = lane & 3;
-  const char* gsrc[6];
-  int ldst[6];
+  // ---- DMA: stage image = [A_hi | A_lo | W_hi | W_lo], instruction i moves RPI consecutive rows of it ----
+  const int lrow = lane / SL, lslot = lane % SL;
+  const char* gsrc[NDMA];
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const int i = wave * 6 + q;
+  for (int q = 0; q < NDMA; ++q) {
+    const int i = wave * NDMA + q;
+    int ri = i * RPI + lrow;                          // row index inside the stage image
     const char* base;
     long ldb;
     int row, grow;
-    if (i < 32) {                       // A planes
-      row = (i & 15) * 16 + lrow;
+    if (ri < 2 * HM) {
+      const bool lo = ri >= HM;
+      row = lo ? ri - HM : ri;
       grow = min(m0 + row, a.M - 1);
-      base = (const char*)(i < 16 ? a.Ah : a.Al);
+      base = (const char*)(lo ? a.Al : a.Ah);
       ldb = a.lda * 2;
-    } else {                            // W planes
-      row = (i & 7) * 16 + lrow;
+    } else {
+      ri -= 2 * HM;
+      const bool lo = ri >= HN;
+      row = lo ? ri - HN : ri;
       grow = n0 + row;
-      base = (const char*)(i < 40 ? a.Wh : a.Wl);
+      base = (const char*)(lo ? a.Wl : a.Wh);
       ldb = (long)a.Kp * 2;
     }
-    gsrc[q] = base + (long)grow * ldb + 16 * (lslot ^ ((row >> 2) & 3));
-    ldst[q] = i * 1024;                 // stage layout is exactly the instruction order
+    gsrc[q] = base + (long)grow * ldb + 16 * (lslot ^ ((row / RPB) % SL));
   }
   auto issue = [&](int kt, int buf) {
-    char* st = lds + buf * H_STAGE;
+    char* st = lds + buf * STAGE;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) glds16b(gsrc[q] + (long)kt * H_ROWB, st + ldst[q]);
+    for (int q = 0; q < NDMA; ++q) glds16b(gsrc[q] + (long)kt * RB, st + (wave * NDMA + q) * 1024);
   };
 
   // ---- fragment offsets (bytes inside a stage) ---------------------------------------------------------
-  const int sw = (r >> 2) & 3;
-  int aoff[2], boff[2];
+  const int sw = (r / RPB) % SL;
+  int aoff[2], boff[WNT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + i * 32 + r) * H_ROWB;
+  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + i * 32 + r) * RB;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) boff[j] = 2 * HM * H_ROWB + (wn * 64 + j * 32 + r) * H_ROWB;
-  constexpr int A_LO = HM * H_ROWB, W_LO = HN * H_ROWB;
+  for (int j = 0; j < WNT; ++j) boff[j] = 2 * HM * RB + (wn * 32 * WNT + j * 32 + r) * RB;
+  constexpr int A_LO = HM * RB, W_LO = HN * RB;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][WNT], accx[2][WNT];     // hi*hi sums, and the cross terms (scaled by kLoScale)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WNT; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
 
-  struct Frags { h16x8 ah[2], al[2], bh[2], bl[2]; };
+  struct Frags { h16x8 ah[2], al[2], bh[WNT], bl[WNT]; };
   auto load_frags = [&](const char* st, int s, Frags& f) {
-    const int sx = 16 * ((2 * s + h) ^ sw);
+    const int sx = 16 * (((2 * s + h) % SL) ^ sw);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       f.ah[i] = *(const h16x8*)(st + aoff[i] + sx);
       f.al[i] = *(const h16x8*)(st + A_LO + aoff[i] + sx);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WNT; ++j) {
       f.bh[j] = *(const h16x8*)(st + boff[j] + sx);
       f.bl[j] = *(const h16x8*)(st + W_LO + boff[j] + sx);
     }
@@ -142,37 +170,72 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < WNT; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], accx[i][j], 0, 0, 0);
+        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], accx[i][j], 0, 0, 0);
       }
   };
 
-  // 3-stage ring, two K-tiles of LDS-DMA in flight.  Per K-tile: every wave waits until its own DMA
-  // instructions of stage kt have landed (counted vmcnt: the 6 of stage kt+1 may stay outstanding), the
-  // raw barrier then makes the whole stage visible and also proves that every wave is done reading stage
-  // kt-1, whose slot the next DMA (kt+2) overwrites.  __syncthreads() would drain vmcnt(0) instead.
+  // Ring of NST stages, NST-1 K-tiles of LDS-DMA in flight.  Per K-tile: every wave waits until its own DMA
+  // instructions of stage kt have landed (counted vmcnt: the newer stages' instructions may stay
+  // outstanding), the raw barrier then makes the whole stage visible and also proves that every wave is
+  // done reading stage kt-1, whose slot the next DMA overwrites.  __syncthreads() would drain vmcnt(0).
   const int KT = a.Kp / HK;
-  Frags f0, f1;
-  issue(0, 0);
-  if (KT > 1) issue(1, 1);
+#if TEPOSE_H3_ABL == 3
+  Frags f[KS];
+#endif
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < KT) issue(p, p);
   for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int newer = min(NST - 2, KT - 1 - kt);     // stages issued after kt that may still be in flight
+    if (newer >= 2) wait_vm<(NST >= 4 ? 2 : 0) * NDMA>();
+    else if (newer == 1) wait_vm<NDMA>();
+    else wait_vm<0>();
+#if TEPOSE_H3_ABL != 2
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < KT) issue(kt + 2, (kt + 2) % H_NSTAGE);
-    const char* st = lds + (kt % H_NSTAGE) * H_STAGE;
-    load_frags(st, 0, f0);
-    load_frags(st, 1, f1);
-    mma(f0);
-    mma(f1);
+#endif
+    const char* st = lds + (kt % NST) * STAGE;
+    // Fragments first, then the MFMAs with the next stage's DMA instructions spread between them: all 8
+    // waves leave the barrier together, so DMA issued up front would keep every matrix pipe idle meanwhile.
+    const bool more = kt + NST - 1 < KT;
+    char* dst = lds + ((kt + NST - 1) % NST) * STAGE;
+    const long koff = (long)(kt + NST - 1) * RB;
+#if TEPOSE_H3_ABL != 3
+    Frags f[KS];
+#endif
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#if TEPOSE_H3_ABL == 3
+      if (kt == 0)
+#endif
+      load_frags(st, ks, f[ks]);
+    }
+    int q = 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bh[j], acc[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bl[j], accx[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].al[i], f[ks].bh[j], accx[i][j], 0, 0, 0);
+          if (q < NDMA) {
+#if TEPOSE_H3_ABL != 1
+            if (more) glds16b(gsrc[q] + koff, dst + (wave * NDMA + q) * 1024);
+#endif
+            ++q;
+          }
+        }
+    static_assert(NDMA <= KS * 2 * WNT, "one DMA per MFMA triple");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vm<0>();
 
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + r;
+  for (int j = 0; j < WNT; ++j) {
+    const int col = n0 + wn * 32 * WNT + j * 32 + r;
     if (col >= a.N) continue;
     const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
@@ -180,7 +243,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < a.M) a.C[(long)row * a.ldc + col] = acc[i][j][e] + bv;
+        if (row < a.M) a.C[(long)row * a.ldc + col] = (acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale)) + bv;
       }
     }
   }
@@ -189,7 +252,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
 // test / bench entry: fp32 A[M,K], W[N,K] -> planes in `ws` -> C (K multiple of 32)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s) {
-  const int Np = round_up(N, 128);
+  const int Np = round_up(N, 256);     // the widest tile variant reads 256-row W panels
   char* p = (char*)ws;
   _Float16* Ah = (_Float16*)p; p += align_up((size_t)M * K * 2, 256);
   _Float16* Al = (_Float16*)p; p += align_up((size_t)M * K * 2, 256);
@@ -208,8 +271,18 @@ hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw
 // up to 3 independent products of the same M, N, Kp in one launch (the directions of a GRU step)
 hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
-  const int tilesM = (b.p[0].M + HM - 1) / HM, tilesN = (b.p[0].N + HN - 1) / HN;
-  hipLaunchKernelGGL(gemm_h3_kernel, dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM, tilesN);
+  static const int variant = [] {
+    const char* e = getenv("TEPOSE_H3_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  const int tilesM = (b.p[0].M + HM - 1) / HM;
+  if (variant == 2) {            // 256 x 128 tile, K-tile 16, 4-stage ring
+    const int tilesN = (b.p[0].N + 127) / 128;
+    hipLaunchKernelGGL((gemm_h3_kernel<2, 16, 4>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM, tilesN);
+  } else {                       // 256 x 128 tile, K-tile 32, 3-stage ring
+    const int tilesN = (b.p[0].N + 127) / 128;
+    hipLaunchKernelGGL((gemm_h3_kernel<2, 32, 3>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM, tilesN);
+  }
   return hipGetLastError();
 }
 
@@ -221,9 +294,7 @@ __global__ void __launch_bounds__(256) pad_input_planes_kernel(const float* __re
     const long row = idx / kInputP;
     const int k = (int)(idx - row * kInputP);
     const float a = k < kInput ? x[row * kInput + k] : 0.f;
-    const _Float16 h = (_Float16)a;
-    hi[idx] = h;
-    lo[idx] = (_Float16)(a - (float)h);
+    split_hi_lo(a, hi[idx], lo[idx]);
   }
 }
 
@@ -260,9 +331,7 @@ __global__ void __launch_bounds__(256) gru_gates_kernel(GateBatch gb, int M, int
     const float ng = g_tanh(gi[2 * Hp] + rg * hn);
     const float hv = (1.f - zg) * ng + zg * hp;
     d.hout[row * d.ldo + j] = hv;
-    const _Float16 hh = (_Float16)hv;
-    d.hout_hi[row * d.ldo + j] = hh;
-    d.hout_lo[row * d.ldo + j] = (_Float16)(hv - (float)hh);
+    split_hi_lo(hv, d.hout_hi[row * d.ldo + j], d.hout_lo[row * d.ldo + j]);
   }
 }
 
@@ -275,7 +344,7 @@ hipError_t launch_gru_gates(const GateBatch& gb, int ndir, int M, int Hp, int fi
 }
 
 size_t gemm_h3_ws_bytes(int M, int N, int K) {
-  return 2 * align_up((size_t)M * K * 2, 256) + 2 * align_up((size_t)round_up(N, 128) * K * 2, 256) + 256;
+  return 2 * align_up((size_t)M * K * 2, 256) + 2 * align_up((size_t)round_up(N, 256) * K * 2, 256) + 256;
 }
 
 }  // namespace tepose

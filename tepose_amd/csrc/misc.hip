@@ -39,9 +39,7 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
     if (a.dst) {
       a.dst[idx] = v;
     } else {                              // hi / lo fp16 planes for the split-precision GEMM
-      const half_t hv = (half_t)v;
-      a.dst_hi[idx] = hv;
-      a.dst_lo[idx] = (half_t)(v - (float)hv);
+      split_hi_lo(v, a.dst_hi[idx], a.dst_lo[idx]);
     }
   }
 }

@@ -66,3 +66,49 @@ def test_big_kernels_are_bitwise_repeatable_under_load():
         for _ in range(8):
             noise = noise * 0.9999 - 1.0
             assert torch.equal(ref, model.encoder(x))
+
+
+def test_split_precision_gemm_random_shapes_against_fp64():
+    """csrc/gemm_h3.hip: fp16 hi/lo planes, three fp16 MFMAs per k-step, fp32 accumulate.  Same error
+    bound as the exact-fp32 kernel on GRU-like operand ranges, incl. subnormal low halves."""
+    from tepose_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(11)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    for it in range(40):
+        M = int(rng.choice([1, 63, 255, 256, 257, 769, 1000, 3000]))
+        N = int(rng.choice([1, 100, 128, 129, 257, 1000, 3072]))
+        K = 32 * int(rng.randint(1, 70))
+        scale = float(rng.choice([1e-4, 0.03, 1.0, 30.0]))
+        A = torch.randn(M, K, device='cuda', generator=g) * float(rng.choice([0.01, 1.0, 8.0]))
+        W = torch.randn(N, K, device='cuda', generator=g) * scale
+        b = torch.randn(N, device='cuda', generator=g)
+        C = torch.full((M, N), float('nan'), device='cuda')
+        ws = torch.empty(lib.tepose_gemm_h3_workspace_bytes(M, N, K), dtype=torch.uint8, device='cuda')
+        rc = lib.tepose_gemm_h3_f32(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), C.data_ptr(), N, M, N, K,
+                                    ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = A.double() @ W.double().t() + b.double()
+        mag = (A.double().abs() @ W.double().abs().t()).max().item() + 1.0
+        err = (C.double() - ref).abs().max().item()
+        assert err < 3e-6 * mag, (it, M, N, K, scale, err, mag)      # ~2^-19 of the absolute dot product
+
+
+def test_split_and_exact_paths_agree_on_a_large_batch(monkeypatch):
+    """B > 768 runs the GRU matmuls on the split-precision kernel; TEPOSE_EXACT_FP32=1 (read when the
+    handle is created) keeps them on the exact-fp32 MFMA.  Same inputs, both paths: outputs within 1e-5."""
+    from tepose_amd.testing import build_model
+    smpl_np = synth.synthetic_smpl(0)
+    x = torch.from_numpy(synth.synthetic_windows(900, 6, 17)).cuda()
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    fast, _, _ = build_model(2, 256, seed=5, device='cuda', smpl_np=smpl_np)
+    monkeypatch.setenv('TEPOSE_EXACT_FP32', '1')
+    exact, _, _ = build_model(2, 256, seed=5, device='cuda', smpl_np=smpl_np)
+    monkeypatch.delenv('TEPOSE_EXACT_FP32')
+    with torch.no_grad():
+        a = fast(x, J_regressor=J)[0]
+        b = exact(x, J_regressor=J)[0]
+    for k in ('verts', 'kp_3d', 'rotmat', 'kp_2d'):
+        d = (a[k] - b[k]).abs().max().item()
+        assert 0 < d < 1e-5 or (k != 'verts' and d < 1e-5), (k, d)
+    assert (a['theta'][:, :3] - b['theta'][:, :3]).abs().max() < 1e-5
