@@ -31,6 +31,8 @@ if ROOT not in sys.path:
 # algorithmic work per window, L=2 H=1024
 GFLOP_PER_WINDOW = {6: 0.600, 16: 1.497, 32: 2.931}
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, fp32-input MFMA
+PEAK_F16_MFMA_TFLOPS = 2516.6         # dense fp16/bf16 MFMA (16x the fp32-input rate, ~2.5 PF spec)
+SPLIT_PRODUCTS = 3                    # fp16 MFMAs per fp32-equivalent product in csrc/gemm_h3.hip
 
 
 def synthetic_windows_device(B, T, seed, device):
@@ -209,7 +211,11 @@ def main():
             'metric': '16-frame windows/sec (whole node)' if T == 16 else '%d-frame windows/sec (whole node)' % T,
             'value': windows / t_max, 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if (os.environ.get('TEPOSE_EXACT_FP32', '0') not in ('', '0') or B <= 768) else
+                     'f16x3-split/f32-acc (GRU matmuls: fp32 operands as fp16 hi+lo halves, 22 significant bits, fp32 '
+                     'accumulate; everything else f32)',
+            'data': 'synthetic',
             'config': {'workload': 'cfg-C synthetic [%d,%d,2133] fp32 windows per GPU, TePose n_layers=2 '
                                    'hidden=1024, random-init weights, synthetic SMPL tables, H36M-14 joint path'
                                    % (B, T),
@@ -218,20 +224,35 @@ def main():
         }
         if T in GFLOP_PER_WINDOW:
             res['whole_path_tflops'] = windows * GFLOP_PER_WINDOW[T] / t_max / 1e3
-            res['whole_path_frac_of_f32_mfma_peak'] = res['whole_path_tflops'] / (PEAK_F32_MFMA_TFLOPS * world)
+            res['whole_path_frac_of_f32_mfma_peak'] = res['whole_path_tflops'] / (PEAK_F32_MFMA_TFLOPS * world)   # > 1 is possible in split mode
+        split = os.environ.get('TEPOSE_EXACT_FP32', '0') in ('', '0') and B > 768
         if k_n > 0:
             ach = k_flops / (k_ms / k_n * 1e-3) / 1e12
-            res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(B, T),
-                               'kernel': 'gemm_f32_kernel<false> (layer-0 input projection, M=%d N=9216 K=2133)'
-                                         % (B * T),
-                               'launches': k_n, 'avg_ms': k_ms / k_n}
+            if split:
+                peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
+                res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                                   'traffic': pmc_traffic(B, T),
+                                   'kernel': 'gemm_h3_kernel<2,32,3> (layer-0 input projection, M=%d N=9216 K=2133)'
+                                             % (B * T),
+                                   'launches': k_n, 'avg_ms': k_ms / k_n,
+                                   'note': 'achieved = algorithmic fp32-equivalent FLOP/s; the kernel issues %d fp16 MFMAs '
+                                           'per product (hi*hi, hi*lo, lo*hi; fp32 accumulate), so peak = dense fp16 '
+                                           'MFMA %.1f / %d; executed MFMA rate = %.0f TFLOP/s'
+                                           % (SPLIT_PRODUCTS, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS, ach * SPLIT_PRODUCTS)}
+            else:
+                res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(B, T),
+                                   'kernel': 'gemm_f32_kernel<false> (layer-0 input projection, M=%d N=9216 K=2133)'
+                                             % (B * T),
+                                   'launches': k_n, 'avg_ms': k_ms / k_n}
         if g_n > 0:
             gach = g_flops / (g_ms / g_n * 1e-3) / 1e12
-            res['roofline_gru_steps'] = {'bound': 'mfma', 'achieved': gach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                                         'unit': 'TFLOP/s', 'frac': gach / PEAK_F32_MFMA_TFLOPS,
-                                         'kernel': 'gru_step_kernel: the %d step launches of one forward (5T+1 consumed cell '
-                                                   'steps, first-step matmuls skipped but counted)' % (2 * T + 1),
+            gpeak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS if split else PEAK_F32_MFMA_TFLOPS
+            res['roofline_gru_steps'] = {'bound': 'mfma', 'achieved': gach, 'peak': gpeak,
+                                         'unit': 'TFLOP/s', 'frac': gach / gpeak,
+                                         'kernel': ('gemm_h3_kernel + gru_gates_kernel' if split else 'gru_step_kernel') +
+                                                   ': the %d step launches of one forward (5T+1 consumed cell steps, '
+                                                   'first-step matmuls skipped but counted)' % (2 * T + 1),
                                          'ms_per_forward': g_ms / g_n}
         if bcast_ms is not None:
             res['weight_broadcast_ms'] = bcast_ms
@@ -239,6 +260,26 @@ def main():
             res['per_rank'] = [[float(v) for v in g.tolist()] for g in gathered]
             sums = [r[4] for r in res['per_rank']]
             res['ranks_agree'] = bool(max(sums) - min(sums) <= 1e-6 * max(sums))
+        if world == 1 and split and not args.no_extra:
+            # the same workload with every product on the exact-fp32 MFMA (TEPOSE_EXACT_FP32=1), for comparison
+            os.environ['TEPOSE_EXACT_FP32'] = '1'
+            model_x, _, _ = build_model(L, H, seed=0, device=device, smpl_np=smpl_np, seqlen=T, state=state)
+            del os.environ['TEPOSE_EXACT_FP32']
+            with torch.no_grad():
+                ox = model_x(x, J_regressor=J)[0]
+                torch.cuda.synchronize()
+                tx = time.perf_counter()
+                for _ in range(args.steps):
+                    ox = model_x(x, J_regressor=J)[0]
+                torch.cuda.synchronize()
+            tx = (time.perf_counter() - tx) / args.steps
+            res['exact_fp32_mode'] = {'value': B / tx, 'ms_per_step': tx * 1e3,
+                                      'whole_path_frac_of_f32_mfma_peak': B * GFLOP_PER_WINDOW.get(T, 0) / tx / 1e3 / PEAK_F32_MFMA_TFLOPS,
+                                      'max_abs_diff_verts_vs_default': float((ox['verts'] - out['verts']).abs().max().item()),
+                                      'max_abs_diff_kp3d_vs_default': float((ox['kp_3d'] - out['kp_3d']).abs().max().item())}
+            del model_x, ox
+            torch.cuda.empty_cache()
+            _t('exact-fp32 comparison done')
         if world == 1 and not args.no_extra:
             # the other BASELINE.json shapes, outside the timed region (informational, not `value`)
             extra = {}

@@ -46,6 +46,7 @@ struct tepose_model {
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
   bool split = true;                            // large batches run their GRU matmuls on the fp16x3 split kernel
+  bool fused_gates = true;                      // ... with the cell update in the recurrent product's epilogue
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -265,6 +266,8 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
   {
     const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
     m->split = !(e && atoi(e) != 0);
+    e = getenv("TEPOSE_H3_UNFUSED");                  // 1: separate gate kernel after the recurrent product (A/B)
+    m->fused_gates = !(e && atoi(e) != 0);
   }
   layout(m);
   *out = m;
@@ -425,7 +428,8 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
         CK((hipError_t)pack_planes(d.ih, K, 3 * H, K, B + d.d->wih_p, n128, Kp, ROW_GATES,
                                    d.split ? COL_SPLIT2 : COL_PLAIN, H, Hp, s));
       }
-      CK((hipError_t)pack_planes(d.hh, H, 3 * H, H, B + d.d->whh_p, n128, Hp, ROW_GATES, COL_PLAIN, H, Hp, s));
+      CK((hipError_t)pack_planes(d.hh, H, 3 * H, H, B + d.d->whh_p, n128, Hp,
+                                 m->fused_gates ? ROW_GATES_TILED : ROW_GATES, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.hh, H, 3 * H, H, B + d.d->whh, 3 * Hp, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.bhh, 1, 3 * H, 1, B + d.d->bhh, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
     }
@@ -595,6 +599,18 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   // one GRU step of up to 3 directions: fused fp32 kernel, or split product + gate kernel
   auto step = [&](const GruArgs& a, const size_t (&whh_planes)[3]) -> int {
     if (!h3) return (int)launch_gru_step(a, s);
+    if (!a.first && m->fused_gates) {
+      H3Batch b{};
+      for (int d = 0; d < a.ndir; ++d) {
+        const half_t* wh = (const half_t*)(Bl + whh_planes[d]);
+        b.p[d] = H3Args{w.hi_of(a.d[d].hprev), w.lo_of(a.d[d].hprev), a.d[d].ldh, wh, wh + n128 * Hp, Hp,
+                        nullptr, 0, nullptr, B, H3};
+        b.gate[d] = GateDir{a.d[d].gi, a.d[d].ldgi, nullptr, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh,
+                            a.d[d].hout, w.hi_of(a.d[d].hout), w.lo_of(a.d[d].hout), a.d[d].ldo};
+      }
+      b.n = a.ndir; b.Hp = Hp;
+      return (int)launch_gru_h3(b, s);
+    }
     if (!a.first) {
       H3Batch b{};
       for (int d = 0; d < a.ndir; ++d) {

@@ -137,16 +137,19 @@ struct H3Args {
   const float* bias;                  // [N] or nullptr
   int M, N;
 };
-struct H3Batch { H3Args p[3]; int n; };
-hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
-hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s);
 struct GateDir {
   const float* gi; long ldgi;         // x W_ih^T + b_ih, [row*ldgi + g*Hp + j]
-  const float* gh;                    // h W_hh^T, [row][3Hp] (ignored when first)
+  const float* gh;                    // h W_hh^T, [row][3Hp] (gate kernel only; ignored when first)
   const float* bhh;                   // [3Hp]
   const float* hprev; long ldh;       // fp32 previous state (ignored when first)
   float* hout; half_t* hout_hi; half_t* hout_lo; long ldo;   // same row stride for the three outputs
 };
+struct H3Batch { H3Args p[3]; GateDir gate[3]; int n; int Hp; };
+hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
+// recurrent product with the GRU cell update fused into the epilogue: W planes in the gate-interleaved tile
+// order (ROW_GATES_TILED), p[d].C unused, gate[d] describes the cell operands / outputs
+hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s);
+hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s);
 struct GateBatch { GateDir d[3]; };
 hipError_t launch_gru_gates(const GateBatch& gb, int ndir, int M, int Hp, int first, hipStream_t s);
 hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, void* hi, void* lo, hipStream_t s);

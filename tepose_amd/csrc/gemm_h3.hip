@@ -24,7 +24,6 @@ namespace tepose {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int HM = 256;                               // block rows: 4 waves along M x 2 fragments of 32
 
 __device__ __forceinline__ void glds16b(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -73,6 +72,8 @@ __device__ __forceinline__ void wait_vm() {          // s_waitcnt vmcnt(N) with 
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -81,11 +82,22 @@ __device__ __forceinline__ void wait_vm() {          // s_waitcnt vmcnt(N) with 
   else static_assert(N == 0, "add the literal");
 }
 
-// WNT: 32-column MFMA tiles per wave along N (block columns = 64 * WNT); HK: K-tile (32 | 16);
-// NST: stages in the LDS ring (NST - 1 K-tiles of DMA in flight).
-template <int WNT, int HK, int NST>
+__device__ __forceinline__ float g_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float g_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+}
+
+// WMF: 32-row MFMA fragments per wave along M (block rows = 128 * WMF); WNT: 32-column tiles per wave along
+// N (block columns = 64 * WNT); HK: K-tile (32 | 16); NST: stages in the LDS ring (NST - 1 K-tiles of DMA in
+// flight); GRU: the wave's 3 column tiles are the r, z, n gates of the same 32 hidden units and the epilogue is
+// the GRU cell update (fp32 state + hi/lo planes out) instead of a plain store.
+template <int WMF, int WNT, int HK, int NST, bool GRU>
 __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tilesM, int tilesN) {
+  constexpr int HM = 128 * WMF;
   constexpr int HN = 64 * WNT;
+  static_assert(!GRU || WNT == 3, "GRU epilogue needs the three gate tiles in one wave");
   constexpr int RB = HK * 2;                          // bytes per tile row of one plane
   constexpr int SL = RB / 16;                         // 16-byte slots per row
   constexpr int RPB = 256 / RB;                       // rows per 256-byte LDS bank row
@@ -137,26 +149,26 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
 
   // ---- fragment offsets (bytes inside a stage) ---------------------------------------------------------
   const int sw = (r / RPB) % SL;
-  int aoff[2], boff[WNT];
+  int aoff[WMF], boff[WNT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + i * 32 + r) * RB;
+  for (int i = 0; i < WMF; ++i) aoff[i] = (wm * 32 * WMF + i * 32 + r) * RB;
 #pragma unroll
   for (int j = 0; j < WNT; ++j) boff[j] = 2 * HM * RB + (wn * 32 * WNT + j * 32 + r) * RB;
   constexpr int A_LO = HM * RB, W_LO = HN * RB;
 
-  f32x16 acc[2][WNT], accx[2][WNT];     // hi*hi sums, and the cross terms (scaled by kLoScale)
+  f32x16 acc[WMF][WNT], accx[WMF][WNT];     // hi*hi sums, and the cross terms (scaled by kLoScale)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WMF; ++i)
 #pragma unroll
     for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
 
-  struct Frags { h16x8 ah[2], al[2], bh[WNT], bl[WNT]; };
+  struct Frags { h16x8 ah[WMF], al[WMF], bh[WNT], bl[WNT]; };
   auto load_frags = [&](const char* st, int s, Frags& f) {
     const int sx = 16 * (((2 * s + h) % SL) ^ sw);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WMF; ++i) {
       f.ah[i] = *(const h16x8*)(st + aoff[i] + sx);
       f.al[i] = *(const h16x8*)(st + A_LO + aoff[i] + sx);
     }
@@ -166,17 +178,6 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
       f.bl[j] = *(const h16x8*)(st + W_LO + boff[j] + sx);
     }
   };
-  auto mma = [&](const Frags& f) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], accx[i][j], 0, 0, 0);
-        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], accx[i][j], 0, 0, 0);
-      }
-  };
-
   // Ring of NST stages, NST-1 K-tiles of LDS-DMA in flight.  Per K-tile: every wave waits until its own DMA
   // instructions of stage kt have landed (counted vmcnt: the newer stages' instructions may stay
   // outstanding), the raw barrier then makes the whole stage visible and also proves that every wave is
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WMF; ++i)
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bh[j], acc[i][j], 0, 0, 0);
@@ -229,21 +230,57 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
             ++q;
           }
         }
-    static_assert(NDMA <= KS * 2 * WNT, "one DMA per MFMA triple");
+    static_assert(NDMA <= KS * WMF * WNT, "one DMA per MFMA triple");
   }
   wait_vm<0>();
 
+  if constexpr (GRU) {
+    // columns of this wave: gates r, z, n of hidden units j = tn*64 + wn*32 + r (ROW_GATES_TILED order)
+    const GateDir& d = batch.gate[blockIdx.y];
+    const int Hp = batch.Hp;
+    const int j = tn * 64 + wn * 32 + r;
+    const float br = d.bhh[j], bz = d.bhh[Hp + j], bn = d.bhh[2 * Hp + j];
 #pragma unroll
-  for (int j = 0; j < WNT; ++j) {
-    const int col = n0 + wn * 32 * WNT + j * 32 + r;
-    if (col >= a.N) continue;
-    const float bv = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WMF; ++i) {
+      const int rbase = m0 + wm * 32 * WMF + i * 32 + 4 * h;
+      float gr[16], gz[16], gn[16], hp[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < a.M) a.C[(long)row * a.ldc + col] = (acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale)) + bv;
+        const int row = min(rbase + (e & 3) + 8 * (e >> 2), a.M - 1);
+        const float* gi = d.gi + (long)row * d.ldgi + j;
+        gr[e] = gi[0]; gz[e] = gi[Hp]; gn[e] = gi[2 * Hp];
+        hp[e] = d.hprev[(long)row * d.ldh + j];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        const float hr = acc[i][0][e] + accx[i][0][e] * (1.f / kLoScale);
+        const float hz = acc[i][1][e] + accx[i][1][e] * (1.f / kLoScale);
+        const float hn = acc[i][2][e] + accx[i][2][e] * (1.f / kLoScale);
+        const float rg = g_sigmoid(gr[e] + (hr + br));
+        const float zg = g_sigmoid(gz[e] + (hz + bz));
+        const float ng = g_tanh(gn[e] + rg * (hn + bn));
+        const float hv = (1.f - zg) * ng + zg * hp[e];
+        if (row < a.M) {
+          const long o = (long)row * d.ldo + j;
+          d.hout[o] = hv;
+          split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = n0 + wn * 32 * WNT + j * 32 + r;
+      if (col >= a.N) continue;
+      const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < WMF; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < a.M) a.C[(long)row * a.ldc + col] = (acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale)) + bv;
+        }
       }
     }
   }
@@ -275,14 +312,24 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
     const char* e = getenv("TEPOSE_H3_VARIANT");
     return e ? atoi(e) : 0;
   }();
-  const int tilesM = (b.p[0].M + HM - 1) / HM;
+  const int tilesM = (b.p[0].M + 255) / 256;
   if (variant == 2) {            // 256 x 128 tile, K-tile 16, 4-stage ring
     const int tilesN = (b.p[0].N + 127) / 128;
-    hipLaunchKernelGGL((gemm_h3_kernel<2, 16, 4>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 16, 4, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM,
+                       tilesN);
   } else {                       // 256 x 128 tile, K-tile 32, 3-stage ring
     const int tilesN = (b.p[0].N + 127) / 128;
-    hipLaunchKernelGGL((gemm_h3_kernel<2, 32, 3>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 32, 3, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM,
+                       tilesN);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s) {
+  if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
+  const int tilesM = (b.p[0].M + 127) / 128, tilesJ = b.Hp / 64;   // block = 128 rows x (64 hidden units x 3 gates)
+  hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 32, 3, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM,
+                     tilesJ);
   return hipGetLastError();
 }
 
@@ -308,12 +355,6 @@ hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows
 
 // GRU gate update after the recurrent product gh = h W_hh^T (natural gate order [r | z | n], no bias):
 // thread = (row, hidden unit); writes the new state as fp32 and as hi / lo planes for the next product.
-__device__ __forceinline__ float g_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
-}
-__device__ __forceinline__ float g_tanh(float x) {
-  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
-}
 __global__ void __launch_bounds__(256) gru_gates_kernel(GateBatch gb, int M, int Hp, int first) {
   const GateDir& d = gb.d[blockIdx.y];
   const long total = (long)M * Hp;
