@@ -46,5 +46,36 @@ def pmc(path):
         print('%-52s %10s %-12s %6d %16.1f' % (k, g, c, len(v), sum(v) / len(v)))
 
 
+def sq(counter_path, trace_path):
+    """SQ pass (tools/profile.sh): clock from GRBM_GUI_ACTIVE (summed over the 8 XCDs), MFMA busy share of
+    the 1024 SIMDs, wait shares of the wave cycles; durations from the same run's kernel trace."""
+    dur = {}
+    for r in csv.DictReader(open(trace_path)):
+        dur[r['Dispatch_Id']] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    per = defaultdict(dict)
+    meta = {}
+    for r in csv.DictReader(open(counter_path)):
+        per[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
+        meta[r['Dispatch_Id']] = (short(r['Kernel_Name']), r['Grid_Size'])
+    agg = defaultdict(list)
+    for d, c in per.items():
+        if d in dur and 'GRBM_GUI_ACTIVE' in c:
+            agg[meta[d]].append((dur[d], c))
+    print('%-44s %9s %4s %10s %8s %9s %9s %9s' % ('kernel', 'grid', 'n', 'dur_us', 'clk_GHz', 'mfma_busy',
+                                                    'wait_any', 'wait_inst'))
+    for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
+        if not k.startswith(('gemm', 'gru')):
+            continue
+        n = len(v)
+        du = sum(x[0] for x in v) / n
+        f = lambda name: sum(x[1].get(name, 0.) for x in v) / n
+        cyc = f('GRBM_GUI_ACTIVE') / 8
+        print('%-44s %9s %4d %10.1f %8.3f %9.3f %9.3f %9.3f' % (
+            k, g, n, du, cyc / du / 1e3, f('SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * cyc),
+            f('SQ_WAIT_ANY') / max(f('SQ_WAVE_CYCLES'), 1), f('SQ_WAIT_INST_ANY') / max(f('SQ_WAVE_CYCLES'), 1)))
+    print('# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles at the measured clock); '
+          'wait_* = share of SQ_WAVE_CYCLES')
+
+
 if __name__ == '__main__':
-    {'trace': trace, 'pmc': pmc}[sys.argv[1]](sys.argv[2])
+    {'trace': trace, 'pmc': pmc, 'sq': sq}[sys.argv[1]](*sys.argv[2:])

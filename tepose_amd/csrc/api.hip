@@ -17,7 +17,7 @@ namespace {
 struct DirW {                     // one GRU layer/direction inside the blob (float offsets)
   size_t wih = 0, bih = 0;        // input projection (layer-0 ones live in the stacked block)
   size_t whh = 0, bhh = 0;
-  size_t wih_p = 0, whh_p = 0;    // hi|lo fp16 planes of the same matrices (natural gate order), float offsets
+  size_t wih_p = 0, whh_p = 0;    // blocked hi|lo fp16 planes of the same matrices (whh: gate-tiled rows), float offsets
 };
 
 struct SmplOff {
@@ -46,7 +46,6 @@ struct tepose_model {
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
   bool split = true;                            // large batches run their GRU matmuls on the fp16x3 split kernel
-  bool fused_gates = true;                      // ... with the cell update in the recurrent product's epilogue
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -158,15 +157,15 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
 
 int pack(const float* src, long ld, int N, int K, float* dst, int Np, int Kp, int rowmap, int colmap,
          int H, int Hp, hipStream_t s) {
-  PackArgs a{src, ld, N, K, dst, Np, Kp, nullptr, nullptr, rowmap, colmap, H, Hp};
+  PackArgs a{src, ld, N, K, dst, Np, Kp, nullptr, nullptr, 0, rowmap, colmap, H, Hp};
   return (int)launch_pack(a, s);
 }
 
-// same mapping, written as hi / lo fp16 planes (lo plane follows the hi plane: Np*Kp halfs each)
+// same mapping, written as K-tile-blocked hi / lo fp16 planes of [Np x Kp] (lo plane follows the hi plane)
 int pack_planes(const float* src, long ld, int N, int K, float* dst_planes, int Np, int Kp, int rowmap, int colmap,
                 int H, int Hp, hipStream_t s) {
   half_t* hi = (half_t*)dst_planes;
-  PackArgs a{src, ld, N, K, nullptr, Np, Kp, hi, hi + (size_t)Np * Kp, rowmap, colmap, H, Hp};
+  PackArgs a{src, ld, N, K, nullptr, Np, Kp, hi, hi + (size_t)Np * Kp, (long)Np * 32, rowmap, colmap, H, Hp};
   return (int)launch_pack(a, s);
 }
 
@@ -183,11 +182,24 @@ struct Carver {
 // Buffers of one encoder forward (shared between sizing and execution).
 struct EncWs {
   float *xp, *g0, *g0c, *gf, *grr, *grf, *sf[2], *sr[2], *pf[2], *pr[2], *ytop, *y1;
-  // split-precision path: every state buffer between state_base and ytop's end has fp16 hi / lo mirrors at
-  // the same element offset; gh = recurrent products of up to 3 directions
-  float* state_base; size_t state_floats; half_t *state_hi, *state_lo; float* gh;
-  half_t* hi_of(const float* p) const { return state_hi + (p - state_base); }
-  half_t* lo_of(const float* p) const { return state_lo + (p - state_base); }
+  // split-precision path: every state buffer between state_base and ytop's end has fp16 hi / lo mirrors that
+  // start at the same element offset and hold the buffer's [R x C] matrix K-tile-blocked (common.h)
+  float* state_base; size_t state_floats; half_t *state_hi, *state_lo;
+  struct Buf { const float* base; size_t R, C; };
+  Buf bufs[9]; int nbufs = 0;
+  struct View { half_t *hi, *lo; long kst; };
+  // planes of the sub-matrix that starts at fp32 element p (row stride = the owning buffer's C)
+  View view(const float* p) const {
+    for (int i = 0; i < nbufs; ++i) {
+      const Buf& b = bufs[i];
+      if (p >= b.base && p < b.base + b.R * b.C) {
+        const size_t off = (size_t)(p - b.base), row = off / b.C, col = off % b.C;
+        const size_t e = (size_t)(b.base - state_base) + (size_t)plane_index((long)row, (long)col, (long)b.R);
+        return View{state_hi + e, state_lo + e, (long)b.R * 32};
+      }
+    }
+    return View{nullptr, nullptr, 0};
+  }
 };
 
 void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
@@ -207,14 +219,20 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
     w.sr[i] = c.f(need ? BT * 2 * Hp : 0);
     w.pf[i] = c.f((size_t)B * Hp);
     w.pr[i] = c.f((size_t)B * Hp);
+    if (need) {
+      w.bufs[w.nbufs++] = EncWs::Buf{w.sf[i], BT, Hp};
+      w.bufs[w.nbufs++] = EncWs::Buf{w.sr[i], BT, 2 * Hp};
+    }
+    w.bufs[w.nbufs++] = EncWs::Buf{w.pf[i], (size_t)B, Hp};
+    w.bufs[w.nbufs++] = EncWs::Buf{w.pr[i], (size_t)B, Hp};
   }
   w.ytop = c.f((size_t)B * 2 * Hp);
+  w.bufs[w.nbufs++] = EncWs::Buf{w.ytop, (size_t)B, 2 * Hp};
   w.state_floats = (c.cur - state_begin) / sizeof(float);
   w.y1 = c.f((size_t)B * kFeat);
   const bool h3 = m->split && B > skinny_max_m();
   w.state_hi = (half_t*)c.f(h3 ? w.state_floats / 2 + 64 : 0);
   w.state_lo = (half_t*)c.f(h3 ? w.state_floats / 2 + 64 : 0);
-  w.gh = c.f(h3 ? (size_t)3 * B * 3 * Hp : 0);
 }
 
 struct RegWs {
@@ -266,8 +284,6 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
   {
     const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
     m->split = !(e && atoi(e) != 0);
-    e = getenv("TEPOSE_H3_UNFUSED");                  // 1: separate gate kernel after the recurrent product (A/B)
-    m->fused_gates = !(e && atoi(e) != 0);
   }
   layout(m);
   *out = m;
@@ -409,8 +425,8 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
     half_t* hi = (half_t*)(B + m->wih0_p);
     half_t* lo = hi + rows0 * kInputP;
     for (int d = 0; d < 3; ++d) {
-      PackArgs a{l0[d], kInput, 3 * H, kInput, nullptr, 3 * Hp, kInputP, hi + (size_t)d * 3 * Hp * kInputP,
-                 lo + (size_t)d * 3 * Hp * kInputP, ROW_GATES, COL_PLAIN, H, Hp};
+      PackArgs a{l0[d], kInput, 3 * H, kInput, nullptr, 3 * Hp, kInputP, hi + (size_t)d * 3 * Hp * 32,
+                 lo + (size_t)d * 3 * Hp * 32, (long)rows0 * 32, ROW_GATES, COL_PLAIN, H, Hp};
       CK(launch_pack(a, s));
     }
   }
@@ -428,8 +444,7 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
         CK((hipError_t)pack_planes(d.ih, K, 3 * H, K, B + d.d->wih_p, n128, Kp, ROW_GATES,
                                    d.split ? COL_SPLIT2 : COL_PLAIN, H, Hp, s));
       }
-      CK((hipError_t)pack_planes(d.hh, H, 3 * H, H, B + d.d->whh_p, n128, Hp,
-                                 m->fused_gates ? ROW_GATES_TILED : ROW_GATES, COL_PLAIN, H, Hp, s));
+      CK((hipError_t)pack_planes(d.hh, H, 3 * H, H, B + d.d->whh_p, n128, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.hh, H, 3 * H, H, B + d.d->whh, 3 * Hp, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.bhh, 1, 3 * H, 1, B + d.d->bhh, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
     }
@@ -592,41 +607,35 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     }
     H3Batch b{};
     const half_t* wh = (const half_t*)(Bl + w_planes);
-    b.p[0] = H3Args{w.hi_of(in), w.lo_of(in), (long)K, wh, wh + n128 * K, K, out, (long)H3, Bl + bias, M, H3};
+    const EncWs::View v = w.view(in);
+    if (!v.hi) return (int)hipErrorInvalidValue;
+    b.p[0] = H3Args{v.hi, v.lo, 32, v.kst, wh, wh + n128 * K, (long)n128 * 32, K, out, (long)H3, Bl + bias, M, H3};
     b.n = 1;
     return (int)launch_gemm_h3(b, s);
   };
-  // one GRU step of up to 3 directions: fused fp32 kernel, or split product + gate kernel
+  // one GRU step of up to 3 directions: fused fp32 kernel; or the split product with the cell update in its
+  // epilogue (first step: h = 0, element-wise kernel)
   auto step = [&](const GruArgs& a, const size_t (&whh_planes)[3]) -> int {
     if (!h3) return (int)launch_gru_step(a, s);
-    if (!a.first && m->fused_gates) {
-      H3Batch b{};
-      for (int d = 0; d < a.ndir; ++d) {
-        const half_t* wh = (const half_t*)(Bl + whh_planes[d]);
-        b.p[d] = H3Args{w.hi_of(a.d[d].hprev), w.lo_of(a.d[d].hprev), a.d[d].ldh, wh, wh + n128 * Hp, Hp,
-                        nullptr, 0, nullptr, B, H3};
-        b.gate[d] = GateDir{a.d[d].gi, a.d[d].ldgi, nullptr, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh,
-                            a.d[d].hout, w.hi_of(a.d[d].hout), w.lo_of(a.d[d].hout), a.d[d].ldo};
-      }
-      b.n = a.ndir; b.Hp = Hp;
-      return (int)launch_gru_h3(b, s);
-    }
-    if (!a.first) {
-      H3Batch b{};
-      for (int d = 0; d < a.ndir; ++d) {
-        const half_t* wh = (const half_t*)(Bl + whh_planes[d]);
-        b.p[d] = H3Args{w.hi_of(a.d[d].hprev), w.lo_of(a.d[d].hprev), a.d[d].ldh, wh, wh + n128 * Hp, Hp,
-                        w.gh + (size_t)d * B * H3, (long)H3, nullptr, B, H3};
-      }
-      b.n = a.ndir;
-      hipError_t e = launch_gemm_h3(b, s);
-      if (e != hipSuccess) return (int)e;
-    }
+    H3Batch b{};
     GateBatch gb{};
-    for (int d = 0; d < a.ndir; ++d)
-      gb.d[d] = GateDir{a.d[d].gi, a.d[d].ldgi, w.gh + (size_t)d * B * H3, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh,
-                        a.d[d].hout, w.hi_of(a.d[d].hout), w.lo_of(a.d[d].hout), a.d[d].ldo};
-    return (int)launch_gru_gates(gb, a.ndir, B, Hp, a.first, s);
+    for (int d = 0; d < a.ndir; ++d) {
+      const EncWs::View vo = w.view(a.d[d].hout);
+      if (!vo.hi) return (int)hipErrorInvalidValue;
+      const GateDir g{a.d[d].gi, a.d[d].ldgi, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh, a.d[d].hout, a.d[d].ldo,
+                      vo.hi, vo.lo, vo.kst};
+      b.gate[d] = g;
+      gb.d[d] = g;
+      if (!a.first) {
+        const half_t* wh = (const half_t*)(Bl + whh_planes[d]);
+        const EncWs::View vi = w.view(a.d[d].hprev);
+        if (!vi.hi) return (int)hipErrorInvalidValue;
+        b.p[d] = H3Args{vi.hi, vi.lo, 32, vi.kst, wh, wh + n128 * Hp, (long)n128 * 32, Hp, nullptr, 0, nullptr, B, H3};
+      }
+    }
+    if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s);
+    b.n = a.ndir; b.Hp = Hp;
+    return (int)launch_gru_h3(b, s);
   };
   auto gi0 = [&](int t, int dir, const float*& p, long& ld) {
     if (src.last && t == T - 1) { p = src.last + (long)dir * H3; ld = src.last_ld; return; }
@@ -798,7 +807,8 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
     }
     if (h3) {
       H3Batch b{};
-      b.p[0] = H3Args{xh, xl, (long)kInputP, w0h, w0l, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT, ld0};
+      b.p[0] = H3Args{xh, xl, 32, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0,
+                      (int)BT, ld0};
       b.n = 1;
       CK(launch_gemm_h3(b, s));
     } else {
@@ -814,9 +824,10 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
   if (L == 1) {  // rec.l0 forward direction: only flipped index 0 (= frame T-1) is consumed
     if (h3) {
       H3Batch b{};
-      b.p[0] = H3Args{xh + (long)(T - 1) * kInputP, xl + (long)(T - 1) * kInputP, (long)T * kInputP,
-                      w0h + (size_t)6 * Hp * kInputP, w0l + (size_t)6 * Hp * kInputP, kInputP, w.g0c, (long)H3,
-                      Bl + m->bih0 + 6 * Hp, B, H3};
+      // rows T-1, 2T-1, ... of the blocked input planes; W rows 6Hp.. of the stacked layer-0 block
+      b.p[0] = H3Args{xh + (long)(T - 1) * 32, xl + (long)(T - 1) * 32, (long)T * 32, BT * 32,
+                      w0h + (size_t)6 * Hp * 32, w0l + (size_t)6 * Hp * 32, (long)rows0 * 32, kInputP, w.g0c,
+                      (long)H3, Bl + m->bih0 + 6 * Hp, B, H3};
       b.n = 1;
       CK(launch_gemm_h3(b, s));
     } else {

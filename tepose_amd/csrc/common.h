@@ -72,7 +72,8 @@ enum ColMap { COL_PLAIN = 0, COL_SPLIT2 = 1 };
 struct PackArgs {
   const float* src; long ld_src; int N, K;   // logical source [N][K] (col offset folded into src)
   float* dst; int Np, Kp;                     // fp32 destination, or nullptr with dst_hi / dst_lo set
-  half_t* dst_hi; half_t* dst_lo;             // split-precision planes (gemm_h3.hip)
+  half_t* dst_hi; half_t* dst_lo;             // blocked split-precision planes (gemm_h3.hip): pointer to this
+  long dst_kst;                               // matrix's first row inside the plane, halfs between K-tiles
   int rowmap, colmap;
   int H, Hp;                                  // for the gate / split maps
 };
@@ -130,29 +131,44 @@ hipError_t launch_one_euro(float* x, int N, int D, float min_cutoff, float beta,
 hipError_t launch_slerp_smooth(const float* in, float* out, int N, int J, double ratio, hipStream_t s);
 
 // ---------------------------------------------------------------- gemm_h3.hip (split-precision fp16x3 GEMM)
+// Operand planes are stored K-tile-blocked: element (row, c) of an [R x C] matrix (C multiple of 32) lives at
+//   ((c / 32) * R + row) * 32 + c % 32        (halfs)
+// so the 64 bytes a K-tile takes from each of a block's rows are one contiguous run and every LDS-DMA
+// instruction moves whole 128-byte lines (row-major planes gave it 64-byte pieces of 16 different lines, which
+// cost 14 % of the layer-0 projection).  A view of rows [r0, r0+M) x columns [c0, c0+K), c0 % 32 == 0, is the
+// pointer to (r0, c0) plus the K-tile stride R * 32.
+constexpr int kPlaneK = 32;
+__host__ __device__ inline long plane_index(long row, long c, long R) { return ((c >> 5) * R + row) * 32 + (c & 31); }
 struct H3Args {
-  const half_t *Ah, *Al; long lda;    // [M][Kp] hi / lo planes (lda in halfs, multiple of 8)
-  const half_t *Wh, *Wl; int Kp;      // [Np][Kp] planes, Np multiple of 128, Kp multiple of 32
+  const half_t *Ah, *Al;              // A hi / lo planes, pointing at the view's first row and K-tile
+  long a_rst, a_kst;                  // halfs between consecutive rows of the view (32, or 32 * row step) / K-tiles
+  const half_t *Wh, *Wl; long w_kst;  // W planes (row stride 32): rows padded to the N-tile, zero beyond N
+  int Kp;                             // multiple of 32
   float* C; long ldc;
   const float* bias;                  // [N] or nullptr
   int M, N;
 };
 struct GateDir {
   const float* gi; long ldgi;         // x W_ih^T + b_ih, [row*ldgi + g*Hp + j]
-  const float* gh;                    // h W_hh^T, [row][3Hp] (gate kernel only; ignored when first)
   const float* bhh;                   // [3Hp]
-  const float* hprev; long ldh;       // fp32 previous state (ignored when first)
-  float* hout; half_t* hout_hi; half_t* hout_lo; long ldo;   // same row stride for the three outputs
+  const float* hprev; long ldh;       // fp32 previous state (unused by the first step)
+  float* hout; long ldo;              // fp32 new state
+  half_t *hout_hi, *hout_lo; long okst;   // its planes: view base, halfs between 32-column groups
 };
 struct H3Batch { H3Args p[3]; GateDir gate[3]; int n; int Hp; };
+// up to 3 independent products of the same M, N, Kp in one launch
 hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
 // recurrent product with the GRU cell update fused into the epilogue: W planes in the gate-interleaved tile
 // order (ROW_GATES_TILED), p[d].C unused, gate[d] describes the cell operands / outputs
 hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s);
-hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s);
+// first cell step of a direction (h = 0: no product), writing the same outputs
 struct GateBatch { GateDir d[3]; };
-hipError_t launch_gru_gates(const GateBatch& gb, int ndir, int M, int Hp, int first, hipStream_t s);
-hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, void* hi, void* lo, hipStream_t s);
+hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s);
+// x[rows][2133] fp32 -> blocked hi / lo planes of [rows x 2144]
+hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s);
+// src[rows][ld] fp32 (K valid columns) -> blocked planes of [R x Kp], rows < R
+hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, long R, void* hi, void* lo,
+                               hipStream_t s);
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);

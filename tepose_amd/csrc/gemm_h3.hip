@@ -19,7 +19,7 @@
 namespace tepose {
 
 #ifndef TEPOSE_H3_ABL
-#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds: 1 no DMA in the loop, 2 no barrier, 3 no fragment reads
+#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds: 1 no DMA in the loop, 2 no barrier, 3 no fragment reads, 4 = 1 + 3
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -30,29 +30,40 @@ __device__ __forceinline__ void glds16b(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// fp32 [rows][ld] -> hi / lo fp16 planes [rows][Kp] (columns >= K zero)
+// fp32 [rows][ld] -> blocked hi / lo fp16 planes of [R x Kp] (columns >= K zero).  A wave converts two rows of
+// one K-tile: it reads two 128-byte runs and writes one whole 128-byte line per plane; consecutive waves take
+// consecutive K-tiles of the same row pair, so a block's reads stay contiguous.
 __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ src, long ld, long rows, int K,
-                                                           int Kp, _Float16* __restrict__ hi,
+                                                           int Kp, long R, _Float16* __restrict__ hi,
                                                            _Float16* __restrict__ lo) {
-  const long total = rows * Kp;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long r = idx / Kp;
-    const int k = (int)(idx - r * Kp);
-    const float a = k < K ? src[r * ld + k] : 0.f;
-    split_hi_lo(a, hi[idx], lo[idx]);
+  const int KT = Kp / kPlaneK;
+  const long units = ((rows + 1) / 2) * KT;                 // (row pair, K-tile)
+  const int lane = threadIdx.x & 63;
+  for (long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += (long)gridDim.x * 4) {
+    const long pair = u / KT;
+    const int kt = (int)(u - pair * KT);
+    const long row = 2 * pair + (lane >> 5);
+    const int k = kt * kPlaneK + (lane & 31);
+    if (row >= rows) continue;
+    const float a = k < K ? src[row * ld + k] : 0.f;
+    const long o = ((long)kt * R + row) * 32 + (lane & 31);
+    split_hi_lo(a, hi[o], lo[o]);
   }
 }
 
-hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, void* hi, void* lo,
+hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, long R, void* hi, void* lo,
                                hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  const long total = rows * Kp;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, K, Kp, (_Float16*)hi,
+  const long units = ((rows + 1) / 2) * (Kp / kPlaneK);
+  const int blocks = (int)((units + 3) / 4 < 16384 ? (units + 3) / 4 : 16384);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
                      (_Float16*)lo);
   return hipGetLastError();
 }
 
+hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s) {
+  return launch_split_planes(x, kInput, rows, kInput, kInputP, rows, hi, lo, s);
+}
 
 __device__ __forceinline__ void h3_tile_of_block(int bid, int nwg, int tilesM, int tilesN, int& tm, int& tn) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
@@ -68,18 +79,19 @@ __device__ __forceinline__ void h3_tile_of_block(int bid, int nwg, int tilesM, i
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {          // s_waitcnt vmcnt(N) with a literal count
-  static_assert(N >= 0 && N <= 24, "vmcnt immediate");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else static_assert(N == 0, "add the literal");
+  static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `newer` whole stages (NDMA instructions each, per wave) are still in flight
+template <int NDMA, int MAXNEWER>
+__device__ __forceinline__ void wait_stages(int newer) {
+  static_assert(MAXNEWER * NDMA <= 63 && MAXNEWER <= 5, "ring depth");
+  if (MAXNEWER >= 5 && newer >= 5) wait_vm<(MAXNEWER >= 5 ? 5 : 0) * NDMA>();
+  else if (MAXNEWER >= 4 && newer == 4) wait_vm<(MAXNEWER >= 4 ? 4 : 0) * NDMA>();
+  else if (MAXNEWER >= 3 && newer == 3) wait_vm<(MAXNEWER >= 3 ? 3 : 0) * NDMA>();
+  else if (MAXNEWER >= 2 && newer == 2) wait_vm<(MAXNEWER >= 2 ? 2 : 0) * NDMA>();
+  else if (newer == 1) wait_vm<NDMA>();
+  else wait_vm<0>();
 }
 
 __device__ __forceinline__ float g_sigmoid(float x) {
@@ -90,11 +102,11 @@ __device__ __forceinline__ float g_tanh(float x) {
 }
 
 // WMF: 32-row MFMA fragments per wave along M (block rows = 128 * WMF); WNT: 32-column tiles per wave along
-// N (block columns = 64 * WNT); HK: K-tile (32 | 16); NST: stages in the LDS ring (NST - 1 K-tiles of DMA in
-// flight); GRU: the wave's 3 column tiles are the r, z, n gates of the same 32 hidden units and the epilogue is
+// N (block columns = 64 * WNT); NST: stages in the LDS ring (NST - 1 K-tiles of DMA in flight); GRU: the wave's 3 column tiles are the r, z, n gates of the same 32 hidden units and the epilogue is
 // the GRU cell update (fp32 state + hi/lo planes out) instead of a plain store.
-template <int WMF, int WNT, int HK, int NST, bool GRU>
+template <int WMF, int WNT, int NST, bool GRU>
 __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tilesM, int tilesN) {
+  constexpr int HK = kPlaneK;                         // K-tile = the planes' block width
   constexpr int HM = 128 * WMF;
   constexpr int HN = 64 * WNT;
   static_assert(!GRU || WNT == 3, "GRU epilogue needs the three gate tiles in one wave");
@@ -115,36 +127,39 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- DMA: stage image = [A_hi | A_lo | W_hi | W_lo], instruction i moves RPI consecutive rows of it ----
+  // ---- DMA: stage image = [A_hi | A_lo | W_hi | W_lo], instruction i moves RPI consecutive rows of it: 16 rows
+  // x 64 B, which the blocked planes hold as one contiguous KiB.  The XOR swizzle permutes the 16-byte slots
+  // inside a row on the global side, so the LDS image is lane-linear.
   const int lrow = lane / SL, lslot = lane % SL;
   const char* gsrc[NDMA];
+  long kst[NDMA];                                     // bytes between K-tiles of that source
 #pragma unroll
   for (int q = 0; q < NDMA; ++q) {
     const int i = wave * NDMA + q;
     int ri = i * RPI + lrow;                          // row index inside the stage image
     const char* base;
-    long ldb;
-    int row, grow;
+    long rowoff;
+    int row;
     if (ri < 2 * HM) {
       const bool lo = ri >= HM;
       row = lo ? ri - HM : ri;
-      grow = min(m0 + row, a.M - 1);
       base = (const char*)(lo ? a.Al : a.Ah);
-      ldb = a.lda * 2;
+      rowoff = (long)min(m0 + row, a.M - 1) * a.a_rst * 2;
+      kst[q] = a.a_kst * 2;
     } else {
       ri -= 2 * HM;
       const bool lo = ri >= HN;
       row = lo ? ri - HN : ri;
-      grow = n0 + row;
       base = (const char*)(lo ? a.Wl : a.Wh);
-      ldb = (long)a.Kp * 2;
+      rowoff = (long)(n0 + row) * RB;
+      kst[q] = a.w_kst * 2;
     }
-    gsrc[q] = base + (long)grow * ldb + 16 * (lslot ^ ((row / RPB) % SL));
+    gsrc[q] = base + rowoff + 16 * (lslot ^ ((row / RPB) % SL));
   }
   auto issue = [&](int kt, int buf) {
     char* st = lds + buf * STAGE;
 #pragma unroll
-    for (int q = 0; q < NDMA; ++q) glds16b(gsrc[q] + (long)kt * RB, st + (wave * NDMA + q) * 1024);
+    for (int q = 0; q < NDMA; ++q) glds16b(gsrc[q] + kt * kst[q], st + (wave * NDMA + q) * 1024);
   };
 
   // ---- fragment offsets (bytes inside a stage) ---------------------------------------------------------
@@ -183,32 +198,50 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   // outstanding), the raw barrier then makes the whole stage visible and also proves that every wave is
   // done reading stage kt-1, whose slot the next DMA overwrites.  __syncthreads() would drain vmcnt(0).
   const int KT = a.Kp / HK;
-#if TEPOSE_H3_ABL == 3
+#if TEPOSE_H3_ABL >= 3
   Frags f[KS];
 #endif
 #pragma unroll
   for (int p = 0; p < NST - 1; ++p)
     if (p < KT) issue(p, p);
+  // GRU: the cell operands of this wave's 32 rows x 32 hidden units (gate pre-activations, previous state,
+  // b_hh) are fetched two K-tiles before the end of the loop, so that their HBM latency hides under MFMAs
+  // instead of standing between the last product and the cell update.
+  float pf_gr[16], pf_gz[16], pf_gn[16], pf_hp[16], pf_b[3];
+  const int gj = tn * 64 + wn * 32 + r;       // GRU: hidden unit of this lane's columns (ROW_GATES_TILED order)
+  const int pf_kt = KT >= 2 ? KT - 2 : 0;
   for (int kt = 0; kt < KT; ++kt) {
     const int newer = min(NST - 2, KT - 1 - kt);     // stages issued after kt that may still be in flight
-    if (newer >= 2) wait_vm<(NST >= 4 ? 2 : 0) * NDMA>();
-    else if (newer == 1) wait_vm<NDMA>();
-    else wait_vm<0>();
+    wait_stages<NDMA, NST - 2>(newer);
 #if TEPOSE_H3_ABL != 2
     __builtin_amdgcn_s_barrier();
 #endif
     const char* st = lds + (kt % NST) * STAGE;
+    if constexpr (GRU) {
+      if (kt == pf_kt) {
+        const GateDir& d = batch.gate[blockIdx.y];
+        const int Hp = batch.Hp;
+        pf_b[0] = d.bhh[gj]; pf_b[1] = d.bhh[Hp + gj]; pf_b[2] = d.bhh[2 * Hp + gj];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = min(m0 + wm * 32 + 4 * h + (e & 3) + 8 * (e >> 2), a.M - 1);
+          const float* gi = d.gi + (long)row * d.ldgi + gj;
+          pf_gr[e] = gi[0]; pf_gz[e] = gi[Hp]; pf_gn[e] = gi[2 * Hp];
+          pf_hp[e] = d.hprev[(long)row * d.ldh + gj];
+        }
+      }
+    }
     // Fragments first, then the MFMAs with the next stage's DMA instructions spread between them: all 8
     // waves leave the barrier together, so DMA issued up front would keep every matrix pipe idle meanwhile.
     const bool more = kt + NST - 1 < KT;
     char* dst = lds + ((kt + NST - 1) % NST) * STAGE;
-    const long koff = (long)(kt + NST - 1) * RB;
-#if TEPOSE_H3_ABL != 3
+    const long koff = kt + NST - 1;
+#if TEPOSE_H3_ABL < 3
     Frags f[KS];
 #endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-#if TEPOSE_H3_ABL == 3
+#if TEPOSE_H3_ABL >= 3
       if (kt == 0)
 #endif
       load_frags(st, ks, f[ks]);
@@ -224,8 +257,8 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
           accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bl[j], accx[i][j], 0, 0, 0);
           accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].al[i], f[ks].bh[j], accx[i][j], 0, 0, 0);
           if (q < NDMA) {
-#if TEPOSE_H3_ABL != 1
-            if (more) glds16b(gsrc[q] + koff, dst + (wave * NDMA + q) * 1024);
+#if TEPOSE_H3_ABL != 1 && TEPOSE_H3_ABL != 4
+            if (more) glds16b(gsrc[q] + koff * kst[q], dst + (wave * NDMA + q) * 1024);
 #endif
             ++q;
           }
@@ -235,37 +268,23 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   wait_vm<0>();
 
   if constexpr (GRU) {
-    // columns of this wave: gates r, z, n of hidden units j = tn*64 + wn*32 + r (ROW_GATES_TILED order)
+    static_assert(!GRU || WMF == 1, "GRU epilogue prefetch holds one 32-row fragment of cell operands");
     const GateDir& d = batch.gate[blockIdx.y];
-    const int Hp = batch.Hp;
-    const int j = tn * 64 + wn * 32 + r;
-    const float br = d.bhh[j], bz = d.bhh[Hp + j], bn = d.bhh[2 * Hp + j];
+    const int rbase = m0 + wm * 32 + 4 * h;
 #pragma unroll
-    for (int i = 0; i < WMF; ++i) {
-      const int rbase = m0 + wm * 32 * WMF + i * 32 + 4 * h;
-      float gr[16], gz[16], gn[16], hp[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = min(rbase + (e & 3) + 8 * (e >> 2), a.M - 1);
-        const float* gi = d.gi + (long)row * d.ldgi + j;
-        gr[e] = gi[0]; gz[e] = gi[Hp]; gn[e] = gi[2 * Hp];
-        hp[e] = d.hprev[(long)row * d.ldh + j];
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rbase + (e & 3) + 8 * (e >> 2);
-        const float hr = acc[i][0][e] + accx[i][0][e] * (1.f / kLoScale);
-        const float hz = acc[i][1][e] + accx[i][1][e] * (1.f / kLoScale);
-        const float hn = acc[i][2][e] + accx[i][2][e] * (1.f / kLoScale);
-        const float rg = g_sigmoid(gr[e] + (hr + br));
-        const float zg = g_sigmoid(gz[e] + (hz + bz));
-        const float ng = g_tanh(gn[e] + rg * (hn + bn));
-        const float hv = (1.f - zg) * ng + zg * hp[e];
-        if (row < a.M) {
-          const long o = (long)row * d.ldo + j;
-          d.hout[o] = hv;
-          split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
-        }
+    for (int e = 0; e < 16; ++e) {
+      const int row = rbase + (e & 3) + 8 * (e >> 2);
+      const float hr = acc[0][0][e] + accx[0][0][e] * (1.f / kLoScale);
+      const float hz = acc[0][1][e] + accx[0][1][e] * (1.f / kLoScale);
+      const float hn = acc[0][2][e] + accx[0][2][e] * (1.f / kLoScale);
+      const float rg = g_sigmoid(pf_gr[e] + (hr + pf_b[0]));
+      const float zg = g_sigmoid(pf_gz[e] + (hz + pf_b[1]));
+      const float ng = g_tanh(pf_gn[e] + rg * (hn + pf_b[2]));
+      const float hv = (1.f - zg) * ng + zg * pf_hp[e];
+      if (row < a.M) {
+        d.hout[(long)row * d.ldo + gj] = hv;
+        const long o = (long)(gj >> 5) * d.okst + (long)row * 32 + r;
+        split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
       }
     }
   } else {
@@ -289,7 +308,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
 // test / bench entry: fp32 A[M,K], W[N,K] -> planes in `ws` -> C (K multiple of 32)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s) {
-  const int Np = round_up(N, 256);     // the widest tile variant reads 256-row W panels
+  const int Np = round_up(N, 128);
   char* p = (char*)ws;
   _Float16* Ah = (_Float16*)p; p += align_up((size_t)M * K * 2, 256);
   _Float16* Al = (_Float16*)p; p += align_up((size_t)M * K * 2, 256);
@@ -297,95 +316,60 @@ hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw
   _Float16* Wl = (_Float16*)p;
   hipError_t e = hipMemsetAsync(Wh, 0, 2 * align_up((size_t)Np * K * 2, 256), s);
   if (e != hipSuccess) return e;
-  if ((e = launch_split_planes(A, lda, M, K, K, Ah, Al, s)) != hipSuccess) return e;
-  if ((e = launch_split_planes(W, ldw, N, K, K, Wh, Wl, s)) != hipSuccess) return e;
+  if ((e = launch_split_planes(A, lda, M, K, K, M, Ah, Al, s)) != hipSuccess) return e;
+  if ((e = launch_split_planes(W, ldw, N, K, K, Np, Wh, Wl, s)) != hipSuccess) return e;
   H3Batch b{};
-  b.p[0] = H3Args{Ah, Al, (long)K, Wh, Wl, K, C, ldc, bias, M, N};
+  b.p[0] = H3Args{(const half_t*)Ah, (const half_t*)Al, 32, (long)M * 32, (const half_t*)Wh, (const half_t*)Wl,
+                  (long)Np * 32, K, C, ldc, bias, M, N};
   b.n = 1;
   return launch_gemm_h3(b, s);
 }
 
-// up to 3 independent products of the same M, N, Kp in one launch (the directions of a GRU step)
+// 256 x 128 block tile, 3-stage ring of 48 KB stages
 hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
-  static const int variant = [] {
-    const char* e = getenv("TEPOSE_H3_VARIANT");
-    return e ? atoi(e) : 0;
-  }();
-  const int tilesM = (b.p[0].M + 255) / 256;
-  if (variant == 2) {            // 256 x 128 tile, K-tile 16, 4-stage ring
-    const int tilesN = (b.p[0].N + 127) / 128;
-    hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 16, 4, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM,
-                       tilesN);
-  } else {                       // 256 x 128 tile, K-tile 32, 3-stage ring
-    const int tilesN = (b.p[0].N + 127) / 128;
-    hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 32, 3, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM,
-                       tilesN);
-  }
+  const int tilesM = (b.p[0].M + 255) / 256, tilesN = (b.p[0].N + 127) / 128;
+  hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 3, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM,
+                     tilesN);
   return hipGetLastError();
 }
 
 hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   const int tilesM = (b.p[0].M + 127) / 128, tilesJ = b.Hp / 64;   // block = 128 rows x (64 hidden units x 3 gates)
-  hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 32, 3, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM,
+  hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 3, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM,
                      tilesJ);
   return hipGetLastError();
 }
 
-// x[rows][2133] fp32 -> hi / lo planes [rows][2144] (pad columns zero): the split kernel's A operand
-__global__ void __launch_bounds__(256) pad_input_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
-                                                               _Float16* __restrict__ lo, long rows) {
-  const long total = rows * kInputP;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long row = idx / kInputP;
-    const int k = (int)(idx - row * kInputP);
-    const float a = k < kInput ? x[row * kInput + k] : 0.f;
-    split_hi_lo(a, hi[idx], lo[idx]);
-  }
-}
-
-hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s) {
-  if (rows <= 0) return hipSuccess;
-  const long total = rows * kInputP;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(pad_input_planes_kernel, dim3(blocks), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, rows);
-  return hipGetLastError();
-}
-
-// GRU gate update after the recurrent product gh = h W_hh^T (natural gate order [r | z | n], no bias):
-// thread = (row, hidden unit); writes the new state as fp32 and as hi / lo planes for the next product.
-__global__ void __launch_bounds__(256) gru_gates_kernel(GateBatch gb, int M, int Hp, int first) {
+// First cell step of a direction: h_prev = 0, so h W_hh^T vanishes and the step is element-wise.  Writes the
+// new state as fp32 and as blocked hi / lo planes for the next step's product.
+__global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int Hp) {
   const GateDir& d = gb.d[blockIdx.y];
   const long total = (long)M * Hp;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long row = idx / Hp;
     const int j = (int)(idx - row * Hp);
     const float* gi = d.gi + row * d.ldgi + j;
-    float hr = d.bhh[j], hz = d.bhh[Hp + j], hn = d.bhh[2 * Hp + j], hp = 0.f;
-    if (!first) {
-      const float* gh = d.gh + row * 3 * Hp + j;
-      hr += gh[0]; hz += gh[Hp]; hn += gh[2 * Hp];
-      hp = d.hprev[row * d.ldh + j];
-    }
-    const float rg = g_sigmoid(gi[0] + hr), zg = g_sigmoid(gi[Hp] + hz);
-    const float ng = g_tanh(gi[2 * Hp] + rg * hn);
-    const float hv = (1.f - zg) * ng + zg * hp;
+    const float rg = g_sigmoid(gi[0] + d.bhh[j]), zg = g_sigmoid(gi[Hp] + d.bhh[Hp + j]);
+    const float ng = g_tanh(gi[2 * Hp] + rg * d.bhh[2 * Hp + j]);
+    const float hv = (1.f - zg) * ng;
     d.hout[row * d.ldo + j] = hv;
-    split_hi_lo(hv, d.hout_hi[row * d.ldo + j], d.hout_lo[row * d.ldo + j]);
+    const long o = (long)(j >> 5) * d.okst + row * 32 + (j & 31);
+    split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
   }
 }
 
-hipError_t launch_gru_gates(const GateBatch& gb, int ndir, int M, int Hp, int first, hipStream_t s) {
+hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s) {
   if (M <= 0 || ndir <= 0) return hipSuccess;
   const long total = (long)M * Hp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(gru_gates_kernel, dim3(blocks, ndir), dim3(256), 0, s, gb, M, Hp, first);
+  hipLaunchKernelGGL(gru_first_kernel, dim3(blocks, ndir), dim3(256), 0, s, gb, M, Hp);
   return hipGetLastError();
 }
 
 size_t gemm_h3_ws_bytes(int M, int N, int K) {
-  return 2 * align_up((size_t)M * K * 2, 256) + 2 * align_up((size_t)round_up(N, 256) * K * 2, 256) + 256;
+  return 2 * align_up((size_t)M * K * 2, 256) + 2 * align_up((size_t)round_up(N, 128) * K * 2, 256) + 256;
 }
 
 }  // namespace tepose

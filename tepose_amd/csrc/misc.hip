@@ -38,8 +38,9 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
     const float v = (n >= 0 && k >= 0) ? a.src[(long)n * a.ld_src + k] : 0.f;
     if (a.dst) {
       a.dst[idx] = v;
-    } else {                              // hi / lo fp16 planes for the split-precision GEMM
-      split_hi_lo(v, a.dst_hi[idx], a.dst_lo[idx]);
+    } else {                              // blocked hi / lo fp16 planes for the split-precision GEMM
+      const long o = (long)(kp >> 5) * a.dst_kst + (long)np * 32 + (kp & 31);
+      split_hi_lo(v, a.dst_hi[o], a.dst_lo[o]);
     }
   }
 }

@@ -12,4 +12,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_fetch -- python3 bench.py $common > gpurun_out/${tag}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_write -- python3 bench.py $common > gpurun_out/${tag}_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/${tag}_sq -- python3 bench.py $common > gpurun_out/${tag}_sq.log 2>&1
-for d in trace fetch write sq; do ls gpurun_out/${tag}_$d/*/ | head -3; done
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/${tag}_lds -- python3 bench.py $common > gpurun_out/${tag}_lds.log 2>&1 || true
+for d in trace fetch write sq lds; do ls gpurun_out/${tag}_$d/*/ | head -3; done
