@@ -182,20 +182,30 @@ struct Carver {
 // Buffers of one encoder forward (shared between sizing and execution).
 struct EncWs {
   float *xp, *g0, *g0c, *gf, *grr, *grf, *sf[2], *sr[2], *pf[2], *pr[2], *ytop, *y1;
-  // split-precision path: every state buffer between state_base and ytop's end has fp16 hi / lo mirrors that
-  // start at the same element offset and hold the buffer's [R x C] matrix K-tile-blocked (common.h)
-  float* state_base; size_t state_floats; half_t *state_hi, *state_lo;
-  struct Buf { const float* base; size_t R, C; };
+  // split-precision path: every state buffer [T][B][C] has fp16 hi / lo mirror planes holding the
+  // [T * Bs x C] matrix in the K-tile-blocked layout of common.h (slabs of Bs = B rounded up to 16 rows, in the
+  // fp32 buffers too, so that every time slab starts on a swizzle period; the pad rows are never consumed); x0h / x0l: compact planes of the frames a 1-layer model's rec.l0
+  // forward direction consumes
+  half_t *state_hi, *state_lo, *x0h, *x0l;
+  size_t Bs = 0;       // rows per time slab of gf/grr/grf/sf/sr: B, or B rounded up to 16 on the split path
+  struct Buf { const float* base; size_t T, B, C, poff; };   // poff: first half of its mirror inside state_hi/lo
   Buf bufs[9]; int nbufs = 0;
+  size_t plane_halfs = 0;
+  void add(const float* base, size_t T, size_t B, size_t C) {     // B = slab rows (multiple of 16 when split)
+    bufs[nbufs++] = Buf{base, T, B, C, plane_halfs};
+    plane_halfs += T * B * C;
+  }
   struct View { half_t *hi, *lo; long kst; };
-  // planes of the sub-matrix that starts at fp32 element p (row stride = the owning buffer's C)
+  // planes of the sub-matrix that starts at fp32 element p = (slab t, row 0, column c0)
   View view(const float* p) const {
     for (int i = 0; i < nbufs; ++i) {
       const Buf& b = bufs[i];
-      if (p >= b.base && p < b.base + b.R * b.C) {
-        const size_t off = (size_t)(p - b.base), row = off / b.C, col = off % b.C;
-        const size_t e = (size_t)(b.base - state_base) + (size_t)plane_index((long)row, (long)col, (long)b.R);
-        return View{state_hi + e, state_lo + e, (long)b.R * 32};
+      if (p >= b.base && p < b.base + b.T * b.B * b.C) {
+        const size_t off = (size_t)(p - b.base), t = off / (b.B * b.C), rem = off % (b.B * b.C);
+        if (rem / b.C != 0 || (rem % b.C) % 32 != 0) break;
+        const size_t R = b.T * b.B;
+        const size_t e = b.poff + (size_t)plane_index((long)(t * b.B), (long)(rem % b.C), (long)R);
+        return View{state_hi + e, state_lo + e, (long)R * 32};
       }
     }
     return View{nullptr, nullptr, 0};
@@ -205,34 +215,35 @@ struct EncWs {
 void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   const size_t Hp = m->Hp, BT = (size_t)B * T;
   const int L = m->L;
+  const bool h3 = m->split && B > skinny_max_m();
+  const size_t Bs = h3 ? (size_t)round_up(B, 16) : (size_t)B, BTs = Bs * T;
+  w.Bs = Bs;
   w.xp = c.f(BT * kInputP);
   w.g0 = c.f(BT * (L >= 2 ? 9 : 6) * Hp);
   w.g0c = c.f(L >= 2 ? 0 : (size_t)B * 3 * Hp);
-  w.gf = c.f(L >= 2 ? BT * 3 * Hp : 0);
-  w.grr = c.f(L >= 2 ? BT * 3 * Hp : 0);
-  w.grf = c.f(L >= 3 ? BT * 3 * Hp : (L == 2 ? (size_t)B * 3 * Hp : 0));
-  const size_t state_begin = c.cur;
-  w.state_base = c.f(0);
+  w.gf = c.f(L >= 2 ? BTs * 3 * Hp : 0);
+  w.grr = c.f(L >= 2 ? BTs * 3 * Hp : 0);
+  w.grf = c.f(L >= 3 ? BTs * 3 * Hp : (L == 2 ? (size_t)B * 3 * Hp : 0));
   for (int i = 0; i < 2; ++i) {
     const bool need = (i == 0 && L >= 2) || (i == 1 && L >= 3);
-    w.sf[i] = c.f(need ? BT * Hp : 0);
-    w.sr[i] = c.f(need ? BT * 2 * Hp : 0);
-    w.pf[i] = c.f((size_t)B * Hp);
-    w.pr[i] = c.f((size_t)B * Hp);
+    w.sf[i] = c.f(need ? BTs * Hp : 0);
+    w.sr[i] = c.f(need ? BTs * 2 * Hp : 0);
+    w.pf[i] = c.f(Bs * Hp);
+    w.pr[i] = c.f(Bs * Hp);
     if (need) {
-      w.bufs[w.nbufs++] = EncWs::Buf{w.sf[i], BT, Hp};
-      w.bufs[w.nbufs++] = EncWs::Buf{w.sr[i], BT, 2 * Hp};
+      w.add(w.sf[i], T, Bs, Hp);
+      w.add(w.sr[i], T, Bs, 2 * Hp);
     }
-    w.bufs[w.nbufs++] = EncWs::Buf{w.pf[i], (size_t)B, Hp};
-    w.bufs[w.nbufs++] = EncWs::Buf{w.pr[i], (size_t)B, Hp};
+    w.add(w.pf[i], 1, Bs, Hp);
+    w.add(w.pr[i], 1, Bs, Hp);
   }
-  w.ytop = c.f((size_t)B * 2 * Hp);
-  w.bufs[w.nbufs++] = EncWs::Buf{w.ytop, (size_t)B, 2 * Hp};
-  w.state_floats = (c.cur - state_begin) / sizeof(float);
+  w.ytop = c.f(Bs * 2 * Hp);
+  w.add(w.ytop, 1, Bs, 2 * Hp);
   w.y1 = c.f((size_t)B * kFeat);
-  const bool h3 = m->split && B > skinny_max_m();
-  w.state_hi = (half_t*)c.f(h3 ? w.state_floats / 2 + 64 : 0);
-  w.state_lo = (half_t*)c.f(h3 ? w.state_floats / 2 + 64 : 0);
+  w.state_hi = (half_t*)c.f(h3 ? w.plane_halfs / 2 + 64 : 0);
+  w.state_lo = (half_t*)c.f(h3 ? w.plane_halfs / 2 + 64 : 0);
+  w.x0h = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
+  w.x0l = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
 }
 
 struct RegWs {
@@ -598,6 +609,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const long BT = (long)B * T;
   const int H3 = 3 * Hp;
   const bool h3 = m->split && B > skinny_max_m();
+  const long Bs = (long)w.Bs;          // rows per time slab of the layer >= 1 buffers
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t bias, float* out, int M) -> int {
@@ -609,7 +621,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     const half_t* wh = (const half_t*)(Bl + w_planes);
     const EncWs::View v = w.view(in);
     if (!v.hi) return (int)hipErrorInvalidValue;
-    b.p[0] = H3Args{v.hi, v.lo, 32, v.kst, wh, wh + n128 * K, (long)n128 * 32, K, out, (long)H3, Bl + bias, M, H3};
+    b.p[0] = H3Args{v.hi, v.lo, v.kst, wh, wh + n128 * K, (long)n128 * 32, K, out, (long)H3, Bl + bias, M, H3};
     b.n = 1;
     return (int)launch_gemm_h3(b, s);
   };
@@ -630,7 +642,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         const half_t* wh = (const half_t*)(Bl + whh_planes[d]);
         const EncWs::View vi = w.view(a.d[d].hprev);
         if (!vi.hi) return (int)hipErrorInvalidValue;
-        b.p[d] = H3Args{vi.hi, vi.lo, 32, vi.kst, wh, wh + n128 * Hp, (long)n128 * 32, Hp, nullptr, 0, nullptr, B, H3};
+        b.p[d] = H3Args{vi.hi, vi.lo, vi.kst, wh, wh + n128 * Hp, (long)n128 * 32, Hp, nullptr, 0, nullptr, B, H3};
       }
     }
     if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s);
@@ -654,14 +666,15 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     } else {
       const float* inf = w.sf[(l - 1) & 1];
       const float* inr = w.sr[(l - 1) & 1];
-      CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, (int)BT));
-      CK((hipError_t)proj(inr, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].bih, w.grr, (int)BT));
-      CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].bih, w.grf, top ? B : (int)BT));
+      const int MT = (int)(Bs * T);       // every slab row, pad rows included (their results are never read)
+      CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, MT));
+      CK((hipError_t)proj(inr, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].bih, w.grr, MT));
+      CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].bih, w.grf, top ? B : MT));
       gf = w.gf; grr = w.grr; grf = w.grf;
       ldg = H3;
     }
     // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
-    auto goff = [&](int q) -> long { return (long)q * B * H3; };
+    auto goff = [&](int q) -> long { return (long)q * Bs * H3; };
 
     if (m->prof) { int rc = prof_mark(mm, s); if (rc) return rc; }
     for (int st = 0; st < T; ++st) {
@@ -674,8 +687,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         if (l == 0) gi0(st, 0, d.gi, d.ldgi);
         else { d.gi = gf + goff(st); d.ldgi = ldg; }
         if (!top) {
-          d.hprev = sf + (long)(st - 1) * B * Hp; d.ldh = Hp;
-          d.hout = sf + (long)st * B * Hp; d.ldo = Hp;
+          d.hprev = sf + (long)(st - 1) * Bs * Hp; d.ldh = Hp;
+          d.hout = sf + (long)st * Bs * Hp; d.ldo = Hp;
         } else {
           d.hprev = w.pf[(st + 1) & 1]; d.ldh = Hp;
           d.hout = w.pf[st & 1]; d.ldo = Hp;
@@ -688,8 +701,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         if (l == 0) gi0(st, 1, d.gi, d.ldgi);
         else { d.gi = grr + goff(i); d.ldgi = ldg; }
         if (!top) {
-          d.hprev = sr + (long)(i + 1) * B * 2 * Hp + Hp; d.ldh = 2 * Hp;
-          d.hout = sr + (long)i * B * 2 * Hp + Hp; d.ldo = 2 * Hp;
+          d.hprev = sr + (long)(i + 1) * Bs * 2 * Hp + Hp; d.ldh = 2 * Hp;
+          d.hout = sr + (long)i * Bs * 2 * Hp + Hp; d.ldo = 2 * Hp;
         } else {
           d.hprev = w.pr[(st + 1) & 1]; d.ldh = Hp;
           if (st == T - 1) { d.hout = w.ytop + Hp; d.ldo = 2 * Hp; }
@@ -701,8 +714,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
         if (l == 0) gi0(T - 1 - st, 2, d.gi, d.ldgi);
         else { d.gi = grf + goff(st); d.ldgi = ldg; }
-        d.hprev = sr + (long)(st - 1) * B * 2 * Hp; d.ldh = 2 * Hp;
-        d.hout = sr + (long)st * B * 2 * Hp; d.ldo = 2 * Hp;
+        d.hprev = sr + (long)(st - 1) * Bs * 2 * Hp; d.ldh = 2 * Hp;
+        d.hout = sr + (long)st * Bs * 2 * Hp; d.ldo = 2 * Hp;
       }
       a.ndir = nd;
       const size_t wp[3] = {m->fwd[l].whh_p, m->rec_r[l].whh_p, m->rec_f[l].whh_p};
@@ -807,8 +820,8 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
     }
     if (h3) {
       H3Batch b{};
-      b.p[0] = H3Args{xh, xl, 32, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0,
-                      (int)BT, ld0};
+      b.p[0] = H3Args{xh, xl, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT,
+                      ld0};
       b.n = 1;
       CK(launch_gemm_h3(b, s));
     } else {
@@ -824,10 +837,10 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
   if (L == 1) {  // rec.l0 forward direction: only flipped index 0 (= frame T-1) is consumed
     if (h3) {
       H3Batch b{};
-      // rows T-1, 2T-1, ... of the blocked input planes; W rows 6Hp.. of the stacked layer-0 block
-      b.p[0] = H3Args{xh + (long)(T - 1) * 32, xl + (long)(T - 1) * 32, (long)T * 32, BT * 32,
-                      w0h + (size_t)6 * Hp * 32, w0l + (size_t)6 * Hp * 32, (long)rows0 * 32, kInputP, w.g0c,
-                      (long)H3, Bl + m->bih0 + 6 * Hp, B, H3};
+      // frames T-1 of every window as compact planes; W rows 6Hp.. of the stacked layer-0 block
+      CK(launch_split_planes(x + (long)(T - 1) * kInput, (long)T * kInput, B, kInput, kInputP, B, w.x0h, w.x0l, s));
+      b.p[0] = H3Args{w.x0h, w.x0l, (long)B * 32, w0h + (size_t)6 * Hp * 32, w0l + (size_t)6 * Hp * 32,
+                      (long)rows0 * 32, kInputP, w.g0c, (long)H3, Bl + m->bih0 + 6 * Hp, B, H3};
       b.n = 1;
       CK(launch_gemm_h3(b, s));
     } else {

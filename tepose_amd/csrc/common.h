@@ -131,18 +131,25 @@ hipError_t launch_one_euro(float* x, int N, int D, float min_cutoff, float beta,
 hipError_t launch_slerp_smooth(const float* in, float* out, int N, int J, double ratio, hipStream_t s);
 
 // ---------------------------------------------------------------- gemm_h3.hip (split-precision fp16x3 GEMM)
-// Operand planes are stored K-tile-blocked: element (row, c) of an [R x C] matrix (C multiple of 32) lives at
-//   ((c / 32) * R + row) * 32 + c % 32        (halfs)
-// so the 64 bytes a K-tile takes from each of a block's rows are one contiguous run and every LDS-DMA
-// instruction moves whole 128-byte lines (row-major planes gave it 64-byte pieces of 16 different lines, which
-// cost 14 % of the layer-0 projection).  A view of rows [r0, r0+M) x columns [c0, c0+K), c0 % 32 == 0, is the
-// pointer to (r0, c0) plus the K-tile stride R * 32.
+// Operand planes are stored K-tile-blocked and slot-swizzled: element (row, c) of an [R x C] matrix (C multiple
+// of 32) lives at
+//   ((c / 32) * R + row) * 32 + (((c / 8) % 4) ^ ((row / 4) % 4)) * 8 + c % 8        (halfs)
+// * blocked: the 64 bytes a K-tile takes from each of a block's rows form one contiguous run, so an LDS-DMA
+//   instruction (16 rows) moves one contiguous KiB = 8 whole 128-byte lines;
+// * swizzled in memory: the XOR that makes the LDS image bank-conflict-free for ds_read_b128 is already in
+//   the data, so the DMA's global addresses simply ascend with the lane number.
+// Measured against row-major planes with the XOR applied in the lane addresses, this layout is worth 0-3 % on
+// the layer-0 projection (within box-to-box noise; profiles/r01_README.md) -- it is kept because it makes the
+// DMA addressing trivial, not because it is faster.
+// A view of rows [r0, r0+M) x columns [c0, c0+K), r0 % 16 == 0 and c0 % 32 == 0, is the pointer to block
+// (r0, c0) plus the K-tile stride R * 32.
 constexpr int kPlaneK = 32;
-__host__ __device__ inline long plane_index(long row, long c, long R) { return ((c >> 5) * R + row) * 32 + (c & 31); }
+__host__ __device__ inline long plane_index(long row, long c, long R) {
+  return ((c >> 5) * R + row) * 32 + ((((c >> 3) & 3) ^ ((row >> 2) & 3)) << 3) + (c & 7);
+}
 struct H3Args {
-  const half_t *Ah, *Al;              // A hi / lo planes, pointing at the view's first row and K-tile
-  long a_rst, a_kst;                  // halfs between consecutive rows of the view (32, or 32 * row step) / K-tiles
-  const half_t *Wh, *Wl; long w_kst;  // W planes (row stride 32): rows padded to the N-tile, zero beyond N
+  const half_t *Ah, *Al; long a_kst;  // A hi / lo planes: pointer to the view's first block, halfs between K-tiles
+  const half_t *Wh, *Wl; long w_kst;  // W planes: rows padded to the N-tile, zero beyond N
   int Kp;                             // multiple of 32
   float* C; long ldc;
   const float* bias;                  // [N] or nullptr
@@ -153,7 +160,7 @@ struct GateDir {
   const float* bhh;                   // [3Hp]
   const float* hprev; long ldh;       // fp32 previous state (unused by the first step)
   float* hout; long ldo;              // fp32 new state
-  half_t *hout_hi, *hout_lo; long okst;   // its planes: view base, halfs between 32-column groups
+  half_t *hout_hi, *hout_lo; long okst;   // its planes: view base (row % 16 == 0), halfs between 32-column groups
 };
 struct H3Batch { H3Args p[3]; GateDir gate[3]; int n; int Hp; };
 // up to 3 independent products of the same M, N, Kp in one launch

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
     const int k = kt * kPlaneK + (lane & 31);
     if (row >= rows) continue;
     const float a = k < K ? src[row * ld + k] : 0.f;
-    const long o = ((long)kt * R + row) * 32 + (lane & 31);
+    const long o = plane_index(row, k, R);
     split_hi_lo(a, hi[o], lo[o]);
   }
 }
@@ -127,34 +127,30 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- DMA: stage image = [A_hi | A_lo | W_hi | W_lo], instruction i moves RPI consecutive rows of it: 16 rows
-  // x 64 B, which the blocked planes hold as one contiguous KiB.  The XOR swizzle permutes the 16-byte slots
-  // inside a row on the global side, so the LDS image is lane-linear.
-  const int lrow = lane / SL, lslot = lane % SL;
+  // ---- DMA: stage image = [A_hi | A_lo | W_hi | W_lo], instruction i moves RPI = 16 consecutive rows of it: one
+  // contiguous KiB of a blocked plane, lane l taking bytes [16 l, 16 l + 16).  The slot swizzle the fragment
+  // reads rely on is in the stored data (plane_index), not in these addresses.
   const char* gsrc[NDMA];
   long kst[NDMA];                                     // bytes between K-tiles of that source
 #pragma unroll
   for (int q = 0; q < NDMA; ++q) {
     const int i = wave * NDMA + q;
-    int ri = i * RPI + lrow;                          // row index inside the stage image
+    int ri = i * RPI + lane / SL;                     // row index inside the stage image
     const char* base;
-    long rowoff;
-    int row;
+    long grow;
     if (ri < 2 * HM) {
       const bool lo = ri >= HM;
-      row = lo ? ri - HM : ri;
       base = (const char*)(lo ? a.Al : a.Ah);
-      rowoff = (long)min(m0 + row, a.M - 1) * a.a_rst * 2;
+      grow = min(m0 + (lo ? ri - HM : ri), a.M - 1);  // rows past M repeat the last row; never stored
       kst[q] = a.a_kst * 2;
     } else {
       ri -= 2 * HM;
       const bool lo = ri >= HN;
-      row = lo ? ri - HN : ri;
       base = (const char*)(lo ? a.Wl : a.Wh);
-      rowoff = (long)(n0 + row) * RB;
+      grow = n0 + (lo ? ri - HN : ri);
       kst[q] = a.w_kst * 2;
     }
-    gsrc[q] = base + rowoff + 16 * (lslot ^ ((row / RPB) % SL));
+    gsrc[q] = base + grow * RB + 16 * (lane % SL);
   }
   auto issue = [&](int kt, int buf) {
     char* st = lds + buf * STAGE;
@@ -283,7 +279,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
       const float hv = (1.f - zg) * ng + zg * pf_hp[e];
       if (row < a.M) {
         d.hout[(long)row * d.ldo + gj] = hv;
-        const long o = (long)(gj >> 5) * d.okst + (long)row * 32 + r;
+        const long o = (long)(gj >> 5) * d.okst + plane_index(row, r, 0);
         split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
       }
     }
@@ -309,18 +305,19 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s) {
   const int Np = round_up(N, 128);
+  const long Ra = M, Rw = Np;
   char* p = (char*)ws;
-  _Float16* Ah = (_Float16*)p; p += align_up((size_t)M * K * 2, 256);
-  _Float16* Al = (_Float16*)p; p += align_up((size_t)M * K * 2, 256);
-  _Float16* Wh = (_Float16*)p; p += align_up((size_t)Np * K * 2, 256);
+  _Float16* Ah = (_Float16*)p; p += align_up((size_t)Ra * K * 2, 256);
+  _Float16* Al = (_Float16*)p; p += align_up((size_t)Ra * K * 2, 256);
+  _Float16* Wh = (_Float16*)p; p += align_up((size_t)Rw * K * 2, 256);
   _Float16* Wl = (_Float16*)p;
-  hipError_t e = hipMemsetAsync(Wh, 0, 2 * align_up((size_t)Np * K * 2, 256), s);
+  hipError_t e = hipMemsetAsync(Wh, 0, 2 * align_up((size_t)Rw * K * 2, 256), s);
   if (e != hipSuccess) return e;
-  if ((e = launch_split_planes(A, lda, M, K, K, M, Ah, Al, s)) != hipSuccess) return e;
-  if ((e = launch_split_planes(W, ldw, N, K, K, Np, Wh, Wl, s)) != hipSuccess) return e;
+  if ((e = launch_split_planes(A, lda, M, K, K, Ra, Ah, Al, s)) != hipSuccess) return e;
+  if ((e = launch_split_planes(W, ldw, N, K, K, Rw, Wh, Wl, s)) != hipSuccess) return e;
   H3Batch b{};
-  b.p[0] = H3Args{(const half_t*)Ah, (const half_t*)Al, 32, (long)M * 32, (const half_t*)Wh, (const half_t*)Wl,
-                  (long)Np * 32, K, C, ldc, bias, M, N};
+  b.p[0] = H3Args{(const half_t*)Ah, (const half_t*)Al, Ra * 32, (const half_t*)Wh, (const half_t*)Wl, Rw * 32, K,
+                  C, ldc, bias, M, N};
   b.n = 1;
   return launch_gemm_h3(b, s);
 }
@@ -355,7 +352,7 @@ __global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int
     const float ng = g_tanh(gi[2 * Hp] + rg * d.bhh[2 * Hp + j]);
     const float hv = (1.f - zg) * ng;
     d.hout[row * d.ldo + j] = hv;
-    const long o = (long)(j >> 5) * d.okst + row * 32 + (j & 31);
+    const long o = (long)(j >> 5) * d.okst + plane_index(row, j & 31, 0);
     split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
   }
 }

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
     if (a.dst) {
       a.dst[idx] = v;
     } else {                              // blocked hi / lo fp16 planes for the split-precision GEMM
-      const long o = (long)(kp >> 5) * a.dst_kst + (long)np * 32 + (kp & 31);
+      const long o = (long)(kp >> 5) * a.dst_kst + plane_index(np, kp & 31, 0);   // dst row offset % 16 == 0
       split_hi_lo(v, a.dst_hi[o], a.dst_lo[o]);
     }
   }

@@ -4,6 +4,6 @@
 export TMPDIR=/tmp
 for v in ${@:-base 1 3 4}; do
   if [ $v = base ]; then unset TEPOSE_AMD_LIB; else export TEPOSE_AMD_LIB=$PWD/build/abl/lib_h3abl$v.so; fi
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/abl_$v -- python3 tools/h3_loop.py 131072 9216 2144 4 > gpurun_out/abl_$v.log 2>&1
+  rm -rf gpurun_out/abl_$v; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/abl_$v -- python3 tools/h3_loop.py 131072 9216 2144 4 > gpurun_out/abl_$v.log 2>&1
   echo "== $v"; python3 profiles/summarize.py sq gpurun_out/abl_$v/*/*counter_collection.csv gpurun_out/abl_$v/*/*kernel_trace.csv | grep h3
 done
