@@ -49,14 +49,14 @@ def synthetic_windows_device(B, T, seed, device):
     return x
 
 
-def pmc_traffic(B, T):
+def pmc_traffic(B, T, split):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes of this same command (profiles/rNN_traffic.json; FETCH_SIZE x2 + WRITE_SIZE,
+    passes of this same command (profiles/rNN_traffic_{split,exact}.json; FETCH_SIZE x2 + WRITE_SIZE,
     MI355X_MICROARCH.md HBM section).  None when the workload differs from the profiled one."""
     import glob
     if (B, T) != (8192, 16):
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic_%s.json' % ('split' if split else 'exact'))))
     if not files:
         return None
     with open(files[-1]) as f:
@@ -231,8 +231,8 @@ def main():
             if split:
                 peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                                   'traffic': pmc_traffic(B, T),
-                                   'kernel': 'gemm_h3_kernel<2,32,3> (layer-0 input projection, M=%d N=9216 K=2133)'
+                                   'traffic': pmc_traffic(B, T, True),
+                                   'kernel': 'gemm_h3_kernel<2,2,3,false> (layer-0 input projection, M=%d N=9216 K=2133)'
                                              % (B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n,
                                    'note': 'achieved = algorithmic fp32-equivalent FLOP/s; the kernel issues %d fp16 MFMAs '
@@ -241,7 +241,7 @@ def main():
                                            % (SPLIT_PRODUCTS, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS, ach * SPLIT_PRODUCTS)}
             else:
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                   'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(B, T),
+                                   'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(B, T, False),
                                    'kernel': 'gemm_f32_kernel<false> (layer-0 input projection, M=%d N=9216 K=2133)'
                                              % (B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n}
@@ -250,7 +250,7 @@ def main():
             gpeak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS if split else PEAK_F32_MFMA_TFLOPS
             res['roofline_gru_steps'] = {'bound': 'mfma', 'achieved': gach, 'peak': gpeak,
                                          'unit': 'TFLOP/s', 'frac': gach / gpeak,
-                                         'kernel': ('gemm_h3_kernel + gru_gates_kernel' if split else 'gru_step_kernel') +
+                                         'kernel': ('gemm_h3_kernel<1,3,3,true> (cell update fused) + gru_first_kernel' if split else 'gru_step_kernel') +
                                                    ': the %d step launches of one forward (5T+1 consumed cell steps, '
                                                    'first-step matmuls skipped but counted)' % (2 * T + 1),
                                          'ms_per_forward': g_ms / g_n}

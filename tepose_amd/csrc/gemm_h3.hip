@@ -19,7 +19,7 @@
 namespace tepose {
 
 #ifndef TEPOSE_H3_ABL
-#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds: 1 no DMA in the loop, 2 no barrier, 3 no fragment reads, 4 = 1 + 3
+#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   // outstanding), the raw barrier then makes the whole stage visible and also proves that every wave is
   // done reading stage kt-1, whose slot the next DMA overwrites.  __syncthreads() would drain vmcnt(0).
   const int KT = a.Kp / HK;
-#if TEPOSE_H3_ABL >= 3
+#if TEPOSE_H3_ABL & 4
   Frags f[KS];
 #endif
 #pragma unroll
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   for (int kt = 0; kt < KT; ++kt) {
     const int newer = min(NST - 2, KT - 1 - kt);     // stages issued after kt that may still be in flight
     wait_stages<NDMA, NST - 2>(newer);
-#if TEPOSE_H3_ABL != 2
+#if !(TEPOSE_H3_ABL & 2)
     __builtin_amdgcn_s_barrier();
 #endif
     const char* st = lds + (kt % NST) * STAGE;
@@ -232,12 +232,12 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
     const bool more = kt + NST - 1 < KT;
     char* dst = lds + ((kt + NST - 1) % NST) * STAGE;
     const long koff = kt + NST - 1;
-#if TEPOSE_H3_ABL < 3
+#if !(TEPOSE_H3_ABL & 4)
     Frags f[KS];
 #endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-#if TEPOSE_H3_ABL >= 3
+#if TEPOSE_H3_ABL & 4
       if (kt == 0)
 #endif
       load_frags(st, ks, f[ks]);
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
           accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bl[j], accx[i][j], 0, 0, 0);
           accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].al[i], f[ks].bh[j], accx[i][j], 0, 0, 0);
           if (q < NDMA) {
-#if TEPOSE_H3_ABL != 1 && TEPOSE_H3_ABL != 4
+#if !(TEPOSE_H3_ABL & 1)
             if (more) glds16b(gsrc[q] + koff * kst[q], dst + (wave * NDMA + q) * 1024);
 #endif
             ++q;
