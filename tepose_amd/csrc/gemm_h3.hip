@@ -12,6 +12,8 @@
 // K-tile 32; LDS stage = [A_hi | A_lo | W_hi | W_lo] = 48 KB, double-buffered, filled by LDS-DMA.
 // A tile row is 64 B = 4 slots of 16 B (8 halfs); slot index XOR ((row>>2)&3) on the DMA source and
 // on the read keeps ds_read_b128 conflict-free with a lane-linear LDS image.
+#include <type_traits>
+
 #include "common.h"
 
 #include <stdlib.h>
@@ -206,14 +208,19 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   float pf_gr[16], pf_gz[16], pf_gn[16], pf_hp[16], pf_b[3];
   const int gj = tn * 64 + wn * 32 + r;       // GRU: hidden unit of this lane's columns (ROW_GATES_TILED order)
   const int pf_kt = KT >= 2 ? KT - 2 : 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int newer = min(NST - 2, KT - 1 - kt);     // stages issued after kt that may still be in flight
-    wait_stages<NDMA, NST - 2>(newer);
+  // One K-tile.  DMA = std::true_type in the steady state (the stage NST-1 ahead exists: its DMA instructions
+  // are issued unconditionally, one per MFMA triple, and exactly NST-2 newer stages may stay in flight at the
+  // wait), std::false_type in the last NST-1 K-tiles.  Two instantiations instead of a per-instruction
+  // `if (more)` keep the K-tile one basic block, so the compiler can schedule reads, MFMAs and DMA freely.
+  auto ktile = [&](int kt, auto dma) {
+    constexpr bool DMA = decltype(dma)::value;
+    if constexpr (DMA) wait_vm<(NST - 2) * NDMA>();
+    else wait_stages<NDMA, NST - 2>(min(NST - 2, KT - 1 - kt));
 #if !(TEPOSE_H3_ABL & 2)
     __builtin_amdgcn_s_barrier();
 #endif
     const char* st = lds + (kt % NST) * STAGE;
-    if constexpr (GRU) {
+    if constexpr (GRU && !DMA) {
       if (kt == pf_kt) {
         const GateDir& d = batch.gate[blockIdx.y];
         const int Hp = batch.Hp;
@@ -229,7 +236,6 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
     }
     // Fragments first, then the MFMAs with the next stage's DMA instructions spread between them: all 8
     // waves leave the barrier together, so DMA issued up front would keep every matrix pipe idle meanwhile.
-    const bool more = kt + NST - 1 < KT;
     char* dst = lds + ((kt + NST - 1) % NST) * STAGE;
     const long koff = kt + NST - 1;
 #if !(TEPOSE_H3_ABL & 4)
@@ -254,13 +260,16 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
           accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].al[i], f[ks].bh[j], accx[i][j], 0, 0, 0);
           if (q < NDMA) {
 #if !(TEPOSE_H3_ABL & 1)
-            if (more) glds16b(gsrc[q] + koff * kst[q], dst + (wave * NDMA + q) * 1024);
+            if constexpr (DMA) glds16b(gsrc[q] + koff * kst[q], dst + (wave * NDMA + q) * 1024);
 #endif
             ++q;
           }
         }
     static_assert(NDMA <= KS * WMF * WNT, "one DMA per MFMA triple");
-  }
+  };
+  int kt = 0;
+  for (; kt + NST - 1 < KT; ++kt) ktile(kt, std::true_type{});
+  for (; kt < KT; ++kt) ktile(kt, std::false_type{});
   wait_vm<0>();
 
   if constexpr (GRU) {
