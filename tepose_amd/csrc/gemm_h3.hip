@@ -104,9 +104,9 @@ __device__ __forceinline__ float g_tanh(float x) {
 }
 
 // WMF: 32-row MFMA fragments per wave along M (block rows = 128 * WMF); WNT: 32-column tiles per wave along
-// N (block columns = 64 * WNT); NST: stages in the LDS ring (NST - 1 K-tiles of DMA in flight); GRU: the wave's 3 column tiles are the r, z, n gates of the same 32 hidden units and the epilogue is
+// N (block columns = 64 * WNT); NST: stages in the LDS ring (NST - 1 K-tiles of DMA in flight); ROT: barrier in the middle of the K-tile (see the main loop); GRU: the wave's 3 column tiles are the r, z, n gates of the same 32 hidden units and the epilogue is
 // the GRU cell update (fp32 state + hi/lo planes out) instead of a plain store.
-template <int WMF, int WNT, int NST, bool GRU>
+template <int WMF, int WNT, int NST, bool GRU, bool ROT>
 __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tilesM, int tilesN) {
   constexpr int HK = kPlaneK;                         // K-tile = the planes' block width
   constexpr int HM = 128 * WMF;
@@ -153,11 +153,20 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
       kst[q] = a.w_kst * 2;
     }
     gsrc[q] = base + grow * RB + 16 * (lane % SL);
+    // wave-uniform (an instruction's 16 rows belong to one plane): keep the stride in scalar registers
+    kst[q] = ((long)__builtin_amdgcn_readfirstlane((int)(kst[q] >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)kst[q]);
   }
-  auto issue = [&](int kt, int buf) {
-    char* st = lds + buf * STAGE;
+  // every DMA instruction q is issued once per stage, in stage order: gsrc[q] walks along K by itself
+  auto dma_part = [&](int stage, int q) {
+#if !(TEPOSE_H3_ABL & 1)
+    glds16b(gsrc[q], lds + (stage % NST) * STAGE + (wave * NDMA + q) * 1024);
+#endif
+    gsrc[q] += kst[q];
+  };
+  auto issue = [&](int stage) {
 #pragma unroll
-    for (int q = 0; q < NDMA; ++q) glds16b(gsrc[q] + kt * kst[q], st + (wave * NDMA + q) * 1024);
+    for (int q = 0; q < NDMA; ++q) dma_part(stage, q);
   };
 
   // ---- fragment offsets (bytes inside a stage) ---------------------------------------------------------
@@ -191,85 +200,177 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
       f.bl[j] = *(const h16x8*)(st + W_LO + boff[j] + sx);
     }
   };
-  // Ring of NST stages, NST-1 K-tiles of LDS-DMA in flight.  Per K-tile: every wave waits until its own DMA
-  // instructions of stage kt have landed (counted vmcnt: the newer stages' instructions may stay
-  // outstanding), the raw barrier then makes the whole stage visible and also proves that every wave is
-  // done reading stage kt-1, whose slot the next DMA overwrites.  __syncthreads() would drain vmcnt(0).
   const int KT = a.Kp / HK;
-#if TEPOSE_H3_ABL & 4
-  Frags f[KS];
-#endif
-#pragma unroll
-  for (int p = 0; p < NST - 1; ++p)
-    if (p < KT) issue(p, p);
-  // GRU: the cell operands of this wave's 32 rows x 32 hidden units (gate pre-activations, previous state,
-  // b_hh) are fetched two K-tiles before the end of the loop, so that their HBM latency hides under MFMAs
-  // instead of standing between the last product and the cell update.
+  // GRU: cell operands of this wave's 32 rows x 32 hidden units, fetched during the last K-tiles so that their
+  // HBM latency hides under MFMAs instead of standing between the last product and the cell update
   float pf_gr[16], pf_gz[16], pf_gn[16], pf_hp[16], pf_b[3];
   const int gj = tn * 64 + wn * 32 + r;       // GRU: hidden unit of this lane's columns (ROW_GATES_TILED order)
-  const int pf_kt = KT >= 2 ? KT - 2 : 0;
-  // One K-tile.  DMA = std::true_type in the steady state (the stage NST-1 ahead exists: its DMA instructions
-  // are issued unconditionally, one per MFMA triple, and exactly NST-2 newer stages may stay in flight at the
-  // wait), std::false_type in the last NST-1 K-tiles.  Two instantiations instead of a per-instruction
-  // `if (more)` keep the K-tile one basic block, so the compiler can schedule reads, MFMAs and DMA freely.
-  auto ktile = [&](int kt, auto dma) {
-    constexpr bool DMA = decltype(dma)::value;
-    if constexpr (DMA) wait_vm<(NST - 2) * NDMA>();
-    else wait_stages<NDMA, NST - 2>(min(NST - 2, KT - 1 - kt));
-#if !(TEPOSE_H3_ABL & 2)
-    __builtin_amdgcn_s_barrier();
-#endif
-    const char* st = lds + (kt % NST) * STAGE;
-    if constexpr (GRU && !DMA) {
-      if (kt == pf_kt) {
-        const GateDir& d = batch.gate[blockIdx.y];
-        const int Hp = batch.Hp;
-        pf_b[0] = d.bhh[gj]; pf_b[1] = d.bhh[Hp + gj]; pf_b[2] = d.bhh[2 * Hp + gj];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = min(m0 + wm * 32 + 4 * h + (e & 3) + 8 * (e >> 2), a.M - 1);
-          const float* gi = d.gi + (long)row * d.ldgi + gj;
-          pf_gr[e] = gi[0]; pf_gz[e] = gi[Hp]; pf_gn[e] = gi[2 * Hp];
-          pf_hp[e] = d.hprev[(long)row * d.ldh + gj];
-        }
-      }
-    }
-    // Fragments first, then the MFMAs with the next stage's DMA instructions spread between them: all 8
-    // waves leave the barrier together, so DMA issued up front would keep every matrix pipe idle meanwhile.
-    char* dst = lds + ((kt + NST - 1) % NST) * STAGE;
-    const long koff = kt + NST - 1;
-#if !(TEPOSE_H3_ABL & 4)
-    Frags f[KS];
-#endif
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#if TEPOSE_H3_ABL & 4
-      if (kt == 0)
-#endif
-      load_frags(st, ks, f[ks]);
-    }
-    int q = 0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+  if constexpr (ROT) {
+    // ---- main loop ---------------------------------------------------------------------------------------
+    // Ring of NST = 3 stages; stage s lives in slot s % 3.  The stage barrier sits in the MIDDLE of a K-tile:
+    //
+    //   K-tile kt, first half : read the ks=1 fragments of stage kt; MFMAs of ks=0 (fragments loaded during the
+    //                           previous K-tile); the last NB DMA instructions of stage kt+2
+    //   lgkmcnt(0); vmcnt     : own reads of stage kt done; own DMA of stage kt+1 landed (stage kt+2 may fly)
+    //   s_barrier             : => stage kt+1 complete and visible, and nobody reads stage kt any more
+    //   K-tile kt, second half: read the ks=0 fragments of stage kt+1; MFMAs of ks=1; the first NA DMA
+    //                           instructions of stage kt+3 (into the slot stage kt just left)
+    //
+    // so the fragment reads of a half always run under the other half's MFMAs (with the barrier at the top of the
+    // K-tile, all 8 waves waited for their first ds_read_b128s together after every barrier), two K-tiles of
+    // DMA stay in flight, and the steady state is one basic block (tail K-tiles are a second instantiation).
+    static_assert(!ROT || (NST == 3 && KS == 2), "the rotated pipeline is written for a 3-slot ring and two k-steps per stage");
+    constexpr int TPH = WMF * WNT;                      // MFMA triples per half K-tile
+    constexpr int NB = NDMA / 2, NA = NDMA - NB;        // DMA instructions issued in the first / second half
+    static_assert(NA <= TPH && NB <= TPH, "one DMA per MFMA triple");
+
+    auto half = [&](const Frags& f, int stage, int q0, int nq, bool dma) {
 #pragma unroll
       for (int i = 0; i < WMF; ++i)
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bh[j], acc[i][j], 0, 0, 0);
-          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bl[j], accx[i][j], 0, 0, 0);
-          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].al[i], f[ks].bh[j], accx[i][j], 0, 0, 0);
-          if (q < NDMA) {
-#if !(TEPOSE_H3_ABL & 1)
-            if constexpr (DMA) glds16b(gsrc[q] + koff * kst[q], dst + (wave * NDMA + q) * 1024);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], accx[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], accx[i][j], 0, 0, 0);
+          const int t = i * WNT + j;
+          if (t < nq && dma) dma_part(stage, q0 + t);
+        }
+    };
+
+    // prologue: stages 0, 1 and the first part of stage 2; then stage 0 visible, its ks=0 fragments in flight
+    issue(0);
+    if (KT > 1) issue(1);
+    if (KT > 2) {
+#pragma unroll
+      for (int q = 0; q < NA; ++q) dma_part(2, q);
+    }
+    if (KT > 2) wait_vm<NDMA + NA>();
+    else if (KT > 1) wait_vm<NDMA>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    load_frags(lds, 0, f0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0) on the loop's entry edge too (see the end of ktile)
+
+    auto ktile = [&](int kt, auto steady_t) {
+      constexpr bool STEADY = decltype(steady_t)::value;        // stage kt+3 exists
+      const char* st = lds + (kt % NST) * STAGE;
+      const bool has1 = STEADY || kt + 1 < KT, has2 = STEADY || kt + 2 < KT;
+#if !(TEPOSE_H3_ABL & 4)
+      load_frags(st, 1, f1);
 #endif
-            ++q;
+      __builtin_amdgcn_sched_barrier(0);
+      half(f0, kt + 2, NA, NB, has2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (has1) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's reads of stage kt are done
+        if (has2) wait_vm<NDMA>();
+        else wait_vm<0>();
+#if !(TEPOSE_H3_ABL & 2)
+        __builtin_amdgcn_s_barrier();
+#endif
+#if !(TEPOSE_H3_ABL & 4)
+        load_frags(lds + ((kt + 1) % NST) * STAGE, 0, f0);
+#endif
+      }
+      if constexpr (GRU && !STEADY) {
+        if (kt == (KT >= 2 ? KT - 2 : 0)) {     // youngest memory operations from here on: no DMA follows
+          const GateDir& d = batch.gate[blockIdx.y];
+          const int Hp = batch.Hp;
+          pf_b[0] = d.bhh[gj]; pf_b[1] = d.bhh[Hp + gj]; pf_b[2] = d.bhh[2 * Hp + gj];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = min(m0 + wm * 32 + 4 * h + (e & 3) + 8 * (e >> 2), a.M - 1);
+            const float* gi = d.gi + (long)row * d.ldgi + gj;
+            pf_gr[e] = gi[0]; pf_gz[e] = gi[Hp]; pf_gn[e] = gi[2 * Hp];
+            pf_hp[e] = d.hprev[(long)row * d.ldh + gj];
           }
         }
-    static_assert(NDMA <= KS * WMF * WNT, "one DMA per MFMA triple");
-  };
-  int kt = 0;
-  for (; kt + NST - 1 < KT; ++kt) ktile(kt, std::true_type{});
-  for (; kt < KT; ++kt) ktile(kt, std::false_type{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      half(f1, kt + 3, 0, NA, STEADY);
+      __builtin_amdgcn_sched_barrier(0);
+      // the ks=0 fragments of the next stage landed long ago; saying so keeps the compiler from putting a
+      // conservative lgkmcnt(0) between the next half's reads and its first MFMA (loop-header merge)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    };
+    int kt = 0;
+    for (; kt + 3 < KT; ++kt) ktile(kt, std::true_type{});
+    for (; kt < KT; ++kt) ktile(kt, std::false_type{});
+  } else {
+    // Ring of NST stages, NST-1 K-tiles of LDS-DMA in flight.  Per K-tile: every wave waits until its own DMA
+    // instructions of stage kt have landed (counted vmcnt: the newer stages' instructions may stay
+    // outstanding), the raw barrier then makes the whole stage visible and also proves that every wave is
+    // done reading stage kt-1, whose slot the next DMA overwrites.  __syncthreads() would drain vmcnt(0).
+#if TEPOSE_H3_ABL & 4
+    Frags f[KS];
+#endif
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+      if (p < KT) issue(p);
+    // GRU: the cell operands of this wave's 32 rows x 32 hidden units (gate pre-activations, previous state,
+    // b_hh) are fetched two K-tiles before the end of the loop, so that their HBM latency hides under MFMAs
+    // instead of standing between the last product and the cell update.
+    const int pf_kt = KT >= 2 ? KT - 2 : 0;
+    // One K-tile.  DMA = std::true_type in the steady state (the stage NST-1 ahead exists: its DMA instructions
+    // are issued unconditionally, one per MFMA triple, and exactly NST-2 newer stages may stay in flight at the
+    // wait), std::false_type in the last NST-1 K-tiles.  Two instantiations instead of a per-instruction
+    // `if (more)` keep the K-tile one basic block, so the compiler can schedule reads, MFMAs and DMA freely.
+    auto ktile = [&](int kt, auto dma) {
+      constexpr bool DMA = decltype(dma)::value;
+      if constexpr (DMA) wait_vm<(NST - 2) * NDMA>();
+      else wait_stages<NDMA, NST - 2>(min(NST - 2, KT - 1 - kt));
+#if !(TEPOSE_H3_ABL & 2)
+      __builtin_amdgcn_s_barrier();
+#endif
+      const char* st = lds + (kt % NST) * STAGE;
+      if constexpr (GRU && !DMA) {
+        if (kt == pf_kt) {
+          const GateDir& d = batch.gate[blockIdx.y];
+          const int Hp = batch.Hp;
+          pf_b[0] = d.bhh[gj]; pf_b[1] = d.bhh[Hp + gj]; pf_b[2] = d.bhh[2 * Hp + gj];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = min(m0 + wm * 32 + 4 * h + (e & 3) + 8 * (e >> 2), a.M - 1);
+            const float* gi = d.gi + (long)row * d.ldgi + gj;
+            pf_gr[e] = gi[0]; pf_gz[e] = gi[Hp]; pf_gn[e] = gi[2 * Hp];
+            pf_hp[e] = d.hprev[(long)row * d.ldh + gj];
+          }
+        }
+      }
+      // Fragments first, then the MFMAs with the next stage's DMA instructions spread between them: all 8
+      // waves leave the barrier together, so DMA issued up front would keep every matrix pipe idle meanwhile.
+#if !(TEPOSE_H3_ABL & 4)
+      Frags f[KS];
+#endif
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#if TEPOSE_H3_ABL & 4
+        if (kt == 0)
+#endif
+        load_frags(st, ks, f[ks]);
+      }
+      int q = 0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+#pragma unroll
+          for (int j = 0; j < WNT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bh[j], acc[i][j], 0, 0, 0);
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bl[j], accx[i][j], 0, 0, 0);
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].al[i], f[ks].bh[j], accx[i][j], 0, 0, 0);
+            if (q < NDMA) {
+              if constexpr (DMA) dma_part(kt + NST - 1, q);
+              ++q;
+            }
+          }
+      static_assert(NDMA <= KS * WMF * WNT, "one DMA per MFMA triple");
+    };
+    int kt = 0;
+    for (; kt + NST - 1 < KT; ++kt) ktile(kt, std::true_type{});
+    for (; kt < KT; ++kt) ktile(kt, std::false_type{});
+  }
   wait_vm<0>();
 
   if constexpr (GRU) {
@@ -335,7 +436,7 @@ hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw
 hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   const int tilesM = (b.p[0].M + 255) / 256, tilesN = (b.p[0].N + 127) / 128;
-  hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 3, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM,
+  hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 3, false, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM,
                      tilesN);
   return hipGetLastError();
 }
@@ -343,7 +444,7 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
 hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   const int tilesM = (b.p[0].M + 127) / 128, tilesJ = b.Hp / 64;   // block = 128 rows x (64 hidden units x 3 gates)
-  hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 3, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM,
+  hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 3, true, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM,
                      tilesJ);
   return hipGetLastError();
 }
