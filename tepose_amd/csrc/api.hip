@@ -40,8 +40,10 @@ struct tepose_model {
   size_t wih0_p = 0;                            // its hi|lo planes
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
+  size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
   // regressor offsets
   size_t w1a = 0, b1 = 0, w1b = 0, w2 = 0, b2 = 0, wdec = 0, bdec = 0, init = 0;
+  size_t w1a_p = 0, w1b_p = 0, w2_p = 0, wdec_p = 0, blendW_p = 0;   // blocked hi|lo planes (split path, N > 768)
   SmplOff smpl{};
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
@@ -122,6 +124,8 @@ void layout(tepose_model* m) {
     }
     for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) d->whh_p = take(cur, n128 * Hp);
   }
+  m->wlf_p = take(cur, (size_t)kFeat * Hp);
+  m->wlr_p = take(cur, (size_t)kFeat * 2 * Hp);
   layout_tail(m, cur);
 }
 
@@ -146,6 +150,11 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
   m->smpl.xr_ptr = take(cur, 16);
   m->smpl.xr_idx = take(cur, (size_t)9 * kNV);
   m->smpl.xr_val = take(cur, (size_t)9 * kNV);
+  m->w1a_p = take(cur, 1024 * (size_t)kFeat);
+  m->w1b_p = take(cur, 1024 * (size_t)kState);
+  m->w2_p = take(cur, 1024 * 1024);
+  m->wdec_p = take(cur, 256 * 1024);
+  m->blendW_p = take(cur, (size_t)kBlendN * kBlendK);
   m->blob_floats = cur;
 }
 
@@ -169,6 +178,12 @@ int pack_planes(const float* src, long ld, int N, int K, float* dst_planes, int 
   return (int)launch_pack(a, s);
 }
 
+// blocked hi / lo planes of an already packed fp32 blob matrix [Np][Kp] (lo plane follows the hi plane)
+int planes_of(const float* packed, int Np, int Kp, float* dst_planes, hipStream_t s) {
+  half_t* hi = (half_t*)dst_planes;
+  return (int)launch_split_planes(packed, Kp, Np, Kp, Kp, Np, hi, hi + (size_t)Np * Kp, s);
+}
+
 struct Carver {
   char* base; size_t cur = 0, cap;
   Carver(void* p, size_t c) : base((char*)p), cap(c) {}
@@ -179,6 +194,15 @@ struct Carver {
   }
 };
 
+struct Planes { half_t *hi = nullptr, *lo = nullptr; long kst = 0; };   // blocked planes of an [R x C] matrix
+Planes carve_planes(Carver& c, size_t R, size_t C, bool on) {
+  Planes p;
+  p.hi = (half_t*)c.f(on ? R * C / 2 + 64 : 0);
+  p.lo = (half_t*)c.f(on ? R * C / 2 + 64 : 0);
+  p.kst = (long)R * 32;
+  return p;
+}
+
 // Buffers of one encoder forward (shared between sizing and execution).
 struct EncWs {
   float *xp, *g0, *g0c, *gf, *grr, *grf, *sf[2], *sr[2], *pf[2], *pr[2], *ytop, *y1;
@@ -187,6 +211,7 @@ struct EncWs {
   // fp32 buffers too, so that every time slab starts on a swizzle period; the pad rows are never consumed); x0h / x0l: compact planes of the frames a 1-layer model's rec.l0
   // forward direction consumes
   half_t *state_hi, *state_lo, *x0h, *x0l;
+  Planes tailF, tailR;   // relu(last forward state) [B x Hp] and relu(ytop) [B x 2Hp]: A operands of the tail linears
   size_t Bs = 0;       // rows per time slab of gf/grr/grf/sf/sr: B, or B rounded up to 16 on the split path
   struct Buf { const float* base; size_t T, B, C, poff; };   // poff: first half of its mirror inside state_hi/lo
   Buf bufs[9]; int nbufs = 0;
@@ -244,13 +269,23 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   w.state_lo = (half_t*)c.f(h3 ? w.plane_halfs / 2 + 64 : 0);
   w.x0h = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
   w.x0l = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
+  w.tailF = carve_planes(c, B, Hp, h3);
+  w.tailR = carve_planes(c, B, 2 * Hp, h3);
 }
 
 struct RegWs {
   float *base, *h1, *h2, *xs, *pf, *amat, *posed, *vposed;
+  bool split;                      // N > 768 on a split-mode handle: FC / blend-shape products on the fp16x3 kernel
+  Planes featP, xsP, h1P, h2P, pfP;
 };
 
-void carve_regressor(int N, Carver& c, RegWs& w) {
+void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
+  w.split = m->split && N > skinny_max_m();
+  w.featP = carve_planes(c, N, kFeat, w.split);
+  w.xsP = carve_planes(c, N, kState, w.split);
+  w.h1P = carve_planes(c, N, 1024, w.split);
+  w.h2P = carve_planes(c, N, 1024, w.split);
+  w.pfP = carve_planes(c, N, kBlendK, w.split);
   w.base = c.f((size_t)N * 1024);
   w.h1 = c.f((size_t)N * 1024);
   w.h2 = c.f((size_t)N * 1024);
@@ -267,6 +302,35 @@ GemmArgs gemm(const float* A, long lda, const float* W, int Kp, float* C, long l
   g.A = A; g.lda = lda; g.W = W; g.Kp = Kp; g.C = C; g.ldc = ldc; g.bias = bias;
   g.addend = nullptr; g.ldadd = 0; g.scale = 1.f; g.M = M; g.N = N; g.relu_a = 0;
   return g;
+}
+
+// C = (A W^T + bias + addend) * scale on the split-precision kernel: A as blocked planes, W = blocked planes of a
+// packed [Np][Kp] blob matrix (hi plane, then lo plane); `out`: also write C as planes (the next product's A)
+int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long ldc, const float* bias, int M, int N,
+          const float* addend, long ldadd, float scale, const Planes* out, hipStream_t s) {
+  H3Batch b{};
+  const half_t* wh = (const half_t*)w_planes;
+  H3Args& p = b.p[0];
+  p.Ah = A.hi; p.Al = A.lo; p.a_kst = A.kst;
+  p.Wh = wh; p.Wl = wh + (size_t)Np * Kp; p.w_kst = (long)Np * 32; p.Kp = Kp;
+  p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N;
+  p.addend = addend; p.ldadd = ldadd; p.scale = scale;
+  if (out) { p.Chi = out->hi; p.Clo = out->lo; p.c_kst = out->kst; }
+  b.n = 1;
+  return (int)launch_gemm_h3(b, s);
+}
+
+// v_posed = v_template + shapedirs beta + posedirs^T pose_feature as one GEMM, K = 224
+int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
+  const float* Bl = m->blob;
+  if (w.split) {
+    hipError_t e = launch_split_planes(w.pf, kBlendK, N, kBlendK, kBlendK, N, w.pfP.hi, w.pfP.lo, s);
+    if (e != hipSuccess) return (int)e;
+    return h3_mm(w.pfP, Bl + m->blendW_p, kBlendN, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV, nullptr, 0, 0.f,
+                 nullptr, s);
+  }
+  GemmArgs gv = gemm(w.pf, kBlendK, Bl + m->smpl.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
+  return (int)launch_gemm(gv, s);
 }
 
 }  // namespace
@@ -465,6 +529,8 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
   CK((hipError_t)pack(t[1], 1, kFeat, 1, B + m->blf, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
   CK((hipError_t)pack(t[2], 2 * H, kFeat, 2 * H, B + m->wlr, kFeat, 2 * Hp, ROW_PLAIN, COL_SPLIT2, H, Hp, s));
   CK((hipError_t)pack(t[3], 1, kFeat, 1, B + m->blr, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  CK((hipError_t)planes_of(B + m->wlf, kFeat, Hp, B + m->wlf_p, s));
+  CK((hipError_t)planes_of(B + m->wlr, kFeat, 2 * Hp, B + m->wlr_p, s));
   m->enc_packed = true;
   return 0;
 }
@@ -493,6 +559,10 @@ int tepose_pack_regressor(tepose_model* m, const float* const* w, int n_w, void*
     CK((hipError_t)pack(w[5 + 2 * i], 1, rows[i], 1, B + m->bdec + off[i], rows[i], 1, 0, 0, 0, 1, s));
     CK((hipError_t)pack(w[10 + i], 1, rows[i], 1, B + m->init + off[i], rows[i], 1, 0, 0, 0, 1, s));
   }
+  CK((hipError_t)planes_of(B + m->w1a, 1024, kFeat, B + m->w1a_p, s));
+  CK((hipError_t)planes_of(B + m->w1b, 1024, kState, B + m->w1b_p, s));
+  CK((hipError_t)planes_of(B + m->w2, 1024, 1024, B + m->w2_p, s));
+  CK((hipError_t)planes_of(B + m->wdec, 256, 1024, B + m->wdec_p, s));
   m->reg_packed = true;
   return 0;
 }
@@ -520,6 +590,7 @@ int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shap
   CK(hipStreamSynchronize(s));   // par/dep are stack arrays (pack time only, never on the forward path)
   CK(launch_smpl_consts(v_template, shapedirs, posedirs, J_regressor, B + m->smpl.J0, B + m->smpl.JS,
                         B + m->smpl.blendW, s));
+  CK((hipError_t)planes_of(B + m->smpl.blendW, kBlendN, kBlendK, B + m->blendW_p, s));
   CK((hipError_t)pack(lbs_weights, kNJ, kNV, kNJ, B + m->smpl.lbsW, kNV, kNJ, 0, 0, 0, 1, s));
   CK(launch_lbs_compact(lbs_weights, (int*)(B + m->smpl.lbs_cidx), B + m->smpl.lbs_cval, (int*)(B + m->smpl.lbs_nnz), s));
   int max_nnz = 0;
@@ -548,7 +619,7 @@ size_t tepose_workspace_bytes(const tepose_model* m, int B, int T) {
   carve_encoder(m, B, T, c, e);
   RegWs r;
   c.f((size_t)B * 2 * kFeat);          // feature buffer of tepose_forward
-  carve_regressor(2 * B, c, r);        // is_train regresses 2 rows per window
+  carve_regressor(m, 2 * B, c, r);        // is_train regresses 2 rows per window
   return c.cur + 256;
 }
 
@@ -742,7 +813,21 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   }
   // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
   const float* hlast = w.pf[(T - 1) & 1];
-  if (!is_train) {
+  if (h3) {
+    CK(launch_split_planes(hlast, Hp, B, Hp, Hp, B, w.tailF.hi, w.tailF.lo, s, 1));
+    CK(launch_split_planes(w.ytop, 2 * Hp, B, 2 * Hp, 2 * Hp, B, w.tailR.hi, w.tailR.lo, s, 1));
+    if (!is_train) {
+      CK((hipError_t)h3_mm(w.tailF, Bl + m->wlf_p, kFeat, Hp, w.y1, kFeat, Bl + m->blf, B, kFeat, nullptr, 0, 0.f,
+                           nullptr, s));
+      CK((hipError_t)h3_mm(w.tailR, Bl + m->wlr_p, kFeat, 2 * Hp, feat, kFeat, Bl + m->blr, B, kFeat, w.y1, kFeat,
+                           0.5f, nullptr, s));
+    } else {
+      CK((hipError_t)h3_mm(w.tailF, Bl + m->wlf_p, kFeat, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat, nullptr, 0,
+                           0.f, nullptr, s));
+      CK((hipError_t)h3_mm(w.tailR, Bl + m->wlr_p, kFeat, 2 * Hp, feat + kFeat, 2 * kFeat, Bl + m->blr, B, kFeat,
+                           nullptr, 0, 0.f, nullptr, s));
+    }
+  } else if (!is_train) {
     GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, w.y1, kFeat, Bl + m->blf, B, kFeat);
     g1.relu_a = 1;
     CK(launch_gemm(g1, s));
@@ -900,22 +985,38 @@ int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_
   hipStream_t s = (hipStream_t)stream;
   Carver c(workspace, ws_bytes);
   RegWs w;
-  carve_regressor(N, c, w);
+  carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   const float* Bl = m->blob;
   // xc = cat[x, pose, shape, cam]; fc1(xc) = x W1a^T + b1 (iteration-invariant) + state W1b^T
-  GemmArgs gb = gemm(feat, kFeat, Bl + m->w1a, kFeat, w.base, 1024, Bl + m->b1, N, 1024);
-  CK(launch_gemm(gb, s));
-  CK(launch_init_state(Bl + m->init, w.xs, N, s));
-  for (int it = 0; it < n_iter; ++it) {
-    GemmArgs g1 = gemm(w.xs, kState, Bl + m->w1b, kState, w.h1, 1024, nullptr, N, 1024);
-    g1.addend = w.base; g1.ldadd = 1024;
-    CK(launch_gemm(g1, s));
-    GemmArgs g2 = gemm(w.h1, 1024, Bl + m->w2, 1024, w.h2, 1024, Bl + m->b2, N, 1024);
-    CK(launch_gemm(g2, s));
-    GemmArgs g3 = gemm(w.h2, 1024, Bl + m->wdec, 1024, w.xs, kState, Bl + m->bdec, N, kState);
-    g3.addend = w.xs; g3.ldadd = kState;
-    CK(launch_gemm(g3, s));
+  if (w.split) {
+    CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
+    CK((hipError_t)h3_mm(w.featP, Bl + m->w1a_p, 1024, kFeat, w.base, 1024, Bl + m->b1, N, 1024, nullptr, 0, 0.f,
+                         nullptr, s));
+    CK(launch_init_state(Bl + m->init, w.xs, N, s));
+    CK(launch_split_planes(w.xs, kState, N, kState, kState, N, w.xsP.hi, w.xsP.lo, s));
+    for (int it = 0; it < n_iter; ++it) {
+      CK((hipError_t)h3_mm(w.xsP, Bl + m->w1b_p, 1024, kState, w.h1, 1024, nullptr, N, 1024, w.base, 1024, 0.f,
+                           &w.h1P, s));
+      CK((hipError_t)h3_mm(w.h1P, Bl + m->w2_p, 1024, 1024, w.h2, 1024, Bl + m->b2, N, 1024, nullptr, 0, 0.f,
+                           &w.h2P, s));
+      CK((hipError_t)h3_mm(w.h2P, Bl + m->wdec_p, 256, 1024, w.xs, kState, Bl + m->bdec, N, kState, w.xs, kState,
+                           0.f, &w.xsP, s));
+    }
+  } else {
+    GemmArgs gb = gemm(feat, kFeat, Bl + m->w1a, kFeat, w.base, 1024, Bl + m->b1, N, 1024);
+    CK(launch_gemm(gb, s));
+    CK(launch_init_state(Bl + m->init, w.xs, N, s));
+    for (int it = 0; it < n_iter; ++it) {
+      GemmArgs g1 = gemm(w.xs, kState, Bl + m->w1b, kState, w.h1, 1024, nullptr, N, 1024);
+      g1.addend = w.base; g1.ldadd = 1024;
+      CK(launch_gemm(g1, s));
+      GemmArgs g2 = gemm(w.h1, 1024, Bl + m->w2, 1024, w.h2, 1024, Bl + m->b2, N, 1024);
+      CK(launch_gemm(g2, s));
+      GemmArgs g3 = gemm(w.h2, 1024, Bl + m->wdec, 1024, w.xs, kState, Bl + m->bdec, N, kState);
+      g3.addend = w.xs; g3.ldadd = kState;
+      CK(launch_gemm(g3, s));
+    }
   }
   SmplConsts sc{};
   sc.J0 = Bl + m->smpl.J0; sc.JS = Bl + m->smpl.JS; sc.blendW = Bl + m->smpl.blendW;
@@ -925,9 +1026,7 @@ int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_
   sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
   sc.xr_val = Bl + m->smpl.xr_val;
   CK(launch_smpl_prep(sc, w.xs, N, w.pf, w.amat, w.posed, rotmat, theta, s));
-  // v_posed = v_template + shapedirs beta + posedirs^T pose_feature as one GEMM, K = 224
-  GemmArgs gv = gemm(w.pf, kBlendK, sc.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
-  CK(launch_gemm(gv, s));
+  CK((hipError_t)blend_shapes(m, w, N, s));
   CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
   JregPacked jr{};
   if (jreg_packed) {
@@ -988,12 +1087,11 @@ int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, cons
   hipStream_t s = (hipStream_t)stream;
   Carver c(workspace, ws_bytes);
   RegWs w;
-  carve_regressor(N, c, w);
+  carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
   CK(launch_smpl_prep_pose(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, N, w.pf, w.amat, w.posed, s));
-  GemmArgs gv = gemm(w.pf, kBlendK, sc.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
-  CK(launch_gemm(gv, s));
+  CK((hipError_t)blend_shapes(m, w, N, s));
   CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
   if (joints49) CK(launch_smpl_joints(sc, nullptr, verts, w.posed, nullptr, N, joints49, nullptr, s));
   return 0;
@@ -1006,12 +1104,11 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
   hipStream_t s = (hipStream_t)stream;
   Carver c(workspace, ws_bytes);
   RegWs w;
-  carve_regressor(N, c, w);
+  carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
   CK(launch_smpl_prep_pose(sc, 1, theta + 3, kTheta, theta + 75, kTheta, N, w.pf, w.amat, nullptr, s));
-  GemmArgs gv = gemm(w.pf, kBlendK, sc.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
-  CK(launch_gemm(gv, s));
+  CK((hipError_t)blend_shapes(m, w, N, s));
   CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
   return 0;
 }

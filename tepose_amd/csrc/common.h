@@ -154,6 +154,11 @@ struct H3Args {
   float* C; long ldc;
   const float* bias;                  // [N] or nullptr
   int M, N;
+  // optional epilogue extras (zero-initialised when omitted): C = (A W^T + bias + addend) * scale, and the same
+  // values written as blocked hi / lo planes (the next product's A operand)
+  const float* addend; long ldadd;
+  float scale;                        // 0 = no scaling
+  half_t *Chi, *Clo; long c_kst;      // view base (row 0, column 0), halfs between 32-column groups
 };
 struct GateDir {
   const float* gi; long ldgi;         // x W_ih^T + b_ih, [row*ldgi + g*Hp + j]
@@ -173,9 +178,9 @@ struct GateBatch { GateDir d[3]; };
 hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s);
 // x[rows][2133] fp32 -> blocked hi / lo planes of [rows x 2144]
 hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s);
-// src[rows][ld] fp32 (K valid columns) -> blocked planes of [R x Kp], rows < R
+// (relu?)src[rows][ld] fp32 (K valid columns) -> blocked planes of [R x Kp], rows < R
 hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, long R, void* hi, void* lo,
-                               hipStream_t s);
+                               hipStream_t s, int relu = 0);
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);

@@ -37,7 +37,7 @@ __device__ __forceinline__ void glds16b(const void* g, void* l) {
 // consecutive K-tiles of the same row pair, so a block's reads stay contiguous.
 __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ src, long ld, long rows, int K,
                                                            int Kp, long R, _Float16* __restrict__ hi,
-                                                           _Float16* __restrict__ lo) {
+                                                           _Float16* __restrict__ lo, int relu) {
   const int KT = Kp / kPlaneK;
   const long units = ((rows + 1) / 2) * KT;                 // (row pair, K-tile)
   const int lane = threadIdx.x & 63;
@@ -47,19 +47,20 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
     const long row = 2 * pair + (lane >> 5);
     const int k = kt * kPlaneK + (lane & 31);
     if (row >= rows) continue;
-    const float a = k < K ? src[row * ld + k] : 0.f;
+    float a = k < K ? src[row * ld + k] : 0.f;
+    if (relu) a = fmaxf(a, 0.f);
     const long o = plane_index(row, k, R);
     split_hi_lo(a, hi[o], lo[o]);
   }
 }
 
 hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, long R, void* hi, void* lo,
-                               hipStream_t s) {
+                               hipStream_t s, int relu) {
   if (rows <= 0) return hipSuccess;
   const long units = ((rows + 1) / 2) * (Kp / kPlaneK);
   const int blocks = (int)((units + 3) / 4 < 16384 ? (units + 3) / 4 : 16384);
   hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
-                     (_Float16*)lo);
+                     (_Float16*)lo, relu);
   return hipGetLastError();
 }
 
@@ -399,12 +400,22 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
       const int col = n0 + wn * 32 * WNT + j * 32 + r;
       if (col >= a.N) continue;
       const float bv = a.bias ? a.bias[col] : 0.f;
+      const float sc = a.scale != 0.f ? a.scale : 1.f;
 #pragma unroll
       for (int i = 0; i < WMF; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (row < a.M) a.C[(long)row * a.ldc + col] = (acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale)) + bv;
+          if (row < a.M) {
+            float v = (acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale)) + bv;
+            if (a.addend) v += a.addend[(long)row * a.ldadd + col];
+            v *= sc;
+            a.C[(long)row * a.ldc + col] = v;
+            if (a.Chi) {
+              const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
+              split_hi_lo(v, a.Chi[o], a.Clo[o]);
+            }
+          }
         }
       }
     }

@@ -81,7 +81,7 @@ def test_encoder_vs_oracle(L, H, B, T, smpl_np):
     assert (feat_tr.cpu().double() - ref_tr).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize('N,use_j', [(1, True), (5, False), (200, True)])
+@pytest.mark.parametrize('N,use_j', [(1, True), (5, False), (200, True), (1000, True)])   # 1000: split-precision FCs
 def test_regressor_vs_oracle(N, use_j, smpl_np):
     from oracle import tepose_ref as O
     model, state, _ = _model(1, 64, 3, smpl_np)
