@@ -947,6 +947,17 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
   hipStream_t s = (hipStream_t)stream;
   float* xp = (float*)workspace;
   CK(launch_pad_rows(feat, feat_ld, theta, theta_ld, xp, B, s));
+  const size_t xbytes = align_up((size_t)B * kInputP * sizeof(float), 256);
+  if (m->split && B > skinny_max_m() && ws_bytes >= 2 * xbytes + 512) {   // split-precision product
+    Planes P;
+    P.hi = (half_t*)((char*)workspace + xbytes);
+    P.lo = (half_t*)((char*)workspace + xbytes + xbytes / 2);
+    P.kst = (long)B * 32;
+    CK(launch_split_planes(xp, kInputP, B, kInputP, kInputP, B, P.hi, P.lo, s));
+    CK((hipError_t)h3_mm(P, m->blob + m->wih0_p, round_up(9 * m->Hp, 128), kInputP, out, out_ld, m->blob + m->bih0, B,
+                         9 * m->Hp, nullptr, 0, 0.f, nullptr, s));
+    return 0;
+  }
   GemmArgs g = gemm(xp, kInputP, m->blob + m->wih0, kInputP, out, out_ld, m->blob + m->bih0, B, 9 * m->Hp);
   CK(launch_gemm(g, s));
   return 0;

@@ -95,3 +95,21 @@ def test_cached_projections_equal_uncached(L, H, T, smpl_np):
         for k in ra:
             assert ra[k].shape == rb[k].shape
             assert (ra[k] - rb[k]).abs().max() < 2e-5, k
+
+
+def test_cached_projections_many_clips_split_path(smpl_np):
+    """> 768 concurrent clips: window batches, the per-frame projection of the cache and the regressor all run on the
+    split-precision kernels; cached and uncached drivers must still agree to rounding."""
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    T, C = 4, 801
+    model, _, _ = build_model(2, 64, seed=21, device='cuda', smpl_np=smpl_np)
+    w = synth.synthetic_windows(C, T + 3, 77)
+    feats = [torch.from_numpy(w[i, :T + 2 + (i % 2), :2048].copy()) for i in range(C)]
+    inits = [torch.from_numpy(w[i, :T - 1, 2048:].copy()) for i in range(C)]
+    a = run_clips(model, feats, inits, T, keep=('theta', 'kp_3d'), cache_projections=False)
+    b = run_clips(model, feats, inits, T, keep=('theta', 'kp_3d'), cache_projections=True)
+    for i in (0, 1, 400, 800):
+        for k in ('theta', 'kp_3d'):
+            assert a[i][k].shape == b[i][k].shape
+            assert (a[i][k] - b[i][k]).abs().max() < 2e-5, (i, k)
