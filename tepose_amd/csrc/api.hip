@@ -240,7 +240,7 @@ struct EncWs {
 void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   const size_t Hp = m->Hp, BT = (size_t)B * T;
   const int L = m->L;
-  const bool h3 = m->split && B > skinny_max_m();
+  const bool h3 = m->split && B > split_min_m();
   const size_t Bs = h3 ? (size_t)round_up(B, 16) : (size_t)B, BTs = Bs * T;
   w.Bs = Bs;
   w.xp = c.f(BT * kInputP);
@@ -280,7 +280,7 @@ struct RegWs {
 };
 
 void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
-  w.split = m->split && N > skinny_max_m();
+  w.split = m->split && N > split_min_m();
   w.featP = carve_planes(c, N, kFeat, w.split);
   w.xsP = carve_planes(c, N, kState, w.split);
   w.h1P = carve_planes(c, N, 1024, w.split);
@@ -679,7 +679,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const float* Bl = m->blob;
   const long BT = (long)B * T;
   const int H3 = 3 * Hp;
-  const bool h3 = m->split && B > skinny_max_m();
+  const bool h3 = m->split && B > split_min_m();
   const long Bs = (long)w.Bs;          // rows per time slab of the layer >= 1 buffers
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
@@ -883,7 +883,7 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
 
   // ---- layer-0 input projections: one GEMM for every direction that runs all T steps --------
   const int ld0 = (L >= 2 ? 9 : 6) * Hp;
-  const bool h3 = m->split && B > skinny_max_m();
+  const bool h3 = m->split && B > split_min_m();
   half_t* xh = (half_t*)w.xp;                       // hi / lo planes share the padded-input buffer
   half_t* xl = xh + (size_t)BT * kInputP;
   const size_t rows0 = (size_t)round_up(9 * Hp, 128);
@@ -948,7 +948,7 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
   float* xp = (float*)workspace;
   CK(launch_pad_rows(feat, feat_ld, theta, theta_ld, xp, B, s));
   const size_t xbytes = align_up((size_t)B * kInputP * sizeof(float), 256);
-  if (m->split && B > skinny_max_m() && ws_bytes >= 2 * xbytes + 512) {   // split-precision product
+  if (m->split && B > split_min_m() && ws_bytes >= 2 * xbytes + 512) {   // split-precision product
     Planes P;
     P.hi = (half_t*)((char*)workspace + xbytes);
     P.lo = (half_t*)((char*)workspace + xbytes + xbytes / 2);

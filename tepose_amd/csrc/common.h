@@ -64,6 +64,7 @@ hipError_t launch_gru_step(const GruArgs& a, hipStream_t s);
 hipError_t launch_skinny_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_skinny_gru(const GruArgs& a, hipStream_t s);
 int skinny_max_m();
+int split_min_m();
 
 // ---------------------------------------------------------------- misc.hip
 // dst[np][kp] (row-major [Np][Kp]) = src[rowmap(np)][colmap(kp)] or 0.

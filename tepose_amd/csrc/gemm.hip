@@ -245,6 +245,16 @@ int skinny_max_m() {
   return v;
 }
 
+// Rows above which a split-mode handle runs its matmuls on the fp16x3 kernels of gemm_h3.hip (measured
+// crossover against the skinny kernels: 2.06 vs 2.13 ms per forward at B = 96, 4.9 vs 10.7 ms at B = 768)
+int split_min_m() {
+  static const int v = [] {
+    const char* e = getenv("TEPOSE_SPLIT_MIN_M");
+    return e ? atoi(e) : 96;
+  }();
+  return v;
+}
+
 static int skinny_max_m_gemm() {
   static const int v = [] {
     const char* e = getenv("TEPOSE_SKINNY_MAX_M_GEMM");
