@@ -213,7 +213,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if (os.environ.get('TEPOSE_EXACT_FP32', '0') not in ('', '0') or B <= 96) else
-                     'f16x3-split/f32-acc (GRU matmuls: fp32 operands as fp16 hi+lo halves, 22 significant bits, fp32 '
+                     'f16x3-split/f32-acc (matmuls: fp32 operands as fp16 hi+lo halves, 22 significant bits, fp32 '
                      'accumulate; everything else f32)',
             'data': 'synthetic',
             'config': {'workload': 'cfg-C synthetic [%d,%d,2133] fp32 windows per GPU, TePose n_layers=2 '
