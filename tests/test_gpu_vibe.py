@@ -64,6 +64,20 @@ def test_vibe_published_size_vs_oracle(smpl_np):
     assert (out['kp_3d'].cpu().reshape(-1, 49, 3) - ref['kp_3d']).abs().max() < 1e-4
 
 
+def test_vibe_long_tracklets_split_regressor(smpl_np):
+    """3 tracklets x 50 frames = 150 regressor rows (> 96): the FC stack and the blend-shape GEMM run on the
+    split-precision kernel; same tolerance against the fp64 oracle."""
+    from oracle import tepose_ref as O
+    model, state = _build(1, 64, 5, smpl_np)
+    x = synth.synthetic_windows(3, 50, 78)[:, :, :2048].copy()
+    with torch.no_grad():
+        out = model(torch.from_numpy(x).cuda())[-1]
+    ref = O.vibe_fwd(state, smpl_np, x, 1)
+    assert (out['verts'].cpu().reshape(-1, 6890, 3) - ref['verts']).abs().max() < 1e-4
+    assert (out['kp_3d'].cpu().reshape(-1, 49, 3) - ref['kp_3d']).abs().max() < 1e-4
+    assert (out['theta'].cpu().reshape(-1, 85)[:, :3] - ref['theta'][:, :3]).abs().max() < 1e-4
+
+
 def test_vibe_rejects_unsupported_configs():
     from tepose_amd.vibe import TemporalEncoder
     with pytest.raises(NotImplementedError):
