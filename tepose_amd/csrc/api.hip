@@ -275,16 +275,19 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
 
 struct RegWs {
   float *base, *h1, *h2, *xs, *pf, *amat, *posed, *vposed;
-  bool split;                      // N > 768 on a split-mode handle: FC / blend-shape products on the fp16x3 kernel
+  bool split, split_fc;            // split-mode handle: blend-shape GEMM (N > 96) / FC stack (N > 768) on the fp16x3 kernel
   Planes featP, xsP, h1P, h2P, pfP;
 };
 
 void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
   w.split = m->split && N > split_min_m();
-  w.featP = carve_planes(c, N, kFeat, w.split);
-  w.xsP = carve_planes(c, N, kState, w.split);
-  w.h1P = carve_planes(c, N, 1024, w.split);
-  w.h2P = carve_planes(c, N, 1024, w.split);
+  // the FC stack is narrow (N <= 1024 columns: 8 tiles of the 256-row kernel per 256 rows), so up to 768 rows the
+  // width-first fp32 kernels of skinny.hip fill the chip better than the split kernel (B = 256: 12 us vs 49 us)
+  w.split_fc = m->split && N > skinny_max_m();
+  w.featP = carve_planes(c, N, kFeat, w.split_fc);
+  w.xsP = carve_planes(c, N, kState, w.split_fc);
+  w.h1P = carve_planes(c, N, 1024, w.split_fc);
+  w.h2P = carve_planes(c, N, 1024, w.split_fc);
   w.pfP = carve_planes(c, N, kBlendK, w.split);
   w.base = c.f((size_t)N * 1024);
   w.h1 = c.f((size_t)N * 1024);
@@ -684,7 +687,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t bias, float* out, int M) -> int {
-    if (!h3) {
+    if (!h3 || M <= skinny_max_m()) {     // few rows (the top layer's single-slab projection): width-first fp32 kernel
       GemmArgs g = gemm(in, K, Bl + w_f32, K, out, H3, Bl + bias, M, H3);
       return (int)launch_gemm(g, s);
     }
@@ -813,7 +816,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   }
   // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
   const float* hlast = w.pf[(T - 1) & 1];
-  if (h3) {
+  if (h3 && B > skinny_max_m()) {     // narrow products (N = 2048): below that the skinny fp32 kernels win
     CK(launch_split_planes(hlast, Hp, B, Hp, Hp, B, w.tailF.hi, w.tailF.lo, s, 1));
     CK(launch_split_planes(w.ytop, 2 * Hp, B, 2 * Hp, 2 * Hp, B, w.tailR.hi, w.tailR.lo, s, 1));
     if (!is_train) {
@@ -1000,7 +1003,7 @@ int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   const float* Bl = m->blob;
   // xc = cat[x, pose, shape, cam]; fc1(xc) = x W1a^T + b1 (iteration-invariant) + state W1b^T
-  if (w.split) {
+  if (w.split_fc) {
     CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     CK((hipError_t)h3_mm(w.featP, Bl + m->w1a_p, 1024, kFeat, w.base, 1024, Bl + m->b1, N, 1024, nullptr, 0, 0.f,
                          nullptr, s));

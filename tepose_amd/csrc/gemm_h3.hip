@@ -104,13 +104,14 @@ __device__ __forceinline__ float g_tanh(float x) {
   return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
 }
 
-// WMF: 32-row MFMA fragments per wave along M (block rows = 128 * WMF); WNT: 32-column tiles per wave along
+// WMF: 32-row MFMA fragments per wave along M, NWM: waves along M (block rows = 32 * WMF * NWM; 2 waves along N); WNT: 32-column tiles per wave along
 // N (block columns = 64 * WNT); NST: stages in the LDS ring (NST - 1 K-tiles of DMA in flight); ROT: barrier in the middle of the K-tile (see the main loop); GRU: the wave's 3 column tiles are the r, z, n gates of the same 32 hidden units and the epilogue is
 // the GRU cell update (fp32 state + hi/lo planes out) instead of a plain store.
-template <int WMF, int WNT, int NST, bool GRU, bool ROT>
-__global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tilesM, int tilesN) {
+template <int WMF, int WNT, int NST, bool GRU, bool ROT, int NWM = 4>
+__global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int tilesM, int tilesN) {
   constexpr int HK = kPlaneK;                         // K-tile = the planes' block width
-  constexpr int HM = 128 * WMF;
+  constexpr int NW = 2 * NWM;                         // waves: NWM along M x 2 along N
+  constexpr int HM = 32 * WMF * NWM;
   constexpr int HN = 64 * WNT;
   static_assert(!GRU || WNT == 3, "GRU epilogue needs the three gate tiles in one wave");
   constexpr int RB = HK * 2;                          // bytes per tile row of one plane
@@ -118,9 +119,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
   constexpr int RPB = 256 / RB;                       // rows per 256-byte LDS bank row
   constexpr int RPI = 1024 / RB;                      // rows moved by one wave-wide DMA instruction
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;
-  constexpr int NDMA = STAGE / 1024 / 8;              // DMA instructions per wave per stage
+  constexpr int NDMA = STAGE / 1024 / NW;             // DMA instructions per wave per stage
   constexpr int KS = HK / 16;                         // 16-deep MFMA steps per stage
-  static_assert(STAGE % 8192 == 0 && NST * STAGE <= 160 * 1024, "stage geometry");
+  static_assert(STAGE % (1024 * NW) == 0 && NST * STAGE <= 160 * 1024, "stage geometry");
   __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
   const H3Args& a = batch.p[blockIdx.y];
   int tm, tn;
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
     static_assert(!ROT || (NST == 3 && KS == 2), "the rotated pipeline is written for a 3-slot ring and two k-steps per stage");
     constexpr int TPH = WMF * WNT;                      // MFMA triples per half K-tile
     constexpr int NB = NDMA / 2, NA = NDMA - NB;        // DMA instructions issued in the first / second half
-    static_assert(NA <= TPH && NB <= TPH, "one DMA per MFMA triple");
+    static_assert(NA <= 2 * TPH && NB <= 2 * TPH, "at most two DMA instructions per MFMA triple");
 
     auto half = [&](const Frags& f, int stage, int q0, int nq, bool dma) {
 #pragma unroll
@@ -233,8 +234,11 @@ __global__ void __launch_bounds__(512, 2) gemm_h3_kernel(H3Batch batch, int tile
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
           accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], accx[i][j], 0, 0, 0);
           accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], accx[i][j], 0, 0, 0);
-          const int t = i * WNT + j;
-          if (t < nq && dma) dma_part(stage, q0 + t);
+          const int t = i * WNT + j;                         // DMA instructions [t*nq/TPH, (t+1)*nq/TPH) go here
+          if (dma) {
+#pragma unroll
+            for (int q = t * nq / TPH; q < (t + 1) * nq / TPH; ++q) dma_part(stage, q0 + q);
+          }
         }
     };
 
@@ -454,7 +458,14 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
 
 hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
-  const int tilesM = (b.p[0].M + 127) / 128, tilesJ = b.Hp / 64;   // block = 128 rows x (64 hidden units x 3 gates)
+  int tilesM = (b.p[0].M + 127) / 128;
+  const int tilesJ = b.Hp / 64;                      // block = 128 rows x (64 hidden units x 3 gates)
+  if (tilesM * tilesJ * b.n <= 160) {                // mid-size batches: 64-row blocks (4 waves) fill more CUs
+    tilesM = (b.p[0].M + 63) / 64;
+    hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 3, true, true, 2>), dim3(tilesM * tilesJ, b.n), dim3(256), 0, s, b, tilesM,
+                       tilesJ);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 3, true, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM,
                      tilesJ);
   return hipGetLastError();
