@@ -246,11 +246,12 @@ int skinny_max_m() {
 }
 
 // Rows above which a split-mode handle runs its matmuls on the fp16x3 kernels of gemm_h3.hip (measured
-// crossover against the skinny kernels: 2.06 vs 2.13 ms per forward at B = 96, 4.9 vs 10.7 ms at B = 768)
+// crossover against the skinny kernels, ms per forward at T = 16: B = 32 1.27 vs 1.10, B = 48 1.54 vs 1.57,
+// B = 64 1.50 vs 1.59, B = 96 1.54 vs 2.14, B = 768 4.7 vs 10.7)
 int split_min_m() {
   static const int v = [] {
     const char* e = getenv("TEPOSE_SPLIT_MIN_M");
-    return e ? atoi(e) : 96;
+    return e ? atoi(e) : 32;
   }();
   return v;
 }
