@@ -721,6 +721,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     }
     if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s);
     b.n = a.ndir; b.Hp = Hp;
+    if (B <= skinny_h3_max_m()) return (int)launch_skinny_gru_h3(b, s);
     return (int)launch_gru_h3(b, s);
   };
   auto gi0 = [&](int t, int dir, const float*& p, long& ld) {

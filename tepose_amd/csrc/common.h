@@ -174,6 +174,9 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
 // recurrent product with the GRU cell update fused into the epilogue: W planes in the gate-interleaved tile
 // order (ROW_GATES_TILED), p[d].C unused, gate[d] describes the cell operands / outputs
 hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s);
+// the same step for small M (skinny_h3.hip): width-first blocks, K split over the waves, operands streamed to VGPRs
+hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s);
+int skinny_h3_max_m();
 // first cell step of a direction (h = 0: no product), writing the same outputs
 struct GateBatch { GateDir d[3]; };
 hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s);

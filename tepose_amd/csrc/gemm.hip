@@ -256,6 +256,15 @@ int split_min_m() {
   return v;
 }
 
+// Rows up to which a split-mode GRU step uses the width-first kernel of skinny_h3.hip instead of 64/128-row tiles
+int skinny_h3_max_m() {
+  static const int v = [] {
+    const char* e = getenv("TEPOSE_SKINNY_H3_MAX_M");
+    return e ? atoi(e) : 128;
+  }();
+  return v;
+}
+
 static int skinny_max_m_gemm() {
   static const int v = [] {
     const char* e = getenv("TEPOSE_SKINNY_MAX_M_GEMM");

@@ -1,0 +1,160 @@
+// Small-M GRU step on the split-precision operands (fp16 hi / lo planes, three fp16 MFMAs per product, fp32
+// accumulation; gemm_h3.hip explains the arithmetic): the 33 < B <= a few hundred regime of a split-mode handle
+// (real-data evaluation with tens to hundreds of concurrent clips).
+//
+// At these batch sizes a GRU step is a weight-streaming problem (37.7 MB of W_hh planes per 3-direction step at
+// H = 1024), the fp32 skinny kernel of skinny.hip is bound by the slow fp32 MFMA once M > 16, and the 64/128-row
+// tiles of gemm_h3.hip leave most CUs idle (B = 64: 48 blocks).  Same cut as skinny.hip, for width: a block owns
+// 16*MT rows x 16 hidden units x 3 gates, its 4 waves split K four ways and stream their slice of the A and W
+// planes straight from global memory into VGPRs (one 16-byte load per lane = the lane's 8 k-values of a
+// 16x16x32 MFMA operand: the blocked plane layout of common.h keeps a row's 32-wide K-tile in one 64-byte run),
+// two K-tiles in flight, one LDS pass to add the 4 partial sums, then the cell update.
+#include "common.h"
+
+namespace tepose {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float sh_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float sh_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+}
+
+// halfs from the start of a row's K-tile to the 8 k-values lane-quarter q reads (slot swizzle of plane_index)
+__device__ __forceinline__ int slot_off(long row, int q) { return ((q ^ (int)((row >> 2) & 3)) << 3); }
+
+template <int MT>
+__global__ void __launch_bounds__(256) skinny_gru_h3_kernel(H3Batch batch, int M) {
+  constexpr int NW = 4;
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
+  const H3Args& a = batch.p[blockIdx.z];
+  const GateDir& d = batch.gate[blockIdx.z];
+  const int Hp = batch.Hp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  // epilogue operands first: their latency hides under the weight stream below
+  const int e = (threadIdx.x >> 6) & 3;          // accumulator register this thread finishes after the reduction
+  const int j = j0 + r16;
+  const float br = d.bhh[j], bz = d.bhh[Hp + j], bn = d.bhh[2 * Hp + j];
+  float gr[MT], gz[MT], gn[MT], hp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = min(m0 + i * 16 + q * 4 + e, M - 1);
+    const float* gi = d.gi + (long)row * d.ldgi + j;
+    gr[i] = gi[0]; gz[i] = gi[Hp]; gn[i] = gi[2 * Hp];
+    hp[i] = d.hprev[(long)row * d.ldh + j];
+  }
+
+  // operand pointers (halfs), K-tile 0: A rows of the hprev view, W rows in the gate-interleaved tile order
+  const half_t *ah[MT], *al[MT], *wh[3], *wl[3];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const long row = min(m0 + i * 16 + r16, M - 1);
+    const long o = row * 32 + slot_off(row, q);
+    ah[i] = a.Ah + o; al[i] = a.Al + o;
+  }
+  const int rbase = (j0 >> 6) * 192 + ((j0 & 63) >> 5) * 96 + (j0 & 31);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const long row = rbase + g * 32 + r16;
+    const long o = row * 32 + slot_off(row, q);
+    wh[g] = a.Wh + o; wl[g] = a.Wl + o;
+  }
+  const int KT = a.Kp / kPlaneK;
+  const int c0 = (wave * KT) / NW, c1 = ((wave + 1) * KT) / NW;
+
+  f32x4 acc[MT][3], accx[MT][3];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  struct Chunk { h16x8 ah[MT], al[MT], wh[3], wl[3]; };
+  auto load = [&](int c, Chunk& k) {
+    const long ao = (long)c * a.a_kst, wo = (long)c * a.w_kst;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      k.ah[i] = *(const h16x8*)(ah[i] + ao);
+      k.al[i] = *(const h16x8*)(al[i] + ao);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      k.wh[g] = *(const h16x8*)(wh[g] + wo);
+      k.wl[g] = *(const h16x8*)(wl[g] + wo);
+    }
+  };
+  auto mma = [&](const Chunk& k) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.ah[i], k.wh[g], acc[i][g], 0, 0, 0);
+        accx[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.ah[i], k.wl[g], accx[i][g], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+        accx[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.al[i], k.wh[g], accx[i][g], 0, 0, 0);
+  };
+  if (c0 < c1) {
+    Chunk p, n;
+    load(c0, p);
+    for (int c = c0; c < c1; c += 2) {
+      const bool more = c + 1 < c1;
+      if (more) load(c + 1, n);
+      mma(p);
+      if (more) {
+        if (c + 2 < c1) load(c + 2, p);
+        mma(n);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee)
+        red[((wave * MT * 3 + i * 3 + g) * 4 + ee) * 64 + lane] = acc[i][g][ee] + accx[i][g][ee] * (1.f / kLoScale);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float hr = 0.f, hz = 0.f, hn = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      hr += red[((w * MT * 3 + i * 3 + 0) * 4 + e) * 64 + lane];
+      hz += red[((w * MT * 3 + i * 3 + 1) * 4 + e) * 64 + lane];
+      hn += red[((w * MT * 3 + i * 3 + 2) * 4 + e) * 64 + lane];
+    }
+    const int row = m0 + i * 16 + q * 4 + e;
+    if (row < M) {
+      const float rg = sh_sigmoid(gr[i] + (hr + br));
+      const float zg = sh_sigmoid(gz[i] + (hz + bz));
+      const float ng = sh_tanh(gn[i] + rg * (hn + bn));
+      const float hv = (1.f - zg) * ng + zg * hp[i];
+      d.hout[(long)row * d.ldo + j] = hv;
+      const long o = (long)(j >> 5) * d.okst + plane_index(row, j & 31, 0);
+      split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
+    }
+  }
+}
+
+hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s) {
+  const int M = b.p[0].M;
+  if (b.n <= 0 || M <= 0) return hipSuccess;
+  const int jt = b.Hp / 16;
+  if (M <= 32) {
+    hipLaunchKernelGGL((skinny_gru_h3_kernel<2>), dim3(jt, 1, b.n), dim3(256), 0, s, b, M);
+  } else {
+    hipLaunchKernelGGL((skinny_gru_h3_kernel<4>), dim3(jt, (M + 63) / 64, b.n), dim3(256), 0, s, b, M);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace tepose
