@@ -212,7 +212,7 @@ def main():
             'value': windows / t_max, 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if (os.environ.get('TEPOSE_EXACT_FP32', '0') not in ('', '0') or B <= 32) else
+            'dtype': 'f32' if (os.environ.get('TEPOSE_EXACT_FP32', '0') not in ('', '0') or B <= 4) else
                      'f16x3-split/f32-acc (matmuls: fp32 operands as fp16 hi+lo halves, 22 significant bits, fp32 '
                      'accumulate; everything else f32)',
             'data': 'synthetic',
@@ -225,7 +225,7 @@ def main():
         if T in GFLOP_PER_WINDOW:
             res['whole_path_tflops'] = windows * GFLOP_PER_WINDOW[T] / t_max / 1e3
             res['whole_path_frac_of_f32_mfma_peak'] = res['whole_path_tflops'] / (PEAK_F32_MFMA_TFLOPS * world)   # > 1 is possible in split mode
-        split = os.environ.get('TEPOSE_EXACT_FP32', '0') in ('', '0') and B > 32
+        split = os.environ.get('TEPOSE_EXACT_FP32', '0') in ('', '0') and B > 4
         if k_n > 0:
             ach = k_flops / (k_ms / k_n * 1e-3) / 1e12
             if split:

@@ -246,12 +246,12 @@ int skinny_max_m() {
 }
 
 // Rows above which a split-mode handle runs its matmuls on the fp16x3 kernels of gemm_h3.hip (measured
-// crossover against the skinny kernels, ms per forward at T = 16: B = 32 1.27 vs 1.10, B = 48 1.54 vs 1.57,
-// B = 64 1.50 vs 1.59, B = 96 1.54 vs 2.14, B = 768 4.7 vs 10.7)
+// crossover against the fp32 skinny kernels, ms per forward at T = 16, split vs fp32: B = 1 0.55 vs 0.54, B = 4
+// 0.66 vs 0.62, B = 8 0.59 vs 0.67, B = 16 0.63 vs 0.79, B = 32 0.77 vs 1.09, B = 64 1.10 vs 1.59, B = 768 4.7 vs 10.7)
 int split_min_m() {
   static const int v = [] {
     const char* e = getenv("TEPOSE_SPLIT_MIN_M");
-    return e ? atoi(e) : 32;
+    return e ? atoi(e) : 4;
   }();
   return v;
 }

@@ -98,7 +98,7 @@ def test_cached_projections_equal_uncached(L, H, T, smpl_np):
 
 
 def test_cached_projections_many_clips_split_path(smpl_np):
-    """> 32 concurrent clips (here 801): window batches, the per-frame projection of the cache and the regressor all run on the
+    """> 4 concurrent clips (here 801): window batches, the per-frame projection of the cache and the regressor all run on the
     split-precision kernels; cached and uncached drivers must still agree to rounding."""
     from tepose_amd.driver import run_clips
     from tepose_amd.testing import build_model

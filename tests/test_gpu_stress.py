@@ -95,7 +95,7 @@ def test_split_precision_gemm_random_shapes_against_fp64():
 
 
 def test_split_and_exact_paths_agree_on_a_large_batch(monkeypatch):
-    """B > 32 runs the matmuls on the split-precision kernels; TEPOSE_EXACT_FP32=1 (read when the
+    """B > 4 runs the matmuls on the split-precision kernels; TEPOSE_EXACT_FP32=1 (read when the
     handle is created) keeps them on the exact-fp32 MFMA.  Same inputs, both paths: outputs within 1e-5."""
     from tepose_amd.testing import build_model
     smpl_np = synth.synthetic_smpl(0)
