@@ -275,15 +275,13 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
 
 struct RegWs {
   float *base, *h1, *h2, *xs, *pf, *amat, *posed, *vposed;
-  bool split, split_fc;            // split-mode handle: blend-shape GEMM (N > 96) / FC stack (N > 768) on the fp16x3 kernel
+  bool split, split_fc;            // split-mode handle with N > 4 rows: blend-shape GEMM / FC stack on the fp16x3 kernels
   Planes featP, xsP, h1P, h2P, pfP;
 };
 
 void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
   w.split = m->split && N > split_min_m();
-  // the FC stack is narrow (N <= 1024 columns: 8 tiles of the 256-row kernel per 256 rows), so up to 768 rows the
-  // width-first fp32 kernels of skinny.hip fill the chip better than the split kernel (B = 256: 12 us vs 49 us)
-  w.split_fc = m->split && N > skinny_max_m();
+  w.split_fc = w.split;            // h3_mm picks the width-first kernel for <= 768 rows, 256-row tiles above
   w.featP = carve_planes(c, N, kFeat, w.split_fc);
   w.xsP = carve_planes(c, N, kState, w.split_fc);
   w.h1P = carve_planes(c, N, 1024, w.split_fc);
@@ -319,6 +317,9 @@ int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long
   p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N;
   p.addend = addend; p.ldadd = ldadd; p.scale = scale;
   if (out) { p.Chi = out->hi; p.Clo = out->lo; p.c_kst = out->kst; }
+  // few rows: width-first kernel (skinny_h3.hip), except the short-K / very wide blend-shape product, which already
+  // makes 162 tiles of the big kernel
+  if (M <= skinny_max_m() && !(N > 4096 && Kp < 512)) return (int)launch_skinny_gemm_h3(p, s);
   b.n = 1;
   return (int)launch_gemm_h3(b, s);
 }
@@ -687,17 +688,14 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t bias, float* out, int M) -> int {
-    if (!h3 || M <= skinny_max_m()) {     // few rows (the top layer's single-slab projection): width-first fp32 kernel
+    if (!h3) {
       GemmArgs g = gemm(in, K, Bl + w_f32, K, out, H3, Bl + bias, M, H3);
       return (int)launch_gemm(g, s);
     }
-    H3Batch b{};
-    const half_t* wh = (const half_t*)(Bl + w_planes);
     const EncWs::View v = w.view(in);
     if (!v.hi) return (int)hipErrorInvalidValue;
-    b.p[0] = H3Args{v.hi, v.lo, v.kst, wh, wh + n128 * K, (long)n128 * 32, K, out, (long)H3, Bl + bias, M, H3};
-    b.n = 1;
-    return (int)launch_gemm_h3(b, s);
+    Planes A; A.hi = v.hi; A.lo = v.lo; A.kst = v.kst;
+    return h3_mm(A, Bl + w_planes, (int)n128, K, out, (long)H3, Bl + bias, M, H3, nullptr, 0, 0.f, nullptr, s);
   };
   // one GRU step of up to 3 directions: fused fp32 kernel; or the split product with the cell update in its
   // epilogue (first step: h = 0, element-wise kernel)
@@ -817,7 +815,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   }
   // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
   const float* hlast = w.pf[(T - 1) & 1];
-  if (h3 && B > skinny_max_m()) {     // narrow products (N = 2048): below that the skinny fp32 kernels win
+  if (h3) {
     CK(launch_split_planes(hlast, Hp, B, Hp, Hp, B, w.tailF.hi, w.tailF.lo, s, 1));
     CK(launch_split_planes(w.ytop, 2 * Hp, B, 2 * Hp, 2 * Hp, B, w.tailR.hi, w.tailR.lo, s, 1));
     if (!is_train) {

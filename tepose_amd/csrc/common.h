@@ -176,6 +176,7 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
 hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s);
 // the same step for small M (skinny_h3.hip): width-first blocks, K split over the waves, operands streamed to VGPRs
 hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s);
+hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s);
 int skinny_h3_max_m();
 // first cell step of a direction (h = 0: no product), writing the same outputs
 struct GateBatch { GateDir d[3]; };

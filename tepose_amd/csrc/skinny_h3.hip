@@ -1,4 +1,4 @@
-// Small-M GRU step on the split-precision operands (fp16 hi / lo planes, three fp16 MFMAs per product, fp32
+// Small-M GRU step and GEMM on the split-precision operands (fp16 hi / lo planes, three fp16 MFMAs per product, fp32
 // accumulation; gemm_h3.hip explains the arithmetic): the 33 < B <= a few hundred regime of a split-mode handle
 // (real-data evaluation with tens to hundreds of concurrent clips).
 //
@@ -143,6 +143,123 @@ __global__ void __launch_bounds__(256) skinny_gru_h3_kernel(H3Batch batch, int M
       split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
     }
   }
+}
+
+// Small-M product C = (A W^T + bias + addend) * scale on the same operands (optionally also written as planes):
+// a block owns 16*MT rows x 48 columns, K split over the 4 waves exactly as above.
+template <int MT>
+__global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3Args a) {
+  constexpr int NW = 4;
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 48, m0 = blockIdx.y * 16 * MT;
+  const int r16 = lane & 15, q = lane >> 4;
+  const long wrows = a.w_kst / 32;               // rows the W planes hold (padded to the 128-row tile, zero past N)
+
+  const half_t *ah[MT], *al[MT], *wh[3], *wl[3];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const long row = min(m0 + i * 16 + r16, a.M - 1);
+    const long o = row * 32 + slot_off(row, q);
+    ah[i] = a.Ah + o; al[i] = a.Al + o;
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const long row = min((long)(n0 + t * 16 + r16), wrows - 1);
+    const long o = row * 32 + slot_off(row, q);
+    wh[t] = a.Wh + o; wl[t] = a.Wl + o;
+  }
+  const int KT = a.Kp / kPlaneK;
+  const int c0 = (wave * KT) / NW, c1 = ((wave + 1) * KT) / NW;
+
+  f32x4 acc[MT][3], accx[MT][3];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  struct Chunk { h16x8 ah[MT], al[MT], wh[3], wl[3]; };
+  auto load = [&](int c, Chunk& k) {
+    const long ao = (long)c * a.a_kst, wo = (long)c * a.w_kst;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      k.ah[i] = *(const h16x8*)(ah[i] + ao);
+      k.al[i] = *(const h16x8*)(al[i] + ao);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      k.wh[t] = *(const h16x8*)(wh[t] + wo);
+      k.wl[t] = *(const h16x8*)(wl[t] + wo);
+    }
+  };
+  auto mma = [&](const Chunk& k) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.ah[i], k.wh[t], acc[i][t], 0, 0, 0);
+        accx[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.ah[i], k.wl[t], accx[i][t], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        accx[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.al[i], k.wh[t], accx[i][t], 0, 0, 0);
+  };
+  if (c0 < c1) {
+    Chunk p, n;
+    load(c0, p);
+    for (int c = c0; c < c1; c += 2) {
+      const bool more = c + 1 < c1;
+      if (more) load(c + 1, n);
+      mma(p);
+      if (more) {
+        if (c + 2 < c1) load(c + 2, p);
+        mma(n);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee)
+        red[((wave * MT * 3 + i * 3 + t) * 4 + ee) * 64 + lane] = acc[i][t][ee] + accx[i][t][ee] * (1.f / kLoScale);
+  __syncthreads();
+  const int e = threadIdx.x >> 6;                // accumulator register of the element this thread finishes
+  const float sc = a.scale != 0.f ? a.scale : 1.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[((w * MT * 3 + i * 3 + t) * 4 + e) * 64 + lane];
+      const int row = m0 + i * 16 + q * 4 + e, col = n0 + t * 16 + r16;
+      if (row < a.M && col < a.N) {
+        if (a.bias) v += a.bias[col];
+        if (a.addend) v += a.addend[(long)row * a.ldadd + col];
+        v *= sc;
+        a.C[(long)row * a.ldc + col] = v;
+        if (a.Chi) {
+          const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
+          split_hi_lo(v, a.Chi[o], a.Clo[o]);
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  const int nt = (a.N + 47) / 48;
+  if (a.M <= 32) {
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (a.M + 63) / 64), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s) {
