@@ -112,3 +112,35 @@ def test_split_and_exact_paths_agree_on_a_large_batch(monkeypatch):
         d = (a[k] - b[k]).abs().max().item()
         assert 0 < d < 1e-5 or (k != 'verts' and d < 1e-5), (k, d)
     assert (a['theta'][:, :3] - b['theta'][:, :3]).abs().max() < 1e-5
+
+
+def test_both_numerics_modes_vs_fp64_oracle_at_the_published_size(monkeypatch, capsys):
+    """L=2, H=1024, T=16 (the benchmark architecture), B=1024: the split-precision default and the exact-fp32 mode
+    against the fp64 oracle on the same windows.  Both must sit far inside the 1e-4 budget; the measured errors are
+    printed (pytest -s) -- the split path is not the less accurate of the two."""
+    from oracle import tepose_ref as O
+    from tepose_amd.testing import build_model
+    smpl_np = synth.synthetic_smpl(0)
+    x = synth.synthetic_windows(1024, 16, 4242)
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    errs = {}
+    state = None
+    for mode in ('split', 'exact'):
+        if mode == 'exact':
+            monkeypatch.setenv('TEPOSE_EXACT_FP32', '1')
+        model, state, _ = build_model(2, 1024, seed=0, device='cuda', smpl_np=smpl_np)
+        if mode == 'exact':
+            monkeypatch.delenv('TEPOSE_EXACT_FP32')
+        with torch.no_grad():
+            out = model(torch.from_numpy(x).cuda(), J_regressor=J)[0]
+        errs[mode] = {k: out[k][:24].cpu().double() for k in ('verts', 'kp_3d', 'rotmat', 'kp_2d', 'theta')}
+        del model
+    ref = O.tepose_fwd(state, smpl_np, x[:24], 2, J_regressor=smpl_np['J_regressor_h36m'], dtype=torch.float64)
+    for mode, got in errs.items():
+        for k in ('verts', 'kp_3d', 'rotmat', 'kp_2d'):
+            e = (got[k] - ref[k]).abs().max().item()
+            with capsys.disabled():
+                print('  %-5s %-7s max|gpu - fp64 oracle| = %.2e' % (mode, k, e))
+            assert e < 2e-5, (mode, k, e)
+        assert (got['theta'][:, :3] - ref['theta'][:, :3]).abs().max() < 2e-5
+        assert (got['theta'][:, 75:] - ref['theta'][:, 75:]).abs().max() < 2e-5
