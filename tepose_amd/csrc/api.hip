@@ -319,7 +319,9 @@ int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long
   if (out) { p.Chi = out->hi; p.Clo = out->lo; p.c_kst = out->kst; }
   // few rows: width-first kernel (skinny_h3.hip), except the short-K / very wide blend-shape product, which already
   // makes 162 tiles of the big kernel
-  if (M <= skinny_max_m() && !(N > 4096 && Kp < 512)) return (int)launch_skinny_gemm_h3(p, s);
+  // (and any product with <= 256 columns -- the stacked decoders -- at every M: 2 column tiles of the big kernel
+  // would use 64 CUs)
+  if ((M <= skinny_max_m() && !(N > 4096 && Kp < 512)) || N <= 256) return (int)launch_skinny_gemm_h3(p, s);
   b.n = 1;
   return (int)launch_gemm_h3(b, s);
 }

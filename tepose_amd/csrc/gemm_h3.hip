@@ -41,16 +41,27 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
   const int KT = Kp / kPlaneK;
   const long units = ((rows + 1) / 2) * KT;                 // (row pair, K-tile)
   const int lane = threadIdx.x & 63;
-  for (long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += (long)gridDim.x * 4) {
-    const long pair = u / KT;
-    const int kt = (int)(u - pair * KT);
-    const long row = 2 * pair + (lane >> 5);
-    const int k = kt * kPlaneK + (lane & 31);
-    if (row >= rows) continue;
-    float a = k < K ? src[row * ld + k] : 0.f;
-    if (relu) a = fmaxf(a, 0.f);
-    const long o = plane_index(row, k, R);
-    split_hi_lo(a, hi[o], lo[o]);
+  constexpr int U = 4;                                      // units per wave and trip: U independent loads in flight
+  for (long u0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * U; u0 < units; u0 += (long)gridDim.x * 4 * U) {
+    float v[U];
+    long o[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const long u = u0 + i;
+      const long pair = u / KT;
+      const int kt = (int)(u - pair * KT);
+      const long row = 2 * pair + (lane >> 5);
+      const int k = kt * kPlaneK + (lane & 31);
+      const bool ok = u < units && row < rows;
+      v[i] = (ok && k < K) ? src[row * ld + k] : 0.f;
+      o[i] = ok ? plane_index(row, k, R) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      if (o[i] < 0) continue;
+      const float a = relu ? fmaxf(v[i], 0.f) : v[i];
+      split_hi_lo(a, hi[o[i]], lo[o[i]]);
+    }
   }
 }
 
@@ -58,7 +69,8 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
                                hipStream_t s, int relu) {
   if (rows <= 0) return hipSuccess;
   const long units = ((rows + 1) / 2) * (Kp / kPlaneK);
-  const int blocks = (int)((units + 3) / 4 < 16384 ? (units + 3) / 4 : 16384);
+  const long want = (units + 15) / 16;                      // 4 waves x 4 units per block and trip
+  const int blocks = (int)(want < 16384 ? want : 16384);
   hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
                      (_Float16*)lo, relu);
   return hipGetLastError();
