@@ -93,7 +93,13 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
         el = time.perf_counter() - t0
         if el > budget_s:
             break
+    torch.set_num_threads(1)                              # also the single-core rate
+    t1 = time.perf_counter()
+    O.tepose_fwd(state, smpl_np, x[:32], L, J_regressor=J, nn_gru=True)
+    single = 32 / (time.perf_counter() - t1)
+    torch.set_num_threads(cores)
     res = {'value': n / el, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
+           'single_thread_value': single, 'host_cpus': all_cores,
            'sample': '%d windows of [%d,2133] in batches of %d, torch %s CPU, nn.GRU op sequence, %.1f s'
                      % (n, T, Bc, torch.__version__, el)}
     if gpu_models:
