@@ -21,6 +21,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tepose_amd import synth  # noqa: E402
 from tepose_amd.data import load_eval_db, load_generator_state_dict, split_db_into_clips, synthetic_eval_db  # noqa: E402
+from tepose_amd.distributed import imbalance, partition_clips  # noqa: E402
 from tepose_amd.evaluate import evaluate_clips, gather_and_reduce  # noqa: E402
 from tepose_amd.smpl import SMPL  # noqa: E402
 from tepose_amd.testing import build_model  # noqa: E402
@@ -80,7 +81,9 @@ def main():
     res = gather_and_reduce(recs)
     if rank == 0:
         frames = int(sum(len(c['features']) for c in clips.values()))
+        lens = [len(c['features']) for c in clips.values()]
         out = {'clips': len(clips), 'frames': frames, 'seqlen': T, 'n_gpus': world, 'seconds': float(el.item()),
+               'imbalance_max_over_mean_rank_frames': imbalance(lens, partition_clips(lens, world)),
                'frames_per_s': frames / float(el.item()), 'metrics_mm': res,
                'data': 'real' if args.db else 'synthetic db + random-init weights (metric values are meaningless)'}
         print(json.dumps(out))
