@@ -20,6 +20,9 @@
 
 namespace tepose {
 
+#ifndef TEPOSE_GRU_PF
+#define TEPOSE_GRU_PF 1    // 0: fetch the GRU cell operands in the epilogue instead of during the last K-tiles (A/B)
+#endif
 #ifndef TEPOSE_H3_ABL
 #define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads
 #endif
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
 #endif
       }
       if constexpr (GRU && !STEADY) {
-        if (kt == (KT >= 2 ? KT - 2 : 0)) {     // youngest memory operations from here on: no DMA follows
+        if (TEPOSE_GRU_PF && kt == (KT >= 2 ? KT - 2 : 0)) {     // youngest memory operations from here on: no DMA follows
           const GateDir& d = batch.gate[blockIdx.y];
           const int Hp = batch.Hp;
           pf_b[0] = d.bhh[gj]; pf_b[1] = d.bhh[Hp + gj]; pf_b[2] = d.bhh[2 * Hp + gj];
@@ -394,6 +397,17 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
     static_assert(!GRU || WMF == 1, "GRU epilogue prefetch holds one 32-row fragment of cell operands");
     const GateDir& d = batch.gate[blockIdx.y];
     const int rbase = m0 + wm * 32 + 4 * h;
+    if (!TEPOSE_GRU_PF) {
+      const int Hp = batch.Hp;
+      pf_b[0] = d.bhh[gj]; pf_b[1] = d.bhh[Hp + gj]; pf_b[2] = d.bhh[2 * Hp + gj];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = min(rbase + (e & 3) + 8 * (e >> 2), a.M - 1);
+        const float* gi = d.gi + (long)row * d.ldgi + gj;
+        pf_gr[e] = gi[0]; pf_gz[e] = gi[Hp]; pf_gn[e] = gi[2 * Hp];
+        pf_hp[e] = d.hprev[(long)row * d.ldh + gj];
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = rbase + (e & 3) + 8 * (e >> 2);
