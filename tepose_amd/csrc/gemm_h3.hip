@@ -24,7 +24,7 @@ namespace tepose {
 #define TEPOSE_GRU_PF 1    // 0: fetch the GRU cell operands in the epilogue instead of during the last K-tiles (A/B)
 #endif
 #ifndef TEPOSE_H3_ABL
-#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads
+#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads, 8 no GRU epilogue stores
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -418,6 +418,9 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
       const float zg = g_sigmoid(pf_gz[e] + (hz + pf_b[1]));
       const float ng = g_tanh(pf_gn[e] + rg * (hn + pf_b[2]));
       const float hv = (1.f - zg) * ng + zg * pf_hp[e];
+#if TEPOSE_H3_ABL & 8
+      if (hv == 12345.678f)
+#endif
       if (row < a.M) {
         d.hout[(long)row * d.ldo + gj] = hv;
         const long o = (long)(gj >> 5) * d.okst + plane_index(row, r, 0);
