@@ -24,7 +24,7 @@ namespace tepose {
 #define TEPOSE_GRU_PF 1    // 0: fetch the GRU cell operands in the epilogue instead of during the last K-tiles (A/B)
 #endif
 #ifndef TEPOSE_H3_ABL
-#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads, 8 no GRU epilogue stores
+#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads, 8 no GRU epilogue stores, 16 no plain epilogue stores
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -439,6 +439,9 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#if TEPOSE_H3_ABL & 16
+          if (acc[i][j][e] == 12345.678f)
+#endif
           if (row < a.M) {
             float v = (acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale)) + bv;
             if (a.addend) v += a.addend[(long)row * a.ldadd + col];
