@@ -28,6 +28,8 @@ namespace tepose {
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4v __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 
 __device__ __forceinline__ void glds16b(const void* g, void* l) {
@@ -428,29 +430,68 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
       }
     }
   } else {
+    // Plain epilogue.  The accumulator layout gives a lane one column and 16 rows, i.e. 4-byte stores; the tile is
+    // turned through the (now idle) LDS ring instead so that a lane owns 4 consecutive columns and the C / plane
+    // stores are 16 / 8 bytes wide: a quarter of the store instructions, and the wave's implicit wait for its
+    // stores at s_endpgm (nothing else can run on the CU meanwhile: one workgroup fills the LDS) shrinks with them.
+    constexpr int TR = 32 * WMF, TC = 32 * WNT;            // this wave's sub-tile
+    static_assert(NW * TR * TC * 4 <= NST * STAGE, "epilogue staging fits the ring");
+    const float sc = a.scale != 0.f ? a.scale : 1.f;
+    __syncthreads();                                       // every wave is done with the last stage
+    float* tile = (float*)lds + wave * TR * TC;
 #pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-      const int col = n0 + wn * 32 * WNT + j * 32 + r;
-      if (col >= a.N) continue;
-      const float bv = a.bias ? a.bias[col] : 0.f;
-      const float sc = a.scale != 0.f ? a.scale : 1.f;
+    for (int i = 0; i < WMF; ++i)
 #pragma unroll
-      for (int i = 0; i < WMF; ++i) {
+      for (int j = 0; j < WNT; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        for (int e = 0; e < 16; ++e)
+          tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TC + j * 32 + r] =
+              acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale);
+    const bool vec = (((size_t)a.C | (size_t)(a.addend ? a.addend : a.C)) & 15) == 0 && (a.ldc & 3) == 0 &&
+                     (!a.addend || (a.ldadd & 3) == 0);
+    constexpr int C4 = TC / 4;                             // float4 groups per sub-tile row
+#pragma unroll
+    for (int t = 0; t < TR * C4 / 64; ++t) {
+      const int idx = t * 64 + lane, rl = idx / C4, c4 = idx % C4;
+      const int row = m0 + wm * TR + rl, col = n0 + wn * TC + c4 * 4;
 #if TEPOSE_H3_ABL & 16
-          if (acc[i][j][e] == 12345.678f)
+      if (acc[0][0][0] == 12345.678f)
 #endif
-          if (row < a.M) {
-            float v = (acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale)) + bv;
-            if (a.addend) v += a.addend[(long)row * a.ldadd + col];
-            v *= sc;
-            a.C[(long)row * a.ldc + col] = v;
-            if (a.Chi) {
-              const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
-              split_hi_lo(v, a.Chi[o], a.Clo[o]);
+      if (row < a.M && col < a.N) {
+        f32x4v v = *(const f32x4v*)(tile + rl * TC + c4 * 4);
+        const int nv = min(4, a.N - col);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (a.bias && c < nv) v[c] += a.bias[col + c];
+        float* cp = a.C + (long)row * a.ldc + col;
+        if (vec && nv == 4) {
+          if (a.addend) {
+            const f32x4v ad = *(const f32x4v*)(a.addend + (long)row * a.ldadd + col);
+            v += ad;
+          }
+          v *= sc;
+          *(f32x4v*)cp = v;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < nv) {
+              if (a.addend) v[c] += a.addend[(long)row * a.ldadd + col + c];
+              v[c] *= sc;
+              cp[c] = v[c];
             }
+        }
+        if (a.Chi) {                                       // 4 consecutive columns share an 8-column slot of the plane
+          const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
+          half_t hh[4], ll[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) split_hi_lo(c < nv ? v[c] : 0.f, hh[c], ll[c]);
+          if (nv == 4) {
+            *(h16x4v*)(a.Chi + o) = h16x4v{hh[0], hh[1], hh[2], hh[3]};
+            *(h16x4v*)(a.Clo + o) = h16x4v{ll[0], ll[1], ll[2], ll[3]};
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < nv) { a.Chi[o + c] = hh[c]; a.Clo[o + c] = ll[c]; }
           }
         }
       }
