@@ -470,11 +470,7 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
             v += ad;
           }
           v *= sc;
-#ifdef TEPOSE_NT_STORES
-          __builtin_nontemporal_store(v, (f32x4v*)cp);
-#else
           *(f32x4v*)cp = v;
-#endif
         } else {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
