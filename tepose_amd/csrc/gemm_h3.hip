@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
     // GRU: the cell operands of this wave's 32 rows x 32 hidden units (gate pre-activations, previous state,
     // b_hh) are fetched two K-tiles before the end of the loop, so that their HBM latency hides under MFMAs
     // instead of standing between the last product and the cell update.
-    const int pf_kt = KT >= 2 ? KT - 2 : 0;
+    const int pf_kt = KT >= NST - 1 ? KT - (NST - 1) : 0;      // first K-tile of the tail (no DMA issued after it)
     // One K-tile.  DMA = std::true_type in the steady state (the stage NST-1 ahead exists: its DMA instructions
     // are issued unconditionally, one per MFMA triple, and exactly NST-2 newer stages may stay in flight at the
     // wait), std::false_type in the last NST-1 K-tiles.  Two instantiations instead of a per-instruction
@@ -382,12 +382,12 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bh[j], acc[i][j], 0, 0, 0);
             accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].ah[i], f[ks].bl[j], accx[i][j], 0, 0, 0);
             accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks].al[i], f[ks].bh[j], accx[i][j], 0, 0, 0);
-            if (q < NDMA) {
+            constexpr int NT = KS * WMF * WNT;       // MFMA triples per K-tile; DMA instructions spread over them
+            const int t = (ks * WMF + i) * WNT + j;
+#pragma unroll
+            for (; q < (t + 1) * NDMA / NT; ++q)
               if constexpr (DMA) dma_part(kt + NST - 1, q);
-              ++q;
-            }
           }
-      static_assert(NDMA <= KS * WMF * WNT, "one DMA per MFMA triple");
     };
     int kt = 0;
     for (; kt + NST - 1 < KT; ++kt) ktile(kt, std::true_type{});
