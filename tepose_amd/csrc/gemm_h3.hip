@@ -24,7 +24,7 @@ namespace tepose {
 #define TEPOSE_GRU_PF 1    // 0: fetch the GRU cell operands in the epilogue instead of during the last K-tiles (A/B)
 #endif
 #ifndef TEPOSE_H3_ABL
-#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads, 8 no GRU epilogue stores, 16 no plain epilogue stores
+#define TEPOSE_H3_ABL 0   // timing-only diagnostic builds, bit mask: 1 no DMA in the loop, 2 no barrier, 4 no fragment reads, 8 no GRU epilogue stores, 16 no plain epilogue stores, 32 every stage re-reads K-tile 0 (L2 hits)
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -175,6 +175,9 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
     // wave-uniform (an instruction's 16 rows belong to one plane): keep the stride in scalar registers
     kst[q] = ((long)__builtin_amdgcn_readfirstlane((int)(kst[q] >> 32)) << 32) |
              (unsigned)__builtin_amdgcn_readfirstlane((int)kst[q]);
+#if TEPOSE_H3_ABL & 32
+    kst[q] = 0;
+#endif
   }
   // every DMA instruction q is issued once per stage, in stage order: gsrc[q] walks along K by itself
   auto dma_part = [&](int stage, int q) {
