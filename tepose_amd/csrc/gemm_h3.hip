@@ -437,64 +437,69 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
     // turned through the (now idle) LDS ring instead so that a lane owns 4 consecutive columns and the C / plane
     // stores are 16 / 8 bytes wide: a quarter of the store instructions, and the wave's implicit wait for its
     // stores at s_endpgm (nothing else can run on the CU meanwhile: one workgroup fills the LDS) shrinks with them.
-    constexpr int TR = 32 * WMF, TC = 32 * WNT;            // this wave's sub-tile
-    static_assert(NW * TR * TC * 4 <= NST * STAGE, "epilogue staging fits the ring");
+    constexpr int TC = 32 * WNT;                           // this wave's sub-tile: 32*WMF rows x TC columns,
+    constexpr int EP = (NW * 32 * WMF * TC * 4 + NST * STAGE - 1) / (NST * STAGE);   // staged in EP passes of
+    constexpr int FP = WMF / EP, TR = 32 * FP;             // FP 32-row fragments each
+    static_assert(WMF % EP == 0 && NW * TR * TC * 4 <= NST * STAGE, "epilogue staging fits the ring");
     const float sc = a.scale != 0.f ? a.scale : 1.f;
     __syncthreads();                                       // every wave is done with the last stage
     float* tile = (float*)lds + wave * TR * TC;
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-#pragma unroll
-      for (int j = 0; j < WNT; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TC + j * 32 + r] =
-              acc[i][j][e] + accx[i][j][e] * (1.f / kLoScale);
     const bool vec = (((size_t)a.C | (size_t)(a.addend ? a.addend : a.C)) & 15) == 0 && (a.ldc & 3) == 0 &&
                      (!a.addend || (a.ldadd & 3) == 0);
     constexpr int C4 = TC / 4;                             // float4 groups per sub-tile row
 #pragma unroll
-    for (int t = 0; t < TR * C4 / 64; ++t) {
-      const int idx = t * 64 + lane, rl = idx / C4, c4 = idx % C4;
-      const int row = m0 + wm * TR + rl, col = n0 + wn * TC + c4 * 4;
-#if TEPOSE_H3_ABL & 16
-      if (acc[0][0][0] == 12345.678f)
-#endif
-      if (row < a.M && col < a.N) {
-        f32x4v v = *(const f32x4v*)(tile + rl * TC + c4 * 4);
-        const int nv = min(4, a.N - col);
+    for (int pass = 0; pass < EP; ++pass) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (a.bias && c < nv) v[c] += a.bias[col + c];
-        float* cp = a.C + (long)row * a.ldc + col;
-        if (vec && nv == 4) {
-          if (a.addend) {
-            const f32x4v ad = *(const f32x4v*)(a.addend + (long)row * a.ldadd + col);
-            v += ad;
-          }
-          v *= sc;
-          *(f32x4v*)cp = v;
-        } else {
+      for (int i = 0; i < FP; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TC + j * 32 + r] =
+                acc[pass * FP + i][j][e] + accx[pass * FP + i][j][e] * (1.f / kLoScale);
+#pragma unroll
+      for (int t = 0; t < TR * C4 / 64; ++t) {
+        const int idx = t * 64 + lane, rl = idx / C4, c4 = idx % C4;
+        const int row = m0 + wm * 32 * WMF + pass * TR + rl, col = n0 + wn * TC + c4 * 4;
+#if TEPOSE_H3_ABL & 16
+        if (acc[0][0][0] == 12345.678f)
+#endif
+        if (row < a.M && col < a.N) {
+          f32x4v v = *(const f32x4v*)(tile + rl * TC + c4 * 4);
+          const int nv = min(4, a.N - col);
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            if (c < nv) {
-              if (a.addend) v[c] += a.addend[(long)row * a.ldadd + col + c];
-              v[c] *= sc;
-              cp[c] = v[c];
+            if (a.bias && c < nv) v[c] += a.bias[col + c];
+          float* cp = a.C + (long)row * a.ldc + col;
+          if (vec && nv == 4) {
+            if (a.addend) {
+              const f32x4v ad = *(const f32x4v*)(a.addend + (long)row * a.ldadd + col);
+              v += ad;
             }
-        }
-        if (a.Chi) {                                       // 4 consecutive columns share an 8-column slot of the plane
-          const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
-          half_t hh[4], ll[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) split_hi_lo(c < nv ? v[c] : 0.f, hh[c], ll[c]);
-          if (nv == 4) {
-            *(h16x4v*)(a.Chi + o) = h16x4v{hh[0], hh[1], hh[2], hh[3]};
-            *(h16x4v*)(a.Clo + o) = h16x4v{ll[0], ll[1], ll[2], ll[3]};
+            v *= sc;
+            *(f32x4v*)cp = v;
           } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              if (c < nv) { a.Chi[o + c] = hh[c]; a.Clo[o + c] = ll[c]; }
+              if (c < nv) {
+                if (a.addend) v[c] += a.addend[(long)row * a.ldadd + col + c];
+                v[c] *= sc;
+                cp[c] = v[c];
+              }
+          }
+          if (a.Chi) {                                     // 4 consecutive columns share an 8-column slot of the plane
+            const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
+            half_t hh[4], ll[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) split_hi_lo(c < nv ? v[c] : 0.f, hh[c], ll[c]);
+            if (nv == 4) {
+              *(h16x4v*)(a.Chi + o) = h16x4v{hh[0], hh[1], hh[2], hh[3]};
+              *(h16x4v*)(a.Clo + o) = h16x4v{ll[0], ll[1], ll[2], ll[3]};
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (c < nv) { a.Chi[o + c] = hh[c]; a.Clo[o + c] = ll[c]; }
+            }
           }
         }
       }
