@@ -43,11 +43,11 @@ struct tepose_model {
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
   // regressor offsets
   size_t w1a = 0, b1 = 0, w1b = 0, w2 = 0, b2 = 0, wdec = 0, bdec = 0, init = 0;
-  size_t w1a_p = 0, w1b_p = 0, w2_p = 0, wdec_p = 0, blendW_p = 0;   // blocked hi|lo planes (split path, N > 768)
+  size_t w1a_p = 0, w1b_p = 0, w2_p = 0, wdec_p = 0, blendW_p = 0;   // blocked hi|lo planes (split path)
   SmplOff smpl{};
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
-  bool split = true;                            // large batches run their GRU matmuls on the fp16x3 split kernel
+  bool split = true;                            // batches of more than split_min_m() rows run their matmuls on the fp16x3 split kernels
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
   std::vector<hipEvent_t> ev;

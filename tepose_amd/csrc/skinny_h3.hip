@@ -1,6 +1,6 @@
 // Small-M GRU step and GEMM on the split-precision operands (fp16 hi / lo planes, three fp16 MFMAs per product, fp32
-// accumulation; gemm_h3.hip explains the arithmetic): the 33 < B <= a few hundred regime of a split-mode handle
-// (real-data evaluation with tens to hundreds of concurrent clips).
+// accumulation; gemm_h3.hip explains the arithmetic): the 4 < B <= a few hundred regime of a split-mode handle
+// (real-data evaluation with tens to hundreds of concurrent clips; the GEMM variant serves every product of <= 768 rows).
 //
 // At these batch sizes a GRU step is a weight-streaming problem (37.7 MB of W_hh planes per 3-direction step at
 // H = 1024), the fp32 skinny kernel of skinny.hip is bound by the slow fp32 MFMA once M > 16, and the 64/128-row
