@@ -413,6 +413,8 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
         pf_hp[e] = d.hprev[(long)row * d.ldh + gj];
       }
     }
+    __syncthreads();                                       // every wave is done with the last stage: LDS is free
+    float* gtile = (float*)lds + wave * 32 * 32;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = rbase + (e & 3) + 8 * (e >> 2);
@@ -423,13 +425,35 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
       const float zg = g_sigmoid(pf_gz[e] + (hz + pf_b[1]));
       const float ng = g_tanh(pf_gn[e] + rg * (hn + pf_b[2]));
       const float hv = (1.f - zg) * ng + zg * pf_hp[e];
+      gtile[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = hv;
+      (void)row;
+    }
+    // the wave's 32 x 32 block of new states, turned through LDS so that a lane stores 4 consecutive hidden
+    // units: 16-byte fp32 stores and 8-byte plane stores instead of 4- and 2-byte ones (12 store instructions per
+    // wave instead of 48; see the plain epilogue below)
+    const bool vec = ((size_t)d.hout & 15) == 0 && (d.ldo & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * 64 + lane, rl = idx >> 3, c4 = idx & 7;
+      const int row = m0 + wm * 32 + rl, j = (gj & ~31) + c4 * 4;
 #if TEPOSE_H3_ABL & 8
-      if (hv == 12345.678f)
+      if (acc[0][0][0] == 12345.678f)
 #endif
       if (row < a.M) {
-        d.hout[(long)row * d.ldo + gj] = hv;
-        const long o = (long)(gj >> 5) * d.okst + plane_index(row, r, 0);
-        split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
+        const f32x4v v = *(const f32x4v*)(gtile + rl * 32 + c4 * 4);
+        float* hp = d.hout + (long)row * d.ldo + j;
+        if (vec) {
+          *(f32x4v*)hp = v;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) hp[c] = v[c];
+        }
+        const long o = (long)(j >> 5) * d.okst + plane_index(row, j & 31, 0);
+        half_t hh[4], ll[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_hi_lo(v[c], hh[c], ll[c]);
+        *(h16x4v*)(d.hout_hi + o) = h16x4v{hh[0], hh[1], hh[2], hh[3]};
+        *(h16x4v*)(d.hout_lo + o) = h16x4v{ll[0], ll[1], ll[2], ll[3]};
       }
     }
   } else {
