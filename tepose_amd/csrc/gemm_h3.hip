@@ -37,35 +37,42 @@ __device__ __forceinline__ void glds16b(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// fp32 [rows][ld] -> blocked hi / lo fp16 planes of [R x Kp] (columns >= K zero).  A wave converts two rows of
-// one K-tile: it reads two 128-byte runs and writes one whole 128-byte line per plane; consecutive waves take
-// consecutive K-tiles of the same row pair, so a block's reads stay contiguous.
+// fp32 [rows][ld] -> blocked hi / lo fp16 planes of [R x Kp] (columns >= K zero).  A wave converts four rows of
+// one K-tile per unit, a lane two consecutive k of one row: it reads 2 floats and writes one 4-byte pair per plane
+// (2-byte stores cost as much per instruction and move half as much); consecutive waves take consecutive K-tiles of
+// the same rows, so a block's reads stay contiguous.
 __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ src, long ld, long rows, int K,
                                                            int Kp, long R, _Float16* __restrict__ hi,
                                                            _Float16* __restrict__ lo, int relu) {
+  typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   const int KT = Kp / kPlaneK;
-  const long units = ((rows + 1) / 2) * KT;                 // (row pair, K-tile)
+  const long units = ((rows + 3) / 4) * KT;                 // (4-row group, K-tile)
   const int lane = threadIdx.x & 63;
-  constexpr int U = 4;                                      // units per wave and trip: U independent loads in flight
+  constexpr int U = 4;                                      // units per wave and trip: 2U independent loads in flight
   for (long u0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * U; u0 < units; u0 += (long)gridDim.x * 4 * U) {
-    float v[U];
+    float v0[U], v1[U];
     long o[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const long u = u0 + i;
-      const long pair = u / KT;
-      const int kt = (int)(u - pair * KT);
-      const long row = 2 * pair + (lane >> 5);
-      const int k = kt * kPlaneK + (lane & 31);
+      const long grp = u / KT;
+      const int kt = (int)(u - grp * KT);
+      const long row = 4 * grp + (lane >> 4);
+      const int k = kt * kPlaneK + 2 * (lane & 15);
       const bool ok = u < units && row < rows;
-      v[i] = (ok && k < K) ? src[row * ld + k] : 0.f;
+      v0[i] = (ok && k < K) ? src[row * ld + k] : 0.f;
+      v1[i] = (ok && k + 1 < K) ? src[row * ld + k + 1] : 0.f;
       o[i] = ok ? plane_index(row, k, R) : -1;
     }
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       if (o[i] < 0) continue;
-      const float a = relu ? fmaxf(v[i], 0.f) : v[i];
-      split_hi_lo(a, hi[o[i]], lo[o[i]]);
+      const float a0 = relu ? fmaxf(v0[i], 0.f) : v0[i], a1 = relu ? fmaxf(v1[i], 0.f) : v1[i];
+      half_t h0, l0, h1, l1;
+      split_hi_lo(a0, h0, l0);
+      split_hi_lo(a1, h1, l1);
+      *(h16x2v*)(hi + o[i]) = h16x2v{h0, h1};
+      *(h16x2v*)(lo + o[i]) = h16x2v{l0, l1};
     }
   }
 }
@@ -73,7 +80,7 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
 hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, long R, void* hi, void* lo,
                                hipStream_t s, int relu) {
   if (rows <= 0) return hipSuccess;
-  const long units = ((rows + 1) / 2) * (Kp / kPlaneK);
+  const long units = ((rows + 3) / 4) * (Kp / kPlaneK);
   const long want = (units + 15) / 16;                      // 4 waves x 4 units per block and trip
   const int blocks = (int)(want < 16384 ? want : 16384);
   hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
