@@ -592,24 +592,35 @@ hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s) {
 // First cell step of a direction: h_prev = 0, so h W_hh^T vanishes and the step is element-wise.  Writes the
 // new state as fp32 and as blocked hi / lo planes for the next step's product.
 __global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int Hp) {
+  typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   const GateDir& d = gb.d[blockIdx.y];
-  const long total = (long)M * Hp;
+  const int Hh = Hp / 2;                                     // a thread owns two consecutive hidden units
+  const long total = (long)M * Hh;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long row = idx / Hp;
-    const int j = (int)(idx - row * Hp);
+    const long row = idx / Hh;
+    const int j = 2 * (int)(idx - row * Hh);
     const float* gi = d.gi + row * d.ldgi + j;
-    const float rg = g_sigmoid(gi[0] + d.bhh[j]), zg = g_sigmoid(gi[Hp] + d.bhh[Hp + j]);
-    const float ng = g_tanh(gi[2 * Hp] + rg * d.bhh[2 * Hp + j]);
-    const float hv = (1.f - zg) * ng;
-    d.hout[row * d.ldo + j] = hv;
+    float hv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float rg = g_sigmoid(gi[c] + d.bhh[j + c]), zg = g_sigmoid(gi[Hp + c] + d.bhh[Hp + j + c]);
+      const float ng = g_tanh(gi[2 * Hp + c] + rg * d.bhh[2 * Hp + j + c]);
+      hv[c] = (1.f - zg) * ng;
+    }
+    d.hout[row * d.ldo + j] = hv[0];
+    d.hout[row * d.ldo + j + 1] = hv[1];
     const long o = (long)(j >> 5) * d.okst + plane_index(row, j & 31, 0);
-    split_hi_lo(hv, d.hout_hi[o], d.hout_lo[o]);
+    half_t h0, l0, h1, l1;
+    split_hi_lo(hv[0], h0, l0);
+    split_hi_lo(hv[1], h1, l1);
+    *(h16x2v*)(d.hout_hi + o) = h16x2v{h0, h1};
+    *(h16x2v*)(d.hout_lo + o) = h16x2v{l0, l1};
   }
 }
 
 hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s) {
   if (M <= 0 || ndir <= 0) return hipSuccess;
-  const long total = (long)M * Hp;
+  const long total = (long)M * Hp / 2;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(gru_first_kernel, dim3(blocks, ndir), dim3(256), 0, s, gb, M, Hp);
   return hipGetLastError();
