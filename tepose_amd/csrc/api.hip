@@ -1142,7 +1142,8 @@ int tepose_filter_slerp(const float* rotmat_in, float* rotmat_out, int N, int J,
 
 size_t tepose_gemm_h3_workspace_bytes(int M, int N, int K) {
   if (M < 1 || N < 1 || K < 1) return 0;
-  return gemm_h3_ws_bytes(M, N, K);
+  const size_t a = gemm_h3_ws_bytes(M, N, K), b = gemm_h3s_ws_bytes(M, N, K);
+  return a > b ? a : b;
 }
 
 int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc,
@@ -1150,6 +1151,14 @@ int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const
   if (!A || !W || !C || !workspace || M < 1 || N < 1 || K < 1) return TEPOSE_E_ARG;
   if (K % 32 != 0) return TEPOSE_E_SHAPE;
   if (ws_bytes < gemm_h3_ws_bytes(M, N, K)) return TEPOSE_E_WORKSPACE;
+  static const int proto = [] {
+    const char* e = getenv("TEPOSE_H3S");              // prototype kernel of gemm_h3s.hip (no bias; scales for the
+    return e ? atoi(e) : 0;                            // operand ranges of tools/h3_loop.py / h3_bench.py)
+  }();
+  if (proto && !bias && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
+    CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream));
+    return 0;
+  }
   CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream));
   return 0;
 }

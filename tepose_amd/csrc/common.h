@@ -189,5 +189,9 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);
+// gemm_h3s.hip (prototype: single accumulator, 256 x 256 tiles, scaled planes)
+size_t gemm_h3s_ws_bytes(int M, int N, int K);
+hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
+                               int K, float pA, float pW, void* ws, hipStream_t s);
 
 }  // namespace tepose

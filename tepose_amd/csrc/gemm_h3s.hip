@@ -1,0 +1,227 @@
+// PROTOTYPE (not on the product path; reached only through the test / bench entry tepose_gemm_h3_f32 with
+// TEPOSE_H3S=1): the split-precision GEMM with ONE accumulator per tile and a 256 x 256 block tile -- the round-2
+// candidate of DESIGN.md section 4b ("Known inefficiencies").
+//
+// Differences from gemm_h3.hip:
+//  * scaled planes: an operand matrix is stored as hi = fp16(v * p), lo = fp16(v * p - hi) with one power-of-two
+//    scale p per matrix (so that max |v * p| ~ 2^9..2^14 and the low halves stay normal fp16 numbers without the
+//    2^11 factor of gemm_h3.hip); hi*hi + hi*lo + lo*hi then share one fp32 accumulator, C = acc / (pA * pW);
+//  * that halves the accumulator registers, so a wave owns 64 x 128 (2 x 4 MFMA tiles, 128 VGPRs) and the block
+//    256 x 256: 33 % fewer LDS-DMA bytes and 25 % fewer fragment reads per MFMA;
+//  * K-tile 16 (32-byte plane rows, [K/16][R][16] blocked, slot swizzle (row >> 3) & 1), 32 KB stages, 4-slot ring
+//    (3 stages in flight): 24 MFMAs per wave and barrier, as in gemm_h3.hip.
+#include <type_traits>
+
+#include "common.h"
+
+namespace tepose {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16s(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vms() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// element (row, k) of an [R x Kp] matrix, Kp multiple of 16
+__host__ __device__ inline long plane16_index(long row, long k, long R) {
+  return ((k >> 4) * R + row) * 16 + ((((k >> 3) & 1) ^ ((row >> 3) & 1)) << 3) + (k & 7);
+}
+
+__global__ void __launch_bounds__(256) split_planes16_kernel(const float* __restrict__ src, long ld, long rows, int K,
+                                                             int Kp, long R, float p, _Float16* __restrict__ hi,
+                                                             _Float16* __restrict__ lo) {
+  const long total = rows * Kp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long row = idx / Kp;
+    const int k = (int)(idx - row * Kp);
+    const float a = (k < K ? src[row * ld + k] : 0.f) * p;
+    const _Float16 h = (_Float16)a;
+    const long o = plane16_index(row, k, R);
+    hi[o] = h;
+    lo[o] = (_Float16)(a - (float)h);
+  }
+}
+
+struct H3SArgs {
+  const _Float16 *Ah, *Al; long a_kst;   // halfs between K-tiles (R * 16)
+  const _Float16 *Wh, *Wl; long w_kst;
+  int Kp;                                // multiple of 16
+  float* C; long ldc;
+  float inv_scale;                       // 1 / (pA * pW)
+  int M, N;
+};
+
+__device__ __forceinline__ void h3s_tile_of_block(int bid, int nwg, int tilesM, int tilesN, int& tm, int& tn) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  constexpr int GM = 4;
+  const int group = lin / (GM * tilesN), rem = lin - group * GM * tilesN;
+  const int gm = min(GM, tilesM - group * GM);
+  tm = group * GM + rem % gm;
+  tn = rem / gm;
+}
+
+__global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SArgs a, int tilesM, int tilesN) {
+  constexpr int WMF = 2, WNT = 4, NST = 4;
+  constexpr int HM = 256, HN = 256, HK = 16;
+  constexpr int RB = HK * 2;                             // 32 bytes per plane row of a stage
+  constexpr int RPI = 1024 / RB;                         // 32 rows per DMA instruction
+  constexpr int STAGE = (2 * HM + 2 * HN) * RB;          // 32 KB
+  constexpr int NDMA = STAGE / 1024 / 8;                 // 4 per wave
+  static_assert(NST * STAGE <= 160 * 1024, "ring fits the LDS");
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
+  int tm, tn;
+  h3s_tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
+  const int m0 = tm * HM, n0 = tn * HN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves: 64 rows x 128 columns each
+  const int r = lane & 31, h = lane >> 5;
+
+  const char* gsrc[NDMA];
+  long kst[NDMA];
+#pragma unroll
+  for (int q = 0; q < NDMA; ++q) {
+    const int i = wave * NDMA + q;
+    int ri = i * RPI + lane / 2;                         // row of the stage image [A_hi | A_lo | W_hi | W_lo]
+    const char* base;
+    long grow, ks;
+    if (ri < 2 * HM) {
+      const bool lo = ri >= HM;
+      base = (const char*)(lo ? a.Al : a.Ah);
+      grow = min(m0 + (lo ? ri - HM : ri), a.M - 1);
+      ks = a.a_kst * 2;
+    } else {
+      ri -= 2 * HM;
+      const bool lo = ri >= HN;
+      base = (const char*)(lo ? a.Wl : a.Wh);
+      grow = n0 + (lo ? ri - HN : ri);
+      ks = a.w_kst * 2;
+    }
+    gsrc[q] = base + grow * RB + 16 * (lane & 1);
+    kst[q] = ((long)__builtin_amdgcn_readfirstlane((int)(ks >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)ks);
+  }
+  auto dma_part = [&](int stage, int q) {
+    glds16s(gsrc[q], lds + (stage % NST) * STAGE + (wave * NDMA + q) * 1024);
+    gsrc[q] += kst[q];
+  };
+
+  // fragment byte offsets inside a stage: row * 32 + 16 * (h ^ swz(row)); tile rows are multiples of 32, so the
+  // swizzle bit is that of the lane's row
+  const int sx = 16 * (h ^ ((r >> 3) & 1));
+  int aoff[WMF], boff[WNT];
+#pragma unroll
+  for (int i = 0; i < WMF; ++i) aoff[i] = (wm * 64 + i * 32 + r) * RB + sx;
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) boff[j] = 2 * HM * RB + (wn * 128 + j * 32 + r) * RB + sx;
+  constexpr int A_LO = HM * RB, W_LO = HN * RB;
+
+  f32x16 acc[WMF][WNT];
+#pragma unroll
+  for (int i = 0; i < WMF; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int KT = a.Kp / HK;
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < KT) {
+#pragma unroll
+      for (int q = 0; q < NDMA; ++q) dma_part(p, q);
+    }
+  auto ktile = [&](int kt, auto dma) __attribute__((always_inline)) {
+    constexpr bool DMA = decltype(dma)::value;
+    if constexpr (DMA) {
+      wait_vms<(NST - 2) * NDMA>();
+    } else {
+      const int newer = min(NST - 2, KT - 1 - kt);
+      if (newer >= 2) wait_vms<2 * NDMA>();
+      else if (newer == 1) wait_vms<NDMA>();
+      else wait_vms<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* st = lds + (kt % NST) * STAGE;
+    h16x8 ah[WMF], al[WMF], bh[WNT], bl[WNT];
+#pragma unroll
+    for (int i = 0; i < WMF; ++i) {
+      ah[i] = *(const h16x8*)(st + aoff[i]);
+      al[i] = *(const h16x8*)(st + A_LO + aoff[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      bh[j] = *(const h16x8*)(st + boff[j]);
+      bl[j] = *(const h16x8*)(st + W_LO + boff[j]);
+    }
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        const int t = i * WNT + j;
+#pragma unroll
+        for (; q < (t + 1) * NDMA / (WMF * WNT); ++q)
+          if constexpr (DMA) dma_part(kt + NST - 1, q);
+      }
+    // the cross terms after all hi*hi products: consecutive MFMAs never share an accumulator
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+  int kt = 0;
+  for (; kt + NST - 1 < KT; ++kt) ktile(kt, std::true_type{});
+  for (; kt < KT; ++kt) ktile(kt, std::false_type{});
+  wait_vms<0>();
+
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const int col = n0 + wn * 128 + j * 32 + r;
+    if (col >= a.N) continue;
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < a.M) a.C[(long)row * a.ldc + col] = acc[i][j][e] * a.inv_scale;
+      }
+  }
+}
+
+size_t gemm_h3s_ws_bytes(int M, int N, int K) {
+  const size_t Kp = (size_t)round_up(K, 16);
+  return 2 * align_up((size_t)M * Kp * 2, 256) + 2 * align_up((size_t)round_up(N, 256) * Kp * 2, 256) + 256;
+}
+
+// fp32 A[M,K], W[N,K] (bias ignored) -> scaled planes in ws -> C; pA / pW: power-of-two operand scales
+hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
+                               int K, float pA, float pW, void* ws, hipStream_t s) {
+  const int Kp = round_up(K, 16), Np = round_up(N, 256);
+  char* p = (char*)ws;
+  _Float16* Ah = (_Float16*)p; p += align_up((size_t)M * Kp * 2, 256);
+  _Float16* Al = (_Float16*)p; p += align_up((size_t)M * Kp * 2, 256);
+  _Float16* Wh = (_Float16*)p; p += align_up((size_t)Np * Kp * 2, 256);
+  _Float16* Wl = (_Float16*)p;
+  hipError_t e = hipMemsetAsync(Wh, 0, 2 * align_up((size_t)Np * Kp * 2, 256), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(split_planes16_kernel, dim3(8192), dim3(256), 0, s, A, lda, (long)M, K, Kp, (long)M, pA, Ah, Al);
+  hipLaunchKernelGGL(split_planes16_kernel, dim3(2048), dim3(256), 0, s, W, ldw, (long)N, K, Kp, (long)Np, pW, Wh, Wl);
+  H3SArgs a{Ah, Al, (long)M * 16, Wh, Wl, (long)Np * 16, Kp, C, ldc, 1.f / (pA * pW), M, N};
+  const int tilesM = (M + 255) / 256, tilesN = (N + 255) / 256;
+  hipLaunchKernelGGL(gemm_h3s_kernel, dim3(tilesM * tilesN), dim3(512), 0, s, a, tilesM, tilesN);
+  return hipGetLastError();
+}
+
+}  // namespace tepose
