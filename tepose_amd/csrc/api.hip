@@ -38,6 +38,9 @@ struct tepose_model {
   // encoder offsets
   size_t wih0 = 0, bih0 = 0;                    // stacked [9Hp][2144]: fwd | rec_reverse | rec
   size_t wih0_p = 0;                            // its hi|lo planes
+  size_t wih0_s = 0, wih0_scale = 0;            // the same block as scaled [K/16][R][16] planes (gemm_h3s.hip) + its scale
+  float w0_scale = 1.f;                         // host copy of blob[wih0_scale]
+  bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
@@ -115,6 +118,8 @@ void layout(tepose_model* m) {
   m->blr = take(cur, kFeat);
   // split-precision copies (hi plane then lo plane, fp16): same float count as the fp32 matrix
   m->wih0_p = take(cur, (size_t)round_up(9 * (int)Hp, 128) * kInputP);
+  m->wih0_s = take(cur, (size_t)round_up(9 * (int)Hp, 256) * kInputP);
+  m->wih0_scale = take(cur, 16);
   for (size_t l = 0; l < L; ++l) {
     const size_t n128 = round_up(3 * (int)Hp, 128);
     if (l > 0) {
@@ -365,6 +370,8 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
   {
     const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
     m->split = !(e && atoi(e) != 0);
+    e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
+    m->g0_single_acc = !(e && atoi(e) == 0);
   }
   layout(m);
   *out = m;
@@ -406,6 +413,10 @@ int tepose_adopt_blob(tepose_model* m) {
   int max_nnz = kNJ;
   CK(hipMemcpy(&max_nnz, m->blob + m->smpl.lbs_nnz, sizeof(int), hipMemcpyDeviceToHost));   // set-up time only
   m->lbs_sparse = max_nnz <= 4 ? 1 : 0;
+  if (m->kind == 0) {
+    CK(hipMemcpy(&m->w0_scale, m->blob + m->wih0_scale, sizeof(float), hipMemcpyDeviceToHost));
+    if (!(m->w0_scale > 0.f)) m->w0_scale = 1.f;
+  }
   return 0;
 }
 
@@ -510,6 +521,28 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
                  lo + (size_t)d * 3 * Hp * 32, (long)rows0 * 32, ROW_GATES, COL_PLAIN, H, Hp};
       CK(launch_pack(a, s));
     }
+  }
+  {  // the same block as scaled planes for the single-accumulator kernel: one power-of-two scale for the matrix,
+     // chosen so that the largest weight lands in [2^13, 2^14) (pack time only: one device reduction + read-back)
+    const size_t rows256 = (size_t)round_up(9 * Hp, 256);
+    float* scale_dev = B + m->wih0_scale;
+    CK(launch_absmax(B + m->wih0, (size_t)9 * Hp * kInputP, scale_dev, s));
+    float wmax = 0.f;
+    CK(hipMemcpyAsync(&wmax, scale_dev, sizeof(float), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    float p = 1.f;
+    if (wmax > 0.f && wmax < 3e38f) {
+      int ex = 0;
+      (void)frexpf(wmax, &ex);              // wmax = f * 2^ex, f in [0.5, 1)
+      p = ldexpf(1.f, 14 - ex);             // wmax * p in [2^13, 2^14)
+    }
+    m->w0_scale = p;
+    CK(hipMemcpyAsync(scale_dev, &m->w0_scale, sizeof(float), hipMemcpyHostToDevice, s));
+    CK(launch_fill(B + m->wih0_s, rows256 * kInputP, 0.f, s));
+    half_t* shi = (half_t*)(B + m->wih0_s);
+    CK(launch_split_planes16(B + m->wih0, kInputP, 9 * Hp, kInputP, kInputP, (long)rows256, p, shi,
+                             shi + rows256 * kInputP, s));
+    CK(hipStreamSynchronize(s));            // m->w0_scale is read by the async copy above
   }
   for (int l = 0; l < L; ++l) {
     struct { DirW* d; const float *ih, *hh, *bih, *bhh; bool split; } dirs[3] = {
@@ -893,7 +926,11 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
   const size_t rows0 = (size_t)round_up(9 * Hp, 128);
   const half_t* w0h = (const half_t*)(Bl + m->wih0_p);
   const half_t* w0l = w0h + rows0 * kInputP;
-  if (h3) CK(launch_pad_input_planes(x, xh, xl, BT, s));
+  // large batches of an L >= 2 model: the single-accumulator kernel (its input planes carry scale 1: same fp16 range
+  // as the other layout; elements below 2^-3 keep an absolute error <= 2^-25 instead of a relative one)
+  const bool g0s = h3 && m->g0_single_acc && L >= 2 && BT >= 8192;
+  if (g0s) CK(launch_split_planes16(x, kInput, BT, kInput, kInputP, BT, 1.f, xh, xl, s));
+  else if (h3) CK(launch_pad_input_planes(x, xh, xl, BT, s));
   else CK(launch_pad_input(x, w.xp, BT, s));
   {
     tepose_model* mm = const_cast<tepose_model*>(m);
@@ -907,7 +944,13 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
       }
       CK(hipEventRecord(mm->ev[mm->ev_used], s));
     }
-    if (h3) {
+    if (h3 && g0s) {          // 256 x 256 tiles, one accumulator per tile, scaled planes (gemm_h3s.hip)
+      const size_t rows256 = (size_t)round_up(9 * Hp, 256);
+      const half_t* sh = (const half_t*)(Bl + m->wih0_s);
+      H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
+                Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0};
+      CK(launch_gemm_h3s(a, s));
+    } else if (h3) {
       H3Batch b{};
       b.p[0] = H3Args{xh, xl, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT,
                       ld0};

@@ -189,7 +189,20 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);
-// gemm_h3s.hip (prototype: single accumulator, 256 x 256 tiles, scaled planes)
+// gemm_h3s.hip: single accumulator, 256 x 256 tiles, scaled planes in the [K/16][R][16] layout
+struct H3SArgs {
+  const half_t *Ah, *Al; long a_kst;     // halfs between K-tiles (R * 16)
+  const half_t *Wh, *Wl; long w_kst;     // W rows padded to 256
+  int Kp;                                // multiple of 16
+  float* C; long ldc;
+  const float* bias;                     // [N] or nullptr
+  float inv_scale;                       // 1 / (pA * pW)
+  int M, N;
+};
+hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s);
+hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
+                                 void* lo, hipStream_t s);
+hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);
 size_t gemm_h3s_ws_bytes(int M, int N, int K);
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
                                int K, float pA, float pW, void* ws, hipStream_t s);

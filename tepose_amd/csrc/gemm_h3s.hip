@@ -1,6 +1,6 @@
-// PROTOTYPE (not on the product path; reached only through the test / bench entry tepose_gemm_h3_f32 with
-// TEPOSE_H3S=1): the split-precision GEMM with ONE accumulator per tile and a 256 x 256 block tile -- the round-2
-// candidate of DESIGN.md section 4b ("Known inefficiencies").
+// The split-precision GEMM with ONE accumulator per tile and a 256 x 256 block tile.  Used for the layer-0 input
+// projection of large batches (the one product whose operands -- input planes and the stacked layer-0 W_ih -- no
+// other kernel shares), and through the test / bench entry tepose_gemm_h3_f32 with TEPOSE_H3S=1.
 //
 // Differences from gemm_h3.hip:
 //  * scaled planes: an operand matrix is stored as hi = fp16(v * p), lo = fp16(v * p - hi) with one power-of-two
@@ -33,29 +33,70 @@ __host__ __device__ inline long plane16_index(long row, long k, long R) {
   return ((k >> 4) * R + row) * 16 + ((((k >> 3) & 1) ^ ((row >> 3) & 1)) << 3) + (k & 7);
 }
 
+// fp32 [rows][ld] (K valid columns) * p -> scaled planes of [R x Kp].  A wave converts 8 rows of one K-tile per unit
+// (a lane two consecutive k of one row): it writes 256 contiguous bytes per plane; consecutive waves take
+// consecutive K-tiles of the same rows, so a block's reads stay contiguous; 4 units in flight per wave.
 __global__ void __launch_bounds__(256) split_planes16_kernel(const float* __restrict__ src, long ld, long rows, int K,
                                                              int Kp, long R, float p, _Float16* __restrict__ hi,
                                                              _Float16* __restrict__ lo) {
-  const long total = rows * Kp;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long row = idx / Kp;
-    const int k = (int)(idx - row * Kp);
-    const float a = (k < K ? src[row * ld + k] : 0.f) * p;
-    const _Float16 h = (_Float16)a;
-    const long o = plane16_index(row, k, R);
-    hi[o] = h;
-    lo[o] = (_Float16)(a - (float)h);
+  typedef _Float16 h16x2s __attribute__((ext_vector_type(2)));
+  const int KT = Kp / 16;
+  const long units = ((rows + 7) / 8) * KT;
+  const int lane = threadIdx.x & 63;
+  constexpr int U = 4;
+  for (long u0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * U; u0 < units; u0 += (long)gridDim.x * 4 * U) {
+    float v0[U], v1[U];
+    long o[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const long u = u0 + i;
+      const long grp = u / KT;
+      const int kt = (int)(u - grp * KT);
+      const long row = 8 * grp + (lane >> 3);
+      const int k = kt * 16 + 2 * (lane & 7);
+      const bool ok = u < units && row < rows;
+      v0[i] = (ok && k < K) ? src[row * ld + k] : 0.f;
+      v1[i] = (ok && k + 1 < K) ? src[row * ld + k + 1] : 0.f;
+      o[i] = ok ? plane16_index(row, k, R) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      if (o[i] < 0) continue;
+      const float a0 = v0[i] * p, a1 = v1[i] * p;
+      const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+      *(h16x2s*)(hi + o[i]) = h16x2s{h0, h1};
+      *(h16x2s*)(lo + o[i]) = h16x2s{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)};
+    }
   }
 }
 
-struct H3SArgs {
-  const _Float16 *Ah, *Al; long a_kst;   // halfs between K-tiles (R * 16)
-  const _Float16 *Wh, *Wl; long w_kst;
-  int Kp;                                // multiple of 16
-  float* C; long ldc;
-  float inv_scale;                       // 1 / (pA * pW)
-  int M, N;
-};
+hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
+                                 void* lo, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  const long units = ((rows + 7) / 8) * (Kp / 16);
+  const long want = (units + 15) / 16;
+  const int blocks = (int)(want < 16384 ? want : 16384);
+  hipLaunchKernelGGL(split_planes16_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, K, Kp, R, p, (_Float16*)hi,
+                     (_Float16*)lo);
+  return hipGetLastError();
+}
+
+// max |v| of a buffer into *out (one float, zeroed by the caller): bit pattern of |v| as an unsigned atomic max
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ src, size_t n, unsigned* out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+  if (e != hipSuccess || n == 0) return e;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, n, (unsigned*)out);
+  return hipGetLastError();
+}
 
 __device__ __forceinline__ void h3s_tile_of_block(int bid, int nwg, int tilesM, int tilesN, int& tm, int& tn) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
@@ -190,14 +231,22 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SArgs a, int tilesM, in
   for (int j = 0; j < WNT; ++j) {
     const int col = n0 + wn * 128 + j * 32 + r;
     if (col >= a.N) continue;
+    const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < a.M) a.C[(long)row * a.ldc + col] = acc[i][j][e] * a.inv_scale;
+        if (row < a.M) a.C[(long)row * a.ldc + col] = acc[i][j][e] * a.inv_scale + bv;
       }
   }
+}
+
+hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
+  hipLaunchKernelGGL(gemm_h3s_kernel, dim3(tilesM * tilesN), dim3(512), 0, s, a, tilesM, tilesN);
+  return hipGetLastError();
 }
 
 size_t gemm_h3s_ws_bytes(int M, int N, int K) {
@@ -205,7 +254,7 @@ size_t gemm_h3s_ws_bytes(int M, int N, int K) {
   return 2 * align_up((size_t)M * Kp * 2, 256) + 2 * align_up((size_t)round_up(N, 256) * Kp * 2, 256) + 256;
 }
 
-// fp32 A[M,K], W[N,K] (bias ignored) -> scaled planes in ws -> C; pA / pW: power-of-two operand scales
+// test / bench entry: fp32 A[M,K], W[N,K] (no bias) -> scaled planes in ws -> C; pA / pW: power-of-two operand scales
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
                                int K, float pA, float pW, void* ws, hipStream_t s) {
   const int Kp = round_up(K, 16), Np = round_up(N, 256);
@@ -216,12 +265,10 @@ hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ld
   _Float16* Wl = (_Float16*)p;
   hipError_t e = hipMemsetAsync(Wh, 0, 2 * align_up((size_t)Np * Kp * 2, 256), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(split_planes16_kernel, dim3(8192), dim3(256), 0, s, A, lda, (long)M, K, Kp, (long)M, pA, Ah, Al);
-  hipLaunchKernelGGL(split_planes16_kernel, dim3(2048), dim3(256), 0, s, W, ldw, (long)N, K, Kp, (long)Np, pW, Wh, Wl);
-  H3SArgs a{Ah, Al, (long)M * 16, Wh, Wl, (long)Np * 16, Kp, C, ldc, 1.f / (pA * pW), M, N};
-  const int tilesM = (M + 255) / 256, tilesN = (N + 255) / 256;
-  hipLaunchKernelGGL(gemm_h3s_kernel, dim3(tilesM * tilesN), dim3(512), 0, s, a, tilesM, tilesN);
-  return hipGetLastError();
+  if ((e = launch_split_planes16(A, lda, M, K, Kp, M, pA, Ah, Al, s)) != hipSuccess) return e;
+  if ((e = launch_split_planes16(W, ldw, N, K, Kp, Np, pW, Wh, Wl, s)) != hipSuccess) return e;
+  H3SArgs a{Ah, Al, (long)M * 16, Wh, Wl, (long)Np * 16, Kp, C, ldc, nullptr, 1.f / (pA * pW), M, N};
+  return launch_gemm_h3s(a, s);
 }
 
 }  // namespace tepose
