@@ -253,7 +253,7 @@ def main():
                 peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                    'traffic': pmc_traffic(B, T, True),
-                                   'kernel': 'gemm_h3_kernel<2,2,3,false> (layer-0 input projection, M=%d N=9216 K=2133)'
+                                   'kernel': 'gemm_h3s_kernel (single-accumulator split GEMM, 256x256 tiles; layer-0 input projection, M=%d N=9216 K=2133)'
                                              % (B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n,
                                    'note': 'achieved = algorithmic fp32-equivalent FLOP/s; the kernel issues %d fp16 MFMAs '
