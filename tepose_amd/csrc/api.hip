@@ -18,6 +18,9 @@ struct DirW {                     // one GRU layer/direction inside the blob (fl
   size_t wih = 0, bih = 0;        // input projection (layer-0 ones live in the stacked block)
   size_t whh = 0, bhh = 0;
   size_t wih_p = 0, whh_p = 0;    // blocked hi|lo fp16 planes of the same matrices (whh: gate-tiled rows), float offsets
+  size_t wih_s = 0, whh_s = 0;    // the same as scaled [K/16][R][16] planes (gemm_h3s.hip; rows padded to 256 / 384)
+  size_t scales = 0;              // blob slot: [0] = W_ih scale, [1] = W_hh scale
+  float wih_scale = 1.f, whh_scale = 1.f;   // host copies
 };
 
 struct SmplOff {
@@ -41,6 +44,7 @@ struct tepose_model {
   size_t wih0_s = 0, wih0_scale = 0;            // the same block as scaled [K/16][R][16] planes (gemm_h3s.hip) + its scale
   float w0_scale = 1.f;                         // host copy of blob[wih0_scale]
   bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
+  bool gru_single_acc = false;                  // large batches: layer >= 1 projections and GRU steps on it too
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
@@ -128,6 +132,16 @@ void layout(tepose_model* m) {
       m->rec_r[l].wih_p = take(cur, n128 * 2 * Hp);
     }
     for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) d->whh_p = take(cur, n128 * Hp);
+    const size_t r256 = round_up(3 * (int)Hp, 256), r384 = round_up(3 * (int)Hp, 384);
+    if (l > 0) {
+      m->fwd[l].wih_s = take(cur, r256 * Hp);
+      m->rec_f[l].wih_s = take(cur, r256 * 2 * Hp);
+      m->rec_r[l].wih_s = take(cur, r256 * 2 * Hp);
+    }
+    for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) {
+      d->whh_s = take(cur, r384 * Hp);
+      d->scales = take(cur, 16);
+    }
   }
   m->wlf_p = take(cur, (size_t)kFeat * Hp);
   m->wlr_p = take(cur, (size_t)kFeat * 2 * Hp);
@@ -189,6 +203,31 @@ int planes_of(const float* packed, int Np, int Kp, float* dst_planes, hipStream_
   return (int)launch_split_planes(packed, Kp, Np, Kp, Kp, Np, hi, hi + (size_t)Np * Kp, s);
 }
 
+// scaled [K/16][R][16] planes (gemm_h3s.hip) of an already packed fp32 blob matrix [rows][Kp], R >= rows rows
+// allocated (zero beyond); one power-of-two scale for the matrix (largest |w| * p in [2^13, 2^14)), written to
+// *scale_dev and *scale_host.  Pack time only: one device reduction + read-back.
+int scaled_planes_of(const float* packed, int rows, int Kp, float* dst_planes, int R, float* scale_dev, float* scale_host,
+                     hipStream_t s) {
+  hipError_t e = launch_absmax(packed, (size_t)rows * Kp, scale_dev, s);
+  if (e != hipSuccess) return (int)e;
+  float wmax = 0.f;
+  if ((e = hipMemcpyAsync(&wmax, scale_dev, sizeof(float), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
+  float p = 1.f;
+  if (wmax > 0.f && wmax < 3e38f) {
+    int ex = 0;
+    (void)frexpf(wmax, &ex);              // wmax = f * 2^ex, f in [0.5, 1)
+    p = ldexpf(1.f, 14 - ex);             // wmax * p in [2^13, 2^14)
+  }
+  *scale_host = p;
+  if ((e = hipMemcpyAsync(scale_dev, scale_host, sizeof(float), hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+  if ((e = launch_fill(dst_planes, (size_t)R * Kp, 0.f, s)) != hipSuccess) return (int)e;
+  half_t* hi = (half_t*)dst_planes;
+  if ((e = launch_split_planes16(packed, Kp, rows, Kp, Kp, (long)R, p, hi, hi + (size_t)R * Kp, s)) != hipSuccess)
+    return (int)e;
+  return (int)hipStreamSynchronize(s);    // *scale_host is read by the async copy above
+}
+
 struct Carver {
   char* base; size_t cur = 0, cap;
   Carver(void* p, size_t c) : base((char*)p), cap(c) {}
@@ -236,6 +275,21 @@ struct EncWs {
         const size_t R = b.T * b.B;
         const size_t e = b.poff + (size_t)plane_index((long)(t * b.B), (long)(rem % b.C), (long)R);
         return View{state_hi + e, state_lo + e, (long)R * 32};
+      }
+    }
+    return View{nullptr, nullptr, 0};
+  }
+  // the same sub-matrix in the scaled [K/16][R][16] format of gemm_h3s.hip (the mirrors hold ONE of the two formats
+  // per forward: every kernel of a forward agrees on it)
+  View view16(const float* p) const {
+    for (int i = 0; i < nbufs; ++i) {
+      const Buf& b = bufs[i];
+      if (p >= b.base && p < b.base + b.T * b.B * b.C) {
+        const size_t off = (size_t)(p - b.base), t = off / (b.B * b.C), rem = off % (b.B * b.C);
+        if (rem / b.C != 0 || (rem % b.C) % 16 != 0) break;
+        const size_t R = b.T * b.B;
+        const size_t e = b.poff + (size_t)plane16_index((long)(t * b.B), (long)(rem % b.C), (long)R);
+        return View{state_hi + e, state_lo + e, (long)R * 16};
       }
     }
     return View{nullptr, nullptr, 0};
@@ -372,6 +426,8 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
     m->split = !(e && atoi(e) != 0);
     e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
     m->g0_single_acc = !(e && atoi(e) == 0);
+    e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 1: layer >= 1 projections and GRU steps of large batches too
+    m->gru_single_acc = e && atoi(e) != 0;
   }
   layout(m);
   *out = m;
@@ -416,6 +472,13 @@ int tepose_adopt_blob(tepose_model* m) {
   if (m->kind == 0) {
     CK(hipMemcpy(&m->w0_scale, m->blob + m->wih0_scale, sizeof(float), hipMemcpyDeviceToHost));
     if (!(m->w0_scale > 0.f)) m->w0_scale = 1.f;
+    for (int l = 0; l < m->L; ++l)
+      for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) {
+        float sc[2] = {1.f, 1.f};
+        CK(hipMemcpy(sc, m->blob + d->scales, sizeof(sc), hipMemcpyDeviceToHost));
+        d->wih_scale = sc[0] > 0.f ? sc[0] : 1.f;
+        d->whh_scale = sc[1] > 0.f ? sc[1] : 1.f;
+      }
   }
   return 0;
 }
@@ -522,28 +585,9 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
       CK(launch_pack(a, s));
     }
   }
-  {  // the same block as scaled planes for the single-accumulator kernel: one power-of-two scale for the matrix,
-     // chosen so that the largest weight lands in [2^13, 2^14) (pack time only: one device reduction + read-back)
-    const size_t rows256 = (size_t)round_up(9 * Hp, 256);
-    float* scale_dev = B + m->wih0_scale;
-    CK(launch_absmax(B + m->wih0, (size_t)9 * Hp * kInputP, scale_dev, s));
-    float wmax = 0.f;
-    CK(hipMemcpyAsync(&wmax, scale_dev, sizeof(float), hipMemcpyDeviceToHost, s));
-    CK(hipStreamSynchronize(s));
-    float p = 1.f;
-    if (wmax > 0.f && wmax < 3e38f) {
-      int ex = 0;
-      (void)frexpf(wmax, &ex);              // wmax = f * 2^ex, f in [0.5, 1)
-      p = ldexpf(1.f, 14 - ex);             // wmax * p in [2^13, 2^14)
-    }
-    m->w0_scale = p;
-    CK(hipMemcpyAsync(scale_dev, &m->w0_scale, sizeof(float), hipMemcpyHostToDevice, s));
-    CK(launch_fill(B + m->wih0_s, rows256 * kInputP, 0.f, s));
-    half_t* shi = (half_t*)(B + m->wih0_s);
-    CK(launch_split_planes16(B + m->wih0, kInputP, 9 * Hp, kInputP, kInputP, (long)rows256, p, shi,
-                             shi + rows256 * kInputP, s));
-    CK(hipStreamSynchronize(s));            // m->w0_scale is read by the async copy above
-  }
+  // the same block as scaled planes for the single-accumulator kernel (gemm_h3s.hip)
+  CK((hipError_t)scaled_planes_of(B + m->wih0, 9 * Hp, kInputP, B + m->wih0_s, round_up(9 * Hp, 256),
+                                  B + m->wih0_scale, &m->w0_scale, s));
   for (int l = 0; l < L; ++l) {
     struct { DirW* d; const float *ih, *hh, *bih, *bhh; bool split; } dirs[3] = {
         {&m->fwd[l], fwd_w(l, 0), fwd_w(l, 1), fwd_w(l, 2), fwd_w(l, 3), false},
@@ -561,6 +605,14 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
       CK((hipError_t)pack_planes(d.hh, H, 3 * H, H, B + d.d->whh_p, n128, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.hh, H, 3 * H, H, B + d.d->whh, 3 * Hp, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
       CK((hipError_t)pack(d.bhh, 1, 3 * H, 1, B + d.d->bhh, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+      // scaled planes of the packed fp32 matrices (W_ih: natural gate order; W_hh: gate-tiled rows)
+      if (l > 0) {
+        const int Kp = d.split ? 2 * Hp : Hp;
+        CK((hipError_t)scaled_planes_of(B + d.d->wih, 3 * Hp, Kp, B + d.d->wih_s, round_up(3 * Hp, 256),
+                                        B + d.d->scales, &d.d->wih_scale, s));
+      }
+      CK((hipError_t)scaled_planes_of(B + d.d->whh, 3 * Hp, Hp, B + d.d->whh_s, round_up(3 * Hp, 384),
+                                      B + d.d->scales + 1, &d.d->whh_scale, s));
     }
   }
   const float* const* t = w + 12 * L;
@@ -720,12 +772,25 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const int H3 = 3 * Hp;
   const bool h3 = m->split && B > split_min_m();
   const long Bs = (long)w.Bs;          // rows per time slab of the layer >= 1 buffers
+  // large batches: recurrent-state planes in the scaled format, layer >= 1 projections and GRU steps on the
+  // single-accumulator kernels (gemm_h3s.hip)
+  const bool sf = h3 && m->gru_single_acc && B >= 1024;
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
-  auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t bias, float* out, int M) -> int {
+  auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t w_s, float w_scale, size_t bias,
+                  float* out, int M) -> int {
     if (!h3) {
       GemmArgs g = gemm(in, K, Bl + w_f32, K, out, H3, Bl + bias, M, H3);
       return (int)launch_gemm(g, s);
+    }
+    if (sf) {
+      const EncWs::View v = w.view16(in);
+      if (!v.hi) return (int)hipErrorInvalidValue;
+      const size_t r256 = (size_t)round_up(H3, 256);
+      const half_t* sh = (const half_t*)(Bl + w_s);
+      H3SArgs a{v.hi, v.lo, v.kst, sh, sh + r256 * K, (long)r256 * 16, K, out, (long)H3, Bl + bias,
+                1.f / (kStateScale * w_scale), M, H3};
+      return (int)launch_gemm_h3s(a, s);
     }
     const EncWs::View v = w.view(in);
     if (!v.hi) return (int)hipErrorInvalidValue;
@@ -734,8 +799,31 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   };
   // one GRU step of up to 3 directions: fused fp32 kernel; or the split product with the cell update in its
   // epilogue (first step: h = 0, element-wise kernel)
-  auto step = [&](const GruArgs& a, const size_t (&whh_planes)[3]) -> int {
+  auto step = [&](const GruArgs& a, const size_t (&whh_planes)[3], const DirW* const (&dw)[3]) -> int {
     if (!h3) return (int)launch_gru_step(a, s);
+    if (sf) {
+      H3SBatch b{};
+      GateBatch gb{};
+      const size_t r384 = (size_t)round_up(H3, 384);
+      for (int d = 0; d < a.ndir; ++d) {
+        const EncWs::View vo = w.view16(a.d[d].hout);
+        if (!vo.hi) return (int)hipErrorInvalidValue;
+        const GateDir g{a.d[d].gi, a.d[d].ldgi, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh, a.d[d].hout, a.d[d].ldo,
+                        vo.hi, vo.lo, vo.kst};
+        b.gate[d] = g;
+        gb.d[d] = g;
+        if (!a.first) {
+          const EncWs::View vi = w.view16(a.d[d].hprev);
+          if (!vi.hi) return (int)hipErrorInvalidValue;
+          const half_t* sh = (const half_t*)(Bl + dw[d]->whh_s);
+          b.p[d] = H3SArgs{vi.hi, vi.lo, vi.kst, sh, sh + r384 * Hp, (long)r384 * 16, Hp, nullptr, 0, nullptr,
+                           1.f / (kStateScale * dw[d]->whh_scale), B, H3};
+        }
+      }
+      if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s, 1);
+      b.n = a.ndir; b.Hp = Hp; b.state_scale = kStateScale;
+      return (int)launch_gru_h3s(b, s);
+    }
     H3Batch b{};
     GateBatch gb{};
     for (int d = 0; d < a.ndir; ++d) {
@@ -775,9 +863,12 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       const float* inf = w.sf[(l - 1) & 1];
       const float* inr = w.sr[(l - 1) & 1];
       const int MT = (int)(Bs * T);       // every slab row, pad rows included (their results are never read)
-      CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, MT));
-      CK((hipError_t)proj(inr, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].bih, w.grr, MT));
-      CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].bih, w.grf, top ? B : MT));
+      CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].wih_s, m->fwd[l].wih_scale, m->fwd[l].bih,
+                          w.gf, MT));
+      CK((hipError_t)proj(inr, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].wih_s, m->rec_r[l].wih_scale,
+                          m->rec_r[l].bih, w.grr, MT));
+      CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].wih_s, m->rec_f[l].wih_scale,
+                          m->rec_f[l].bih, w.grf, top ? B : MT));
       gf = w.gf; grr = w.grr; grf = w.grf;
       ldg = H3;
     }
@@ -827,7 +918,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       }
       a.ndir = nd;
       const size_t wp[3] = {m->fwd[l].whh_p, m->rec_r[l].whh_p, m->rec_f[l].whh_p};
-      CK((hipError_t)step(a, wp));
+      const DirW* const dw[3] = {&m->fwd[l], &m->rec_r[l], &m->rec_f[l]};
+      CK((hipError_t)step(a, wp, dw));
     }
     if (top) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
       GruArgs a{};
@@ -839,7 +931,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       d.hprev = w.ytop; d.ldh = 2 * Hp;
       d.hout = w.ytop; d.ldo = 2 * Hp;
       const size_t wp[3] = {m->rec_f[l].whh_p, 0, 0};
-      CK((hipError_t)step(a, wp));
+      const DirW* const dw[3] = {&m->rec_f[l], nullptr, nullptr};
+      CK((hipError_t)step(a, wp, dw));
     }
     if (m->prof) {
       int rc = prof_mark(mm, s);

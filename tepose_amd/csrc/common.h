@@ -180,7 +180,7 @@ hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s);
 int skinny_h3_max_m();
 // first cell step of a direction (h = 0: no product), writing the same outputs
 struct GateBatch { GateDir d[3]; };
-hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s);
+hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s, int scaled16 = 0);
 // x[rows][2133] fp32 -> blocked hi / lo planes of [rows x 2144]
 hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s);
 // (relu?)src[rows][ld] fp32 (K valid columns) -> blocked planes of [R x Kp], rows < R
@@ -189,7 +189,12 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);
-// gemm_h3s.hip: single accumulator, 256 x 256 tiles, scaled planes in the [K/16][R][16] layout
+// gemm_h3s.hip: single accumulator, 256 x 256 tiles, scaled planes in the [K/16][R][16] layout:
+// element (row, k) of an [R x Kp] matrix (Kp multiple of 16), value v stored as hi = fp16(v p), lo = fp16(v p - hi)
+__host__ __device__ inline long plane16_index(long row, long k, long R) {
+  return ((k >> 4) * R + row) * 16 + ((((k >> 3) & 1) ^ ((row >> 3) & 1)) << 3) + (k & 7);
+}
+constexpr float kStateScale = 16384.f;   // scale of recurrent-state planes in that format (|h| < 1)
 struct H3SArgs {
   const half_t *Ah, *Al; long a_kst;     // halfs between K-tiles (R * 16)
   const half_t *Wh, *Wl; long w_kst;     // W rows padded to 256
@@ -199,7 +204,9 @@ struct H3SArgs {
   float inv_scale;                       // 1 / (pA * pW)
   int M, N;
 };
-hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s);
+struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
+hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s);                                // state planes a GRU step writes
+hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
 hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
                                  void* lo, hipStream_t s);
 hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);

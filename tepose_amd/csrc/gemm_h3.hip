@@ -591,7 +591,7 @@ hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s) {
 
 // First cell step of a direction: h_prev = 0, so h W_hh^T vanishes and the step is element-wise.  Writes the
 // new state as fp32 and as blocked hi / lo planes for the next step's product.
-__global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int Hp) {
+__global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int Hp, int scaled16) {
   typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   const GateDir& d = gb.d[blockIdx.y];
   const int Hh = Hp / 2;                                     // a thread owns two consecutive hidden units
@@ -609,20 +609,28 @@ __global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int
     }
     d.hout[row * d.ldo + j] = hv[0];
     d.hout[row * d.ldo + j + 1] = hv[1];
-    const long o = (long)(j >> 5) * d.okst + plane_index(row, j & 31, 0);
     half_t h0, l0, h1, l1;
-    split_hi_lo(hv[0], h0, l0);
-    split_hi_lo(hv[1], h1, l1);
+    long o;
+    if (scaled16) {       // planes of gemm_h3s.hip: value * kStateScale, [K/16][R][16]
+      o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
+      const float s0 = hv[0] * kStateScale, s1 = hv[1] * kStateScale;
+      h0 = (half_t)s0; l0 = (half_t)(s0 - (float)h0);
+      h1 = (half_t)s1; l1 = (half_t)(s1 - (float)h1);
+    } else {
+      o = (long)(j >> 5) * d.okst + plane_index(row, j & 31, 0);
+      split_hi_lo(hv[0], h0, l0);
+      split_hi_lo(hv[1], h1, l1);
+    }
     *(h16x2v*)(d.hout_hi + o) = h16x2v{h0, h1};
     *(h16x2v*)(d.hout_lo + o) = h16x2v{l0, l1};
   }
 }
 
-hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s) {
+hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s, int scaled16) {
   if (M <= 0 || ndir <= 0) return hipSuccess;
   const long total = (long)M * Hp / 2;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(gru_first_kernel, dim3(blocks, ndir), dim3(256), 0, s, gb, M, Hp);
+  hipLaunchKernelGGL(gru_first_kernel, dim3(blocks, ndir), dim3(256), 0, s, gb, M, Hp, scaled16);
   return hipGetLastError();
 }
 

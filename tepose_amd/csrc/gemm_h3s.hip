@@ -28,11 +28,6 @@ __device__ __forceinline__ void wait_vms() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// element (row, k) of an [R x Kp] matrix, Kp multiple of 16
-__host__ __device__ inline long plane16_index(long row, long k, long R) {
-  return ((k >> 4) * R + row) * 16 + ((((k >> 3) & 1) ^ ((row >> 3) & 1)) << 3) + (k & 7);
-}
-
 // fp32 [rows][ld] (K valid columns) * p -> scaled planes of [R x Kp].  A wave converts 8 rows of one K-tile per unit
 // (a lane two consecutive k of one row): it writes 256 contiguous bytes per plane; consecutive waves take
 // consecutive K-tiles of the same rows, so a block's reads stay contiguous; 4 units in flight per wave.
@@ -108,9 +103,22 @@ __device__ __forceinline__ void h3s_tile_of_block(int bid, int nwg, int tilesM, 
   tn = rem / gm;
 }
 
-__global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SArgs a, int tilesM, int tilesN) {
-  constexpr int WMF = 2, WNT = 4, NST = 4;
-  constexpr int HM = 256, HN = 256, HK = 16;
+__device__ __forceinline__ float gs_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float gs_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+}
+
+// Plain product: 4 x 2 waves of 64 x 128 (WMF 2, WNT 4) = 256 x 256 block.  GRU step: 2 x 4 waves of 64 x 96 (the
+// r, z, n tiles of 32 hidden units) = 128 rows x 128 hidden units x 3 gates, W_hh rows in the gate-interleaved tile
+// order, cell update in the epilogue, new state out as fp32 and as scaled planes.
+template <int WMF, int WNT, int NWM, int NWN, bool GRU>
+__global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tilesM, int tilesN) {
+  constexpr int NST = 4;
+  constexpr int HM = 32 * WMF * NWM, HN = 32 * WNT * NWN, HK = 16;
+  static_assert(NWM * NWN == 8, "8 waves");
+  const H3SArgs& a = batch.p[blockIdx.y];
   constexpr int RB = HK * 2;                             // 32 bytes per plane row of a stage
   constexpr int RPI = 1024 / RB;                         // 32 rows per DMA instruction
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;          // 32 KB
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SArgs a, int tilesM, in
   h3s_tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
   const int m0 = tm * HM, n0 = tn * HN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves: 64 rows x 128 columns each
+  const int wm = wave / NWN, wn = wave % NWN;
   const int r = lane & 31, h = lane >> 5;
 
   const char* gsrc[NDMA];
@@ -158,9 +166,9 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SArgs a, int tilesM, in
   const int sx = 16 * (h ^ ((r >> 3) & 1));
   int aoff[WMF], boff[WNT];
 #pragma unroll
-  for (int i = 0; i < WMF; ++i) aoff[i] = (wm * 64 + i * 32 + r) * RB + sx;
+  for (int i = 0; i < WMF; ++i) aoff[i] = (wm * 32 * WMF + i * 32 + r) * RB + sx;
 #pragma unroll
-  for (int j = 0; j < WNT; ++j) boff[j] = 2 * HM * RB + (wn * 128 + j * 32 + r) * RB + sx;
+  for (int j = 0; j < WNT; ++j) boff[j] = 2 * HM * RB + (wn * 32 * WNT + j * 32 + r) * RB + sx;
   constexpr int A_LO = HM * RB, W_LO = HN * RB;
 
   f32x16 acc[WMF][WNT];
@@ -227,25 +235,104 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SArgs a, int tilesM, in
   for (; kt < KT; ++kt) ktile(kt, std::false_type{});
   wait_vms<0>();
 
+  if constexpr (GRU) {
+    static_assert(!GRU || WNT == 3, "r, z, n tiles");
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    typedef _Float16 h16x4s __attribute__((ext_vector_type(4)));
+    const GateDir& d = batch.gate[blockIdx.y];
+    const int Hp = batch.Hp;
+    const int jb = tn * (32 * NWN) + wn * 32;              // first hidden unit of this wave's 32
+    // The three products of a 32-row fragment go through the idle ring, so that a lane ends up with 4 consecutive
+    // hidden units of one row: the cell operands come in as 16-byte loads, the new state leaves as one 16-byte
+    // store and two 8-byte plane stores (a quarter of the memory instructions of the one-column-per-lane layout).
+    __syncthreads();
+    float* tile = (float*)lds + wave * 3 * 32 * 32;        // [gate][row][32]
+    const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev) & 15) == 0 && (d.ldo & 3) == 0 &&
+                     (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
 #pragma unroll
-  for (int j = 0; j < WNT; ++j) {
-    const int col = n0 + wn * 128 + j * 32 + r;
-    if (col >= a.N) continue;
-    const float bv = a.bias ? a.bias[col] : 0.f;
+    for (int i = 0; i < WMF; ++i) {
 #pragma unroll
-    for (int i = 0; i < WMF; ++i)
+      for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < a.M) a.C[(long)row * a.ldc + col] = acc[i][j][e] * a.inv_scale + bv;
+        for (int e = 0; e < 16; ++e)
+          tile[(g * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[i][g][e] * a.inv_scale;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int idx = t * 64 + lane, rl = idx >> 3, c4 = idx & 7;
+        const int row = m0 + wm * 32 * WMF + i * 32 + rl, j = jb + c4 * 4;
+        if (row < a.M && j < Hp) {
+          const f32x4s hr = *(const f32x4s*)(tile + (0 * 32 + rl) * 32 + c4 * 4);
+          const f32x4s hz = *(const f32x4s*)(tile + (1 * 32 + rl) * 32 + c4 * 4);
+          const f32x4s hn = *(const f32x4s*)(tile + (2 * 32 + rl) * 32 + c4 * 4);
+          const float* gi = d.gi + (long)row * d.ldgi + j;
+          const float* hq = d.hprev + (long)row * d.ldh + j;
+          f32x4s gr, gz, gn, hp, br, bz, bn;
+          if (vec) {
+            gr = *(const f32x4s*)gi; gz = *(const f32x4s*)(gi + Hp); gn = *(const f32x4s*)(gi + 2 * Hp);
+            hp = *(const f32x4s*)hq;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { gr[c] = gi[c]; gz[c] = gi[Hp + c]; gn[c] = gi[2 * Hp + c]; hp[c] = hq[c]; }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { br[c] = d.bhh[j + c]; bz[c] = d.bhh[Hp + j + c]; bn[c] = d.bhh[2 * Hp + j + c]; }
+          f32x4s v;
+          _Float16 hh[4], ll[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float rg = gs_sigmoid(gr[c] + (hr[c] + br[c]));
+            const float zg = gs_sigmoid(gz[c] + (hz[c] + bz[c]));
+            const float ng = gs_tanh(gn[c] + rg * (hn[c] + bn[c]));
+            v[c] = (1.f - zg) * ng + zg * hp[c];
+            const float sv = v[c] * batch.state_scale;
+            hh[c] = (_Float16)sv;
+            ll[c] = (_Float16)(sv - (float)hh[c]);
+          }
+          float* ho = d.hout + (long)row * d.ldo + j;
+          if (vec) {
+            *(f32x4s*)ho = v;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ho[c] = v[c];
+          }
+          const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
+          *(h16x4s*)((_Float16*)d.hout_hi + o) = h16x4s{hh[0], hh[1], hh[2], hh[3]};
+          *(h16x4s*)((_Float16*)d.hout_lo + o) = h16x4s{ll[0], ll[1], ll[2], ll[3]};
+        }
       }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = n0 + wn * 32 * WNT + j * 32 + r;
+      if (col >= a.N) continue;
+      const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < WMF; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < a.M) a.C[(long)row * a.ldc + col] = acc[i][j][e] * a.inv_scale + bv;
+        }
+    }
   }
 }
 
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
-  hipLaunchKernelGGL(gemm_h3s_kernel, dim3(tilesM * tilesN), dim3(512), 0, s, a, tilesM, tilesN);
+  H3SBatch b{};
+  b.p[0] = a; b.n = 1;
+  hipLaunchKernelGGL((gemm_h3s_kernel<2, 4, 4, 2, false>), dim3(tilesM * tilesN, 1), dim3(512), 0, s, b, tilesM, tilesN);
+  return hipGetLastError();
+}
+
+// GRU step of up to 3 directions: p[d] = {hprev planes, W_hh planes (gate-tiled rows, padded to 384), Kp = Hp,
+// inv_scale}, gate[d] = cell operands / outputs (okst = halfs between 16-column groups of the output planes)
+hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s) {
+  if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
+  const int tilesM = (b.p[0].M + 127) / 128, tilesJ = (b.Hp + 127) / 128;
+  hipLaunchKernelGGL((gemm_h3s_kernel<2, 3, 2, 4, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM, tilesJ);
   return hipGetLastError();
 }
 

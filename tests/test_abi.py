@@ -38,7 +38,7 @@ def test_handle_argument_errors_without_gpu(lib):
     n = lib.tepose_packed_bytes(h)
     # encoder 60.6M + regressor 3.5M + SMPL ~5M floats (padded) + 54M floats of fp16 hi/lo planes of the
     # GRU matrices for the split-precision GEMM
-    assert 580e6 < n < 680e6
+    assert 700e6 < n < 840e6
     # nothing packed yet -> state error, before any device access
     assert lib.tepose_encoder_fwd(h, 16, 1, 1, 0, 16, 16, 1 << 20, None) == -4
     assert lib.tepose_workspace_bytes(h, 64, 16) > 0
