@@ -44,7 +44,7 @@ struct tepose_model {
   size_t wih0_s = 0, wih0_scale = 0;            // the same block as scaled [K/16][R][16] planes (gemm_h3s.hip) + its scale
   float w0_scale = 1.f;                         // host copy of blob[wih0_scale]
   bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
-  bool gru_single_acc = false;                  // large batches: layer >= 1 projections and GRU steps on it too
+  bool gru_single_acc = true;                   // large batches: layer >= 1 projections and GRU steps on it too
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
@@ -426,8 +426,8 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
     m->split = !(e && atoi(e) != 0);
     e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
     m->g0_single_acc = !(e && atoi(e) == 0);
-    e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 1: layer >= 1 projections and GRU steps of large batches too
-    m->gru_single_acc = e && atoi(e) != 0;
+    e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
+    m->gru_single_acc = !(e && atoi(e) == 0);
   }
   layout(m);
   *out = m;
@@ -774,7 +774,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const long Bs = (long)w.Bs;          // rows per time slab of the layer >= 1 buffers
   // large batches: recurrent-state planes in the scaled format, layer >= 1 projections and GRU steps on the
   // single-accumulator kernels (gemm_h3s.hip)
-  const bool sf = h3 && m->gru_single_acc && B >= 1024;
+  const bool sf = h3 && m->gru_single_acc && B >= 4096;   // below that its 128 x 384 GRU tiles leave CUs idle
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t w_s, float w_scale, size_t bias,
