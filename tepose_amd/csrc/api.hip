@@ -774,7 +774,11 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const long Bs = (long)w.Bs;          // rows per time slab of the layer >= 1 buffers
   // large batches: recurrent-state planes in the scaled format, layer >= 1 projections and GRU steps on the
   // single-accumulator kernels (gemm_h3s.hip)
-  const bool sf = h3 && m->gru_single_acc && B >= 4096;   // below that its 128 x 384 GRU tiles leave CUs idle
+  static const int s_min_b = [] {
+    const char* e = getenv("TEPOSE_S_MIN_B");
+    return e ? atoi(e) : 2048;        // measured crossover against the two-accumulator recurrent path
+  }();
+  const bool sf = h3 && m->gru_single_acc && B >= s_min_b;
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t w_s, float w_scale, size_t bias,

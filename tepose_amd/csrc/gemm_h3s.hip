@@ -110,8 +110,8 @@ __device__ __forceinline__ float gs_tanh(float x) {
   return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
 }
 
-// Plain product: 4 x 2 waves of 64 x 128 (WMF 2, WNT 4) = 256 x 256 block.  GRU step: 2 x 4 waves of 64 x 96 (the
-// r, z, n tiles of 32 hidden units) = 128 rows x 128 hidden units x 3 gates, W_hh rows in the gate-interleaved tile
+// Plain product: 4 x 2 waves of 64 x 128 (WMF 2, WNT 4) = 256 x 256 block.  GRU step: 4 x 2 waves of 32 x 96 (the
+// r, z, n tiles of 32 hidden units) = 128 rows x 64 hidden units x 3 gates, W_hh rows in the gate-interleaved tile
 // order, cell update in the epilogue, new state out as fp32 and as scaled planes.
 template <int WMF, int WNT, int NWM, int NWN, bool GRU>
 __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tilesM, int tilesN) {
@@ -122,8 +122,10 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
   constexpr int RB = HK * 2;                             // 32 bytes per plane row of a stage
   constexpr int RPI = 1024 / RB;                         // 32 rows per DMA instruction
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;          // 32 KB
-  constexpr int NDMA = STAGE / 1024 / 8;                 // 4 per wave
-  static_assert(NST * STAGE <= 160 * 1024, "ring fits the LDS");
+  constexpr int TOT = STAGE / 1024;                      // DMA instructions per stage, dealt to the 8 waves:
+  constexpr int Q = TOT / 8, REM = TOT % 8;              // waves < REM issue Q + 1 of them, the others Q
+  constexpr int NDMA = Q + (REM ? 1 : 0);
+  static_assert(STAGE % 1024 == 0 && NST * STAGE <= 160 * 1024, "ring fits the LDS");
   __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
   int tm, tn;
   h3s_tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
@@ -132,11 +134,16 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
   const int wm = wave / NWN, wn = wave % NWN;
   const int r = lane & 31, h = lane >> 5;
 
+  const int nd = Q + (wave < REM ? 1 : 0);               // this wave's share
+  const int i0 = wave * Q + min(wave, REM);              // its first instruction of a stage
+  // wait until at most n whole stages of this wave's DMA are still in flight (counted vmcnt, literal per share)
+  auto wait_n1 = [&]() __attribute__((always_inline)) { if (REM && wave < REM) wait_vms<Q + 1>(); else wait_vms<Q>(); };
+  auto wait_n2 = [&]() __attribute__((always_inline)) { if (REM && wave < REM) wait_vms<2 * (Q + 1)>(); else wait_vms<2 * Q>(); };
   const char* gsrc[NDMA];
   long kst[NDMA];
 #pragma unroll
   for (int q = 0; q < NDMA; ++q) {
-    const int i = wave * NDMA + q;
+    const int i = min(i0 + q, TOT - 1);
     int ri = i * RPI + lane / 2;                         // row of the stage image [A_hi | A_lo | W_hi | W_lo]
     const char* base;
     long grow, ks;
@@ -157,8 +164,10 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
              (unsigned)__builtin_amdgcn_readfirstlane((int)ks);
   }
   auto dma_part = [&](int stage, int q) {
-    glds16s(gsrc[q], lds + (stage % NST) * STAGE + (wave * NDMA + q) * 1024);
-    gsrc[q] += kst[q];
+    if (REM == 0 || q < nd) {
+      glds16s(gsrc[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
+      gsrc[q] += kst[q];
+    }
   };
 
   // fragment byte offsets inside a stage: row * 32 + 16 * (h ^ swz(row)); tile rows are multiples of 32, so the
@@ -188,12 +197,13 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
     }
   auto ktile = [&](int kt, auto dma) __attribute__((always_inline)) {
     constexpr bool DMA = decltype(dma)::value;
+    static_assert(NST == 4, "waits written for a 4-slot ring");
     if constexpr (DMA) {
-      wait_vms<(NST - 2) * NDMA>();
+      wait_n2();
     } else {
       const int newer = min(NST - 2, KT - 1 - kt);
-      if (newer >= 2) wait_vms<2 * NDMA>();
-      else if (newer == 1) wait_vms<NDMA>();
+      if (newer >= 2) wait_n2();
+      else if (newer == 1) wait_n1();
       else wait_vms<0>();
     }
     __builtin_amdgcn_s_barrier();
@@ -246,24 +256,30 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
     // hidden units of one row: the cell operands come in as 16-byte loads, the new state leaves as one 16-byte
     // store and two 8-byte plane stores (a quarter of the memory instructions of the one-column-per-lane layout).
     __syncthreads();
-    float* tile = (float*)lds + wave * 3 * 32 * 32;        // [gate][row][32]
+    float* tile = (float*)lds + wave * 32 * 32;            // one gate's [row][32] block at a time (4 KB per wave)
+    static_assert(8 * 32 * 32 * 4 <= NST * STAGE, "epilogue staging fits the ring");
     const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev) & 15) == 0 && (d.ldo & 3) == 0 &&
                      (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
 #pragma unroll
     for (int i = 0; i < WMF; ++i) {
+      f32x4s hg[3][4];                                     // [gate][task]: 4 consecutive hidden units of one row
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+      for (int g = 0; g < 3; ++g) {
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          tile[(g * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[i][g][e] * a.inv_scale;
+          tile[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[i][g][e] * a.inv_scale;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int idx = t * 64 + lane;
+          hg[g][t] = *(const f32x4s*)(tile + (idx >> 3) * 32 + (idx & 7) * 4);
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int idx = t * 64 + lane, rl = idx >> 3, c4 = idx & 7;
         const int row = m0 + wm * 32 * WMF + i * 32 + rl, j = jb + c4 * 4;
         if (row < a.M && j < Hp) {
-          const f32x4s hr = *(const f32x4s*)(tile + (0 * 32 + rl) * 32 + c4 * 4);
-          const f32x4s hz = *(const f32x4s*)(tile + (1 * 32 + rl) * 32 + c4 * 4);
-          const f32x4s hn = *(const f32x4s*)(tile + (2 * 32 + rl) * 32 + c4 * 4);
+          const f32x4s hr = hg[0][t], hz = hg[1][t], hn = hg[2][t];
           const float* gi = d.gi + (long)row * d.ldgi + j;
           const float* hq = d.hprev + (long)row * d.ldh + j;
           f32x4s gr, gz, gn, hp, br, bz, bn;
@@ -331,8 +347,11 @@ hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s) {
 // inv_scale}, gate[d] = cell operands / outputs (okst = halfs between 16-column groups of the output planes)
 hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
-  const int tilesM = (b.p[0].M + 127) / 128, tilesJ = (b.Hp + 127) / 128;
-  hipLaunchKernelGGL((gemm_h3s_kernel<2, 3, 2, 4, true>), dim3(tilesM * tilesJ, b.n), dim3(512), 0, s, b, tilesM, tilesJ);
+  // block = 128 rows x 64 hidden units x 3 gates (4 x 2 waves of 32 x 96): 100 VGPRs and an 80 KB ring, so two blocks
+  // share a CU and cover each other's pipeline fill and store drain.  Measured against 128 x 128 units (148 VGPRs,
+  // one block per CU): -1 % at B = 8192, and it keeps winning down to B ~ 2048; 256 rows x 64 units: +2.5 %.
+  const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
+  hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 2, true>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
   return hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() +
 n = 0
 while time.time() < t_end:
     L = int(rng.choice([1, 2, 2, 3])); H = int(rng.choice([64, 100, 128, 192, 256, 320]))
-    B = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 769, 1000, 1300, 4096, 4200]))
+    B = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 769, 1000, 1300, 2048, 2100, 4096, 4200]))
     T = int(rng.choice([1, 2, 3, 5, 6, 8]))
     seed = int(rng.randint(1 << 20))
     model, state, _ = build_model(L, H, seed=seed, device='cuda', smpl_np=smpl_np)
