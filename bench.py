@@ -116,6 +116,23 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
     return res
 
 
+def self_launch(n):
+    """One process per GPU through torch.distributed.run on 127.0.0.1 (the driver's own launch line), as children
+    of this GPU-free process.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def _t(msg, t0=[time.perf_counter()]):
     """phase timing on stderr (rank 0 only prints JSON on stdout)"""
     now = time.perf_counter()
@@ -136,11 +153,17 @@ def main():
     ap.add_argument('--share-device0', action='store_true', help='testing only: every rank uses cuda:0')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  This process has not touched the GPU
+        # (no HIP call, no torch.cuda query) and never will: the ranks are CHILD processes of the stock launcher,
+        # rank 0 prints the JSON line on the inherited stdout, and we exit with the launcher's code.
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run, or unset WORLD_SIZE to let '
+                         'bench.py start its own ranks)' % (args.gpus, world))
     if args.share_device0:
         local = 0
     torch.cuda.set_device(local)

@@ -32,7 +32,7 @@ extern "C" {
 #define TEPOSE_E_ARG (-1)       /* null pointer / non-positive size / bad enum           */
 #define TEPOSE_E_SHAPE (-2)     /* dimension not supported (see each function)           */
 #define TEPOSE_E_WORKSPACE (-3) /* workspace smaller than tepose_*_workspace_bytes()     */
-#define TEPOSE_E_STATE (-4)     /* handle not packed yet                                 */
+#define TEPOSE_E_STATE (-4)     /* handle not packed yet / blob of another model         */
 
 #define TEPOSE_FEAT 2048        /* ResNet feature width (lib/models/tepose.py:68)         */
 #define TEPOSE_THETA 85         /* cam3 + pose72 + shape10 (lib/models/spin.py:285)       */
@@ -111,6 +111,15 @@ int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_
                          float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                          void* stream);
 
+/* Same with the caller's initial state (Regressor.forward(x, init_pose=, init_shape=, init_cam=, n_iter=),
+ * lib/models/spin.py:240-251): init_pose[N,144] (6D), init_shape[N,10], init_cam[N,3] device rows, each may be NULL
+ * = the model's mean-parameter buffer.  n_iter = 0 returns SMPL(init state) -- rot6d_to_rotmat and
+ * rotation_matrix_to_angle_axis of the given pose, which is how the geometry edge cases are tested.           */
+int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
+                              const float* init_shape, const float* init_cam, const void* jreg_packed,
+                              float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
+                              void* workspace, size_t ws_bytes, void* stream);
+
 /* TePose.forward, eval mode (lib/models/tepose.py:121-136) = the two calls above.     */
 int tepose_forward(const tepose_model* m, const float* x, int B, int T, const void* jreg_packed,
                    float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
@@ -123,7 +132,9 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
  * (slot = frame % ring) plus one row for the newest frame (theta = 0).
  * tepose_project_frames: one frame per clip: feat row b at feat + b*feat_ld (2048 floats),
  * theta row at theta + b*theta_ld (85 floats) or theta == NULL for zeros  ->  out + b*out_ld.
- * workspace >= B*2144*4 bytes.                                                              */
+ * workspace >= tepose_project_frames_workspace_bytes(m, B) (the padded rows, plus their fp16 planes when
+ * the product runs on the split-precision kernel, i.e. with the numerics tepose_forward uses at that B). */
+size_t tepose_project_frames_workspace_bytes(const tepose_model* m, int B);
 int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld, const float* theta,
                           long theta_ld, int B, float* out, long out_ld, void* workspace,
                           size_t ws_bytes, void* stream);
@@ -180,6 +191,13 @@ int tepose_filter_one_euro(float* x, int N, int D, float min_cutoff, float beta,
  * rotmat_out (may alias): sign-continuous quaternions, q_t = slerp(q_{t-1}, q_t, ratio).    */
 int tepose_filter_slerp(const float* rotmat_in, float* rotmat_out, int N, int J, double ratio,
                         void* stream);
+
+/* ---- geometry helpers as callers use them on their own (lib/utils/demo_utils.py:112,
+ * lib/data_utils/threedpw_utils.py:98); the device functions are the ones the regressor kernel inlines ----
+ * rotation_matrix_to_angle_axis (lib/utils/geometry.py:68-233): R[N,3,3] -> aa[N,3], NaN -> 0.         */
+int tepose_rotmat_to_angle_axis(const float* R, int N, float* aa, void* stream);
+/* rot6d_to_rotmat (lib/utils/geometry.py:330-344): x6[N,6] (x.view(-1,3,2)) -> R[N,3,3].                */
+int tepose_rot6d_to_rotmat(const float* x6, int N, float* R, void* stream);
 
 /* ---- building blocks exported for tests and bench.py --------------------------------- */
 /* C[M,N] = (relu_a ? relu(A) : A)[M,K] * W[N,K]^T (+ bias[N]) with the library's own

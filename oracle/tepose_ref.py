@@ -113,12 +113,13 @@ def encoder_fwd_nn_gru(sd, x, n_layers, hidden):
 
 
 # ---- regressor FC loop ------------------------------------------------------------------
-def regressor_iterations(sd, feat, n_iter=3):
-    """Regressor.forward lines spin.py:243-261 (dropout = identity in eval)."""
+def regressor_iterations(sd, feat, n_iter=3, init=(None, None, None)):
+    """Regressor.forward lines spin.py:243-261 (dropout = identity in eval); `init` = the optional per-call
+    init_pose / init_shape / init_cam of spin.py:240-248."""
     B = feat.shape[0]
-    pose = sd['init_pose'].expand(B, -1)
-    shape = sd['init_shape'].expand(B, -1)
-    cam = sd['init_cam'].expand(B, -1)
+    pose = sd['init_pose'].expand(B, -1) if init[0] is None else init[0]
+    shape = sd['init_shape'].expand(B, -1) if init[1] is None else init[1]
+    cam = sd['init_cam'].expand(B, -1) if init[2] is None else init[2]
     for _ in range(n_iter):
         xc = torch.cat([feat, pose, shape, cam], 1)
         xc = xc @ sd['fc1.weight'].t() + sd['fc1.bias']
@@ -235,10 +236,10 @@ def smpl_joints49(smpl, verts, posed):
     return torch.cat([j45, extra], dim=1)[:, JOINT_MAP_49]
 
 
-def regressor_fwd(sd, smpl, feat, J_regressor=None, n_iter=3):
+def regressor_fwd(sd, smpl, feat, J_regressor=None, n_iter=3, init=(None, None, None)):
     """Regressor.forward (spin.py:240-291) -> dict like one element of its list."""
     B = feat.shape[0]
-    pose6d, shape, cam = regressor_iterations(sd, feat, n_iter)
+    pose6d, shape, cam = regressor_iterations(sd, feat, n_iter, init)
     R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
     verts, posed = lbs(smpl, shape, R)
     joints = smpl_joints49(smpl, verts, posed)

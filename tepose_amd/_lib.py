@@ -19,6 +19,8 @@ SYMBOLS = [
     'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read', 'tepose_create_vibe',
     'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
+    'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
+    'tepose_project_frames_workspace_bytes',
 ]
 
 _lib = None
@@ -61,6 +63,10 @@ def load():
                                          c_size_t, c_void_p]
     lib.tepose_forward.argtypes = [c_void_p, fp, c_int, c_int, fp, fp, fp, fp, fp, fp, fp, c_size_t,
                                    c_void_p]
+    lib.tepose_regressor_fwd_init.argtypes = [c_void_p, fp, c_int, c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp,
+                                              c_size_t, c_void_p]
+    lib.tepose_rotmat_to_angle_axis.argtypes = [fp, c_int, fp, c_void_p]
+    lib.tepose_rot6d_to_rotmat.argtypes = [fp, c_int, fp, c_void_p]
     lib.tepose_gemm_workspace_bytes.argtypes = [c_int, c_int]
     lib.tepose_gemm_workspace_bytes.restype = c_size_t
     lib.tepose_gemm_f32.argtypes = [fp, c_long, fp, c_long, fp, fp, c_long, c_int, c_int, c_int, c_int,
@@ -76,6 +82,8 @@ def load():
     lib.tepose_smpl_fwd.argtypes = [c_void_p, c_int, fp, fp, c_int, fp, fp, fp, c_size_t, c_void_p]
     lib.tepose_filter_one_euro.argtypes = [fp, c_int, c_int, c_float, c_float, c_float, c_void_p]
     lib.tepose_filter_slerp.argtypes = [fp, fp, c_int, c_int, c_double, c_void_p]
+    lib.tepose_project_frames_workspace_bytes.argtypes = [c_void_p, c_int]
+    lib.tepose_project_frames_workspace_bytes.restype = c_size_t
     lib.tepose_project_frames.argtypes = [c_void_p, fp, c_long, fp, c_long, c_int, fp, c_long, fp, c_size_t, c_void_p]
     lib.tepose_forward_cached.argtypes = [c_void_p, fp, c_int, c_int, c_long, fp, c_long, c_int, c_int, fp, fp, fp, fp,
                                           fp, fp, fp, c_size_t, c_void_p]
@@ -86,9 +94,7 @@ def load():
     lib.tepose_profile_read.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     lib.tepose_profile_read_gru.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     for name in SYMBOLS:
-        fn = getattr(lib, name)
-        if fn.restype is c_int and name != 'tepose_version':
-            pass
+        getattr(lib, name)              # AttributeError here = the built library is older than this binding
     if lib.tepose_version() != 1:
         raise ImportError('tepose_amd: ABI version mismatch (%d)' % lib.tepose_version())
     _lib = lib

@@ -35,6 +35,7 @@ struct tepose_model {
   size_t vlin_w = 0, vlin_b = 0;
   bool vibe_packed = false;
   int L = 0, H = 0, Hp = 0;
+  size_t hdr = 0;                               // blob header (BlobHeader): what the blob holds, checked by tepose_adopt_blob
   float* blob = nullptr;
   size_t blob_floats = 0;
   bool enc_packed = false, reg_packed = false, smpl_packed = false;
@@ -55,6 +56,7 @@ struct tepose_model {
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
   bool split = true;                            // batches of more than split_min_m() rows run their matmuls on the fp16x3 split kernels
+  int s_min_b = 2048;                           // scaled-format recurrent path from this batch size
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -80,6 +82,7 @@ void layout_tail(tepose_model* m, size_t cur);
 void layout_vibe(tepose_model* m) {
   const size_t Hp = m->Hp, L = m->L;
   size_t cur = 0;
+  m->hdr = take(cur, 64);
   const size_t n128 = round_up(3 * (int)Hp, 128);
   m->vibe.assign(L, DirW());
   for (size_t l = 0; l < L; ++l) {
@@ -96,6 +99,7 @@ void layout_vibe(tepose_model* m) {
 void layout(tepose_model* m) {
   const size_t Hp = m->Hp, L = m->L;
   size_t cur = 0;
+  m->hdr = take(cur, 64);
   m->wih0 = take(cur, (size_t)round_up(9 * (int)Hp, 128) * kInputP);
   m->bih0 = take(cur, 9 * Hp);
   m->fwd.assign(L, DirW());
@@ -182,6 +186,26 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
     hipError_t e__ = (expr);          \
     if (e__ != hipSuccess) return (int)e__; \
   } while (0)
+
+// First 256 bytes of the blob: identifies the model the packed sections belong to, so that a blob that travelled
+// (RCCL broadcast, copy) is only adopted by a handle of the same kind / size / library layout.
+struct BlobHeader {
+  uint32_t magic, abi, kind, L, H, Hp, sections;   // sections: bit 0 encoder, 1 regressor, 2 SMPL tables
+  uint32_t layout_floats_lo, layout_floats_hi;      // blob_floats of the layout that wrote it
+};
+constexpr uint32_t kBlobMagic = 0x54455031u;        // "TEP1"
+
+int write_header(tepose_model* m, hipStream_t s) {
+  BlobHeader h{};
+  h.magic = kBlobMagic; h.abi = TEPOSE_ABI_VERSION; h.kind = (uint32_t)m->kind; h.L = (uint32_t)m->L; h.H = (uint32_t)m->H;
+  h.Hp = (uint32_t)m->Hp;
+  h.sections = ((m->kind == 0 ? m->enc_packed : m->vibe_packed) ? 1u : 0u) | (m->reg_packed ? 2u : 0u) |
+               (m->smpl_packed ? 4u : 0u);
+  h.layout_floats_lo = (uint32_t)(m->blob_floats & 0xffffffffu); h.layout_floats_hi = (uint32_t)((uint64_t)m->blob_floats >> 32);
+  CK(hipMemcpyAsync(m->blob + m->hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
+  CK(hipStreamSynchronize(s));                      // h is a stack object (pack time only)
+  return 0;
+}
 
 int pack(const float* src, long ld, int N, int K, float* dst, int Np, int Kp, int rowmap, int colmap,
          int H, int Hp, hipStream_t s) {
@@ -356,6 +380,12 @@ void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
   w.vposed = c.f((size_t)N * kVertLd);
 }
 
+hipError_t init_state(const float* init160, const float* pose, const float* shape, const float* cam, float* xs, int N,
+                      hipStream_t s) {
+  if (pose || shape || cam) return launch_init_state_rows(init160, pose, shape, cam, xs, N, s);
+  return launch_init_state(init160, xs, N, s);
+}
+
 GemmArgs gemm(const float* A, long lda, const float* W, int Kp, float* C, long ldc, const float* bias,
               int M, int N) {
   GemmArgs g{};
@@ -400,6 +430,18 @@ int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
 
 }  // namespace
 
+// numerics / dispatch knobs, read once per handle at creation (both model kinds)
+static void read_env_knobs(tepose_model* m) {
+  const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
+  m->split = !(e && atoi(e) != 0);
+  e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
+  m->g0_single_acc = !(e && atoi(e) == 0);
+  e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
+  m->gru_single_acc = !(e && atoi(e) == 0);
+  e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
+  m->s_min_b = e ? atoi(e) : 2048;                  // measured crossover against the two-accumulator recurrent path
+}
+
 extern "C" {
 
 int tepose_version(void) { return TEPOSE_ABI_VERSION; }
@@ -421,14 +463,7 @@ int tepose_create(int n_layers, int hidden, tepose_model** out) {
   tepose_model* m = new (std::nothrow) tepose_model();
   if (!m) return TEPOSE_E_ARG;
   m->L = n_layers; m->H = hidden; m->Hp = round_up(hidden, 64);
-  {
-    const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
-    m->split = !(e && atoi(e) != 0);
-    e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
-    m->g0_single_acc = !(e && atoi(e) == 0);
-    e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
-    m->gru_single_acc = !(e && atoi(e) == 0);
-  }
+  read_env_knobs(m);
   layout(m);
   *out = m;
   return 0;
@@ -456,6 +491,7 @@ int tepose_create_vibe(int n_layers, int hidden, tepose_model** out) {
   tepose_model* m = new (std::nothrow) tepose_model();
   if (!m) return TEPOSE_E_ARG;
   m->kind = 1; m->L = n_layers; m->H = hidden; m->Hp = round_up(hidden, 64);
+  read_env_knobs(m);        // TEPOSE_EXACT_FP32 covers the bootstrap model's regressor / blend-shape products too
   layout_vibe(m);
   *out = m;
   return 0;
@@ -464,12 +500,21 @@ int tepose_create_vibe(int n_layers, int hidden, tepose_model** out) {
 int tepose_adopt_blob(tepose_model* m) {
   if (!m) return TEPOSE_E_ARG;
   if (!m->blob) return TEPOSE_E_STATE;
-  m->enc_packed = m->reg_packed = m->smpl_packed = m->vibe_packed = true;
+  BlobHeader h{};
+  CK(hipMemcpy(&h, m->blob + m->hdr, sizeof(h), hipMemcpyDeviceToHost));                      // set-up time only
+  const uint64_t lf = ((uint64_t)h.layout_floats_hi << 32) | h.layout_floats_lo;
+  if (h.magic != kBlobMagic || h.abi != TEPOSE_ABI_VERSION || (int)h.kind != m->kind || (int)h.L != m->L ||
+      (int)h.H != m->H || (int)h.Hp != m->Hp || lf != (uint64_t)m->blob_floats)
+    return TEPOSE_E_STATE;                        // not a blob of this model kind / size / library layout
+  m->enc_packed = m->kind == 0 && (h.sections & 1u);
+  m->vibe_packed = m->kind == 1 && (h.sections & 1u);
+  m->reg_packed = (h.sections & 2u) != 0;
+  m->smpl_packed = (h.sections & 4u) != 0;
   m->maxdepth = kNJ - 1;   // upper bound; chain levels past the real depth are no-ops
   int max_nnz = kNJ;
   CK(hipMemcpy(&max_nnz, m->blob + m->smpl.lbs_nnz, sizeof(int), hipMemcpyDeviceToHost));   // set-up time only
   m->lbs_sparse = max_nnz <= 4 ? 1 : 0;
-  if (m->kind == 0) {
+  if (m->kind == 0 && m->enc_packed) {
     CK(hipMemcpy(&m->w0_scale, m->blob + m->wih0_scale, sizeof(float), hipMemcpyDeviceToHost));
     if (!(m->w0_scale > 0.f)) m->w0_scale = 1.f;
     for (int l = 0; l < m->L; ++l)
@@ -503,7 +548,7 @@ int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, vo
   CK((hipError_t)pack(w[4 * L], H, kFeat, H, B + m->vlin_w, kFeat, Hp, ROW_PLAIN, COL_PLAIN, H, Hp, s));
   CK((hipError_t)pack(w[4 * L + 1], 1, kFeat, 1, B + m->vlin_b, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
   m->vibe_packed = true;
-  return 0;
+  return write_header(m, s);
 }
 
 size_t tepose_vibe_workspace_bytes(const tepose_model* m, int B, int N) {
@@ -623,7 +668,7 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
   CK((hipError_t)planes_of(B + m->wlf, kFeat, Hp, B + m->wlf_p, s));
   CK((hipError_t)planes_of(B + m->wlr, kFeat, 2 * Hp, B + m->wlr_p, s));
   m->enc_packed = true;
-  return 0;
+  return write_header(m, s);
 }
 
 int tepose_pack_regressor(tepose_model* m, const float* const* w, int n_w, void* stream) {
@@ -655,7 +700,7 @@ int tepose_pack_regressor(tepose_model* m, const float* const* w, int n_w, void*
   CK((hipError_t)planes_of(B + m->w2, 1024, 1024, B + m->w2_p, s));
   CK((hipError_t)planes_of(B + m->wdec, 256, 1024, B + m->wdec_p, s));
   m->reg_packed = true;
-  return 0;
+  return write_header(m, s);
 }
 
 int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shapedirs,
@@ -691,7 +736,7 @@ int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shap
   CK(launch_csr_build(J_regressor_extra, 9, kNV, (int*)(B + m->smpl.xr_ptr), (int*)(B + m->smpl.xr_idx),
                       B + m->smpl.xr_val, 9 * kNV, s));
   m->smpl_packed = true;
-  return 0;
+  return write_header(m, s);
 }
 
 size_t tepose_jreg_packed_bytes(void) { return (32 + (size_t)17 * kNV * 2) * 4; }
@@ -774,11 +819,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const long Bs = (long)w.Bs;          // rows per time slab of the layer >= 1 buffers
   // large batches: recurrent-state planes in the scaled format, layer >= 1 projections and GRU steps on the
   // single-accumulator kernels (gemm_h3s.hip)
-  static const int s_min_b = [] {
-    const char* e = getenv("TEPOSE_S_MIN_B");
-    return e ? atoi(e) : 2048;        // measured crossover against the two-accumulator recurrent path
-  }();
-  const bool sf = h3 && m->gru_single_acc && B >= s_min_b;
+  const bool sf = h3 && m->gru_single_acc && B >= m->s_min_b;
   const size_t n128 = (size_t)round_up(H3, 128);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t w_s, float w_scale, size_t bias,
@@ -1083,16 +1124,23 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
   return encoder_core(m, src, B, T, is_train, feat, w, s);
 }
 
+size_t tepose_project_frames_workspace_bytes(const tepose_model* m, int B) {
+  if (!m || B < 1) return 0;
+  const size_t xbytes = align_up((size_t)B * kInputP * sizeof(float), 256);
+  // padded fp32 rows, plus their hi / lo planes when the product runs on the split-precision kernel
+  return (m->split && B > split_min_m()) ? 2 * xbytes + 512 : xbytes;
+}
+
 int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld, const float* theta, long theta_ld,
                           int B, float* out, long out_ld, void* workspace, size_t ws_bytes, void* stream) {
   if (!m || m->kind != 0 || !feat || !out || !workspace || B < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
-  if (ws_bytes < (size_t)B * kInputP * sizeof(float)) return TEPOSE_E_WORKSPACE;
+  if (ws_bytes < tepose_project_frames_workspace_bytes(m, B)) return TEPOSE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* xp = (float*)workspace;
   CK(launch_pad_rows(feat, feat_ld, theta, theta_ld, xp, B, s));
   const size_t xbytes = align_up((size_t)B * kInputP * sizeof(float), 256);
-  if (m->split && B > split_min_m() && ws_bytes >= 2 * xbytes + 512) {   // split-precision product
+  if (m->split && B > split_min_m()) {   // split-precision product, same numerics as tepose_forward's
     Planes P;
     P.hi = (half_t*)((char*)workspace + xbytes);
     P.lo = (half_t*)((char*)workspace + xbytes + xbytes / 2);
@@ -1134,6 +1182,14 @@ int tepose_forward_cached(const tepose_model* m, const float* ring_base, int rin
 int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter, const void* jreg_packed,
                          float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
                          void* workspace, size_t ws_bytes, void* stream) {
+  return tepose_regressor_fwd_init(m, feat, N, n_iter, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d,
+                                   rotmat, workspace, ws_bytes, stream);
+}
+
+int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
+                              const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta,
+                              float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
+                              void* stream) {
   if (!m || !feat || !theta || !verts || !kp_3d || !kp_2d || !rotmat || !workspace || N < 1 || n_iter < 0)
     return TEPOSE_E_ARG;
   if (!m->reg_packed || !m->smpl_packed) return TEPOSE_E_STATE;
@@ -1148,7 +1204,7 @@ int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_
     CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     CK((hipError_t)h3_mm(w.featP, Bl + m->w1a_p, 1024, kFeat, w.base, 1024, Bl + m->b1, N, 1024, nullptr, 0, 0.f,
                          nullptr, s));
-    CK(launch_init_state(Bl + m->init, w.xs, N, s));
+    CK(init_state(Bl + m->init, init_pose, init_shape, init_cam, w.xs, N, s));
     CK(launch_split_planes(w.xs, kState, N, kState, kState, N, w.xsP.hi, w.xsP.lo, s));
     for (int it = 0; it < n_iter; ++it) {
       CK((hipError_t)h3_mm(w.xsP, Bl + m->w1b_p, 1024, kState, w.h1, 1024, nullptr, N, 1024, w.base, 1024, 0.f,
@@ -1161,7 +1217,7 @@ int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_
   } else {
     GemmArgs gb = gemm(feat, kFeat, Bl + m->w1a, kFeat, w.base, 1024, Bl + m->b1, N, 1024);
     CK(launch_gemm(gb, s));
-    CK(launch_init_state(Bl + m->init, w.xs, N, s));
+    CK(init_state(Bl + m->init, init_pose, init_shape, init_cam, w.xs, N, s));
     for (int it = 0; it < n_iter; ++it) {
       GemmArgs g1 = gemm(w.xs, kState, Bl + m->w1b, kState, w.h1, 1024, nullptr, N, 1024);
       g1.addend = w.base; g1.ldadd = 1024;
@@ -1277,6 +1333,18 @@ int tepose_filter_one_euro(float* x, int N, int D, float min_cutoff, float beta,
 int tepose_filter_slerp(const float* rotmat_in, float* rotmat_out, int N, int J, double ratio, void* stream) {
   if (!rotmat_in || !rotmat_out || N < 1 || J < 1) return TEPOSE_E_ARG;
   CK(launch_slerp_smooth(rotmat_in, rotmat_out, N, J, ratio, (hipStream_t)stream));
+  return 0;
+}
+
+int tepose_rotmat_to_angle_axis(const float* R, int N, float* aa, void* stream) {
+  if (!R || !aa || N < 1) return TEPOSE_E_ARG;
+  CK(launch_rotmat_to_aa(R, N, aa, (hipStream_t)stream));
+  return 0;
+}
+
+int tepose_rot6d_to_rotmat(const float* x6, int N, float* R, void* stream) {
+  if (!x6 || !R || N < 1) return TEPOSE_E_ARG;
+  CK(launch_rot6d_to_rotmat(x6, N, R, (hipStream_t)stream));
   return 0;
 }
 

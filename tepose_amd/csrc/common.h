@@ -84,6 +84,10 @@ hipError_t launch_pad_rows(const float* feat, long feat_ld, const float* theta, 
                            long rows, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s);
+hipError_t launch_init_state_rows(const float* init160, const float* pose, const float* shape, const float* cam,
+                                  float* xs, int N, hipStream_t s);
+hipError_t launch_rotmat_to_aa(const float* R, int N, float* aa, hipStream_t s);
+hipError_t launch_rot6d_to_rotmat(const float* x6, int N, float* R, hipStream_t s);
 
 // ---------------------------------------------------------------- smpl.hip
 struct SmplConsts {              // device pointers into the packed blob

@@ -121,6 +121,33 @@ __global__ void __launch_bounds__(256) init_state_kernel(const float* __restrict
     xs[idx] = init160[idx % kState];
 }
 
+// per-call initial state (Regressor.forward(init_pose=, init_shape=, init_cam=), spin.py:240-251): each part comes
+// from the caller's [N, 144 | 10 | 3] rows when given, else from the model's mean-parameter buffers
+__global__ void __launch_bounds__(256) init_state_rows_kernel(const float* __restrict__ init160,
+                                                              const float* __restrict__ pose,
+                                                              const float* __restrict__ shape,
+                                                              const float* __restrict__ cam, float* __restrict__ xs,
+                                                              long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long n = idx / kState;
+    const int c = (int)(idx % kState);
+    float v = init160[c];
+    if (c < kNPose) { if (pose) v = pose[n * kNPose + c]; }
+    else if (c < kNPose + 10) { if (shape) v = shape[n * 10 + (c - kNPose)]; }
+    else if (c < kNPose + 13) { if (cam) v = cam[n * 3 + (c - kNPose - 10)]; }
+    xs[idx] = v;
+  }
+}
+
+hipError_t launch_init_state_rows(const float* init160, const float* pose, const float* shape, const float* cam,
+                                  float* xs, int N, hipStream_t s) {
+  const long total = (long)N * kState;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(init_state_rows_kernel, dim3(blocks), dim3(256), 0, s, init160, pose, shape, cam, xs, total);
+  return hipGetLastError();
+}
+
 hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s) {
   const long total = (long)N * kState;
   if (total <= 0) return hipSuccess;

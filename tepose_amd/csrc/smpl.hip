@@ -141,6 +141,22 @@ __device__ __forceinline__ void rotmat_to_aa(const float R[3][3], float aa[3]) {
     if (aa[i] != aa[i]) aa[i] = 0.f;
 }
 
+// geometry.py:330-344: x.view(-1,3,2): a1 = x[0::2], a2 = x[1::2]; F.normalize(v, eps=1e-6) = v / max(|v|, 1e-6)
+__device__ __forceinline__ void rot6d_to_rotmat(const float* __restrict__ x, float R[3][3]) {
+  const float a1[3] = {x[0], x[2], x[4]};
+  const float a2[3] = {x[1], x[3], x[5]};
+  const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-6f);
+  const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+  const float dp = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  const float u[3] = {a2[0] - dp * b1[0], a2[1] - dp * b1[1], a2[2] - dp * b1[2]};
+  const float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-6f);
+  const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2],
+                       b1[0] * b2[1] - b1[1] * b2[0]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { R[r][0] = b1[r]; R[r][1] = b2[r]; R[r][2] = b3[r]; }
+}
+
 // One wave per person, lane = joint (24 active).  xs row = [pose6d 144 | betas 10 | cam 3 | 0 0 0].
 // mode 0: xs row = regressor state (6D pose, rot6d_to_rotmat).  mode 1: xs row = theta[85]
 // (cam3 | axis-angle 72 | betas 10) and R = Rodrigues(aa) as smplx does for pose2rot=True
@@ -190,19 +206,7 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
         R[r][cc] = (r == cc ? 1.f : 0.f) + sn * K[r][cc] + cs * kk;
       }
   } else {
-  // rot6d_to_rotmat: a1 = x[0::2], a2 = x[1::2]
-  const float a1[3] = {x[6 * j + 0], x[6 * j + 2], x[6 * j + 4]};
-  const float a2[3] = {x[6 * j + 1], x[6 * j + 3], x[6 * j + 5]};
-  const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-6f);
-  const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
-  const float dp = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
-  const float u[3] = {a2[0] - dp * b1[0], a2[1] - dp * b1[1], a2[2] - dp * b1[2]};
-  const float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-6f);
-  const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
-  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2],
-                       b1[0] * b2[1] - b1[1] * b2[0]};
-#pragma unroll
-  for (int r = 0; r < 3; ++r) { R[r][0] = b1[r]; R[r][1] = b2[r]; R[r][2] = b3[r]; }
+    rot6d_to_rotmat(x + 6 * j, R);
   }
   float aa[3] = {0.f, 0.f, 0.f};
   if (theta) rotmat_to_aa(R, aa);
@@ -484,6 +488,44 @@ hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pos
   PrepIn in{pose, pose_ld, betas, betas_ld, nullptr, 0, mode};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, in, N, pf, Amat, posed,
                      (float*)nullptr, (float*)nullptr);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ geometry building blocks
+// lib/utils/geometry.py:68-233 and :330-344 as callers use them on their own (lib/utils/demo_utils.py:112,
+// lib/data_utils/threedpw_utils.py:98); the same device functions the prep kernel inlines.
+__global__ void __launch_bounds__(256) rotmat_to_aa_kernel(const float* __restrict__ R, int N, float* __restrict__ aa) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float M[3][3], a[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) M[r][c] = R[(long)i * 9 + 3 * r + c];
+  rotmat_to_aa(M, a);
+  aa[(long)i * 3 + 0] = a[0]; aa[(long)i * 3 + 1] = a[1]; aa[(long)i * 3 + 2] = a[2];
+}
+
+__global__ void __launch_bounds__(256) rot6d_to_rotmat_kernel(const float* __restrict__ x6, int N, float* __restrict__ R) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float M[3][3];
+  rot6d_to_rotmat(x6 + (long)i * 6, M);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[(long)i * 9 + 3 * r + c] = M[r][c];
+}
+
+hipError_t launch_rotmat_to_aa(const float* R, int N, float* aa, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rotmat_to_aa_kernel, dim3((N + 255) / 256), dim3(256), 0, s, R, N, aa);
+  return hipGetLastError();
+}
+
+hipError_t launch_rot6d_to_rotmat(const float* x6, int N, float* R, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rot6d_to_rotmat_kernel, dim3((N + 255) / 256), dim3(256), 0, s, x6, N, R);
   return hipGetLastError();
 }
 

@@ -44,10 +44,27 @@ def load_eval_db(db_path, pseudotheta_path, target_action=''):
 def load_generator_state_dict(path, map_location='cpu'):
     """checkpoint['gen_state_dict'] with a DataParallel 'module.' prefix stripped
     (evaluate.py:121-124, lib/utils/utils.py:40-45)."""
-    import torch
-    ckpt = torch.load(path, map_location=map_location)
+    ckpt = load_checkpoint(path, map_location)
     sd = ckpt['gen_state_dict'] if 'gen_state_dict' in ckpt else ckpt
     return OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in sd.items())
+
+
+def load_checkpoint(path, map_location='cpu'):
+    """torch.load for the reference's checkpoint files.  Its trainer stores `performance` as the np.float64 that
+    evaluate() returns next to the state dicts, optimizer and lr_scheduler states (lib/core/trainer.py:393-404,413,503),
+    so the weights-only unpickler needs numpy's scalar / dtype reconstructors allow-listed; nothing else is admitted
+    (no weights_only=False fallback: a checkpoint is a download)."""
+    import numpy as np
+    import torch
+    allowed = [np.dtype, np.float64, np.float32, np.int64, np.ndarray]
+    try:
+        from numpy._core import multiarray as _ma            # numpy >= 2
+    except ImportError:                                      # numpy 1.x
+        from numpy.core import multiarray as _ma
+    allowed += [_ma.scalar, _ma._reconstruct]
+    allowed += [type(np.dtype(t)) for t in ('float64', 'float32', 'int64', 'int32', 'uint8', 'bool')]
+    with torch.serialization.safe_globals(allowed):
+        return torch.load(path, map_location=map_location, weights_only=True)
 
 
 def synthetic_eval_db(lengths, seed=0, joints=49):

@@ -52,7 +52,7 @@ def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('thet
         ring_n = max(T - 1, 1)
         ring = torch.empty(C, ring_n, eng.gate_width, device=dev)
         newest = torch.empty(C, eng.gate_width, device=dev)
-        pws = torch.empty(C * 2144 * 4, dtype=torch.uint8, device=dev)
+        pws = torch.empty(int(eng.lib.tepose_project_frames_workspace_bytes(eng.handle, C)), dtype=torch.uint8, device=dev)
 
         def project(frame, theta, b):
             out = newest if theta is None else ring[:, frame % ring_n]

@@ -172,9 +172,14 @@ class Engine:
                    'tepose_encoder_fwd')
         return feat
 
-    def regressor_fwd(self, feat, n_iter, J_regressor, ws_hint=None):
+    def regressor_fwd(self, feat, n_iter, J_regressor, ws_hint=None, init=(None, None, None)):
         N = feat.shape[0]
         dev = feat.device
+        init = [None if t is None else _dev_f32(t, dev) for t in init]      # per-call [N,144] / [N,10] / [N,3]
+        for t, w in zip(init, (144, 10, 3)):
+            if t is not None and tuple(t.shape) != (N, w):
+                raise ValueError('init_pose / init_shape / init_cam must be [N,144] / [N,10] / [N,3] '
+                                 '(lib/models/spin.py:240-251), got %s' % (tuple(t.shape),))
         ws = self.workspace(max(1, (N + 1) // 2), 1, dev) if ws_hint is None else ws_hint
         _, jp = self.jreg(J_regressor, dev)
         nj = 14 if J_regressor is not None else 49
@@ -185,10 +190,11 @@ class Engine:
             'kp_3d': torch.empty((N, nj, 3), dtype=torch.float32, device=dev),
             'rotmat': torch.empty((N, 24, 3, 3), dtype=torch.float32, device=dev),
         }
-        _lib.check(self.lib.tepose_regressor_fwd(
-            self.handle, feat.data_ptr(), N, int(n_iter), jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
+        _lib.check(self.lib.tepose_regressor_fwd_init(
+            self.handle, feat.data_ptr(), N, int(n_iter), *[None if t is None else t.data_ptr() for t in init], jp,
+            out['theta'].data_ptr(), out['verts'].data_ptr(),
             out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
-            self._stream()), 'tepose_regressor_fwd')
+            self._stream()), 'tepose_regressor_fwd_init')
         return out
 
     def forward(self, x, J_regressor):
@@ -293,6 +299,25 @@ class Engine:
         _lib.check(self.lib.tepose_profile_read_gru(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
                    'tepose_profile_read_gru')
         return ms.value, n.value, fl.value
+
+
+_warned_train = [False]
+
+
+def warn_if_training(module, *tensors):
+    """The HIP path is inference-only: no autograd graph is recorded and Dropout (spin.py:262-265) is never applied.
+    Outputs in train mode are therefore eval-mode outputs; say so once instead of diverging silently."""
+    if _warned_train[0]:
+        return
+    grad = torch.is_grad_enabled() and (any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors) or
+                                        any(p.requires_grad for p in module.parameters()))
+    if module.training or grad:
+        import warnings
+        _warned_train[0] = True
+        warnings.warn('tepose_amd is inference-only: outputs carry no autograd graph and Dropout is not applied'
+                      + (' (module is in train mode: call model.eval())' if module.training else '')
+                      + (' (grad is enabled: wrap the call in torch.no_grad())' if grad else ''), RuntimeWarning,
+                      stacklevel=3)
 
 
 def check_input(x):

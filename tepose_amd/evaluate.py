@@ -64,3 +64,22 @@ def gather_and_reduce(records):
     if allr is None:
         return None
     return M.reduce_records(allr) if allr.shape[0] else {}
+
+
+def gather_rank_stats(rank, seconds, lengths, mine):
+    """Per-rank load report on rank 0: wall seconds, clips, frames and the longest clip of every rank.
+    Windows of a clip are serial (evaluate.py:247-269), so a rank's time is set by its longest clip's chain of
+    lock-step window steps, not by its frame total; `seconds_max_over_mean` is the measured imbalance."""
+    row = torch.tensor([[float(rank), float(seconds), float(len(mine)), float(sum(lengths[i] for i in mine)),
+                         float(max([lengths[i] for i in mine], default=0))]], dtype=torch.float64)
+    if D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1:
+        row = row.to(torch.device('cuda', torch.cuda.current_device())) if D.dist.get_backend() == 'nccl' else row
+    allr = D.gather_records(row, dst=0)
+    if allr is None:
+        return None
+    allr = allr.cpu()
+    allr = allr[allr[:, 0].argsort()]
+    secs = allr[:, 1]
+    return {'seconds': [float(v) for v in secs], 'clips': [int(v) for v in allr[:, 2]],
+            'frames': [int(v) for v in allr[:, 3]], 'longest_clip_frames': [int(v) for v in allr[:, 4]],
+            'seconds_max_over_mean': float(secs.max() / secs.mean()) if float(secs.mean()) > 0 else 1.0}

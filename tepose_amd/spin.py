@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .engine import Engine
+from .engine import Engine, warn_if_training
 from .smpl import SMPL, SMPL_MEAN_PARAMS, SMPL_MODEL_DIR, H36M_TO_J14  # noqa: F401
 
 
@@ -43,9 +43,7 @@ class Regressor(nn.Module):
 
     def forward(self, x, init_pose=None, init_shape=None, init_cam=None, n_iter=3, is_train=False,
                 J_regressor=None):
-        if init_pose is not None or init_shape is not None or init_cam is not None:
-            raise NotImplementedError('per-call init_pose/init_shape/init_cam are not used on the TePose '
-                                      'hot path (lib/models/tepose.py:126) and are not implemented')
+        warn_if_training(self, x)
         if not x.is_cuda:
             raise RuntimeError('tepose_amd runs on MI355X only: move the model and input to a cuda device')
         x = x.float().contiguous()
@@ -53,7 +51,7 @@ class Regressor(nn.Module):
         with torch.cuda.device(x.device):
             eng.pack_regressor(self, x.device)
             use_j = J_regressor if (not is_train and J_regressor is not None) else None
-            return [eng.regressor_fwd(x, n_iter, use_j)]
+            return [eng.regressor_fwd(x, n_iter, use_j, init=(init_pose, init_shape, init_cam))]
 
 
 def warm_start_from_spin(regressor, ckpt_path):
@@ -63,7 +61,8 @@ def warm_start_from_spin(regressor, ckpt_path):
     import os
     if not ckpt_path or not os.path.isfile(ckpt_path):
         return False
-    weights = torch.load(ckpt_path, map_location='cpu')['model']
+    from .data import load_checkpoint
+    weights = load_checkpoint(ckpt_path)['model']
     regressor.load_state_dict(weights, strict=False)
     print("=> loaded pretrained model from '%s'" % ckpt_path)
     return True

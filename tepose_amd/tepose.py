@@ -12,7 +12,7 @@ import os.path as osp
 import torch
 import torch.nn as nn
 
-from .engine import Engine, check_input, regroup_outputs
+from .engine import Engine, check_input, regroup_outputs, warn_if_training
 from .smpl import BASE_DATA_DIR
 from .spin import Regressor, warm_start_from_spin
 
@@ -32,6 +32,7 @@ class TemporalEncoder(nn.Module):
         object.__setattr__(self, '_engine', _engine if _engine is not None else Engine(n_layers, hidden_size))
 
     def forward(self, x, is_train=False):
+        warn_if_training(self, x)
         x = check_input(x)
         with torch.cuda.device(x.device):
             self._engine.pack_encoder(self, x.device)
@@ -54,6 +55,7 @@ class TePose(nn.Module):
         warm_start_from_spin(self.regressor, pretrained)
 
     def forward(self, input, is_train=False, J_regressor=None):
+        warn_if_training(self, input)
         x = check_input(input)
         batch_size = x.shape[0]
         if batch_size == 0 or x.shape[1] == 0:

@@ -76,6 +76,25 @@ def test_db_split_and_checkpoint_roundtrip(tmp_path):
     assert list(only) == ['clip_01']
     # checkpoint dict of lib/core/trainer.py:393-401 with a DataParallel prefix
     sd = {'module.encoder.linear_fwd.bias': torch.ones(3), 'regressor.fc1.bias': torch.zeros(2)}
-    torch.save({'epoch': 1, 'gen_state_dict': sd, 'performance': 50.0}, tmp_path / 'model_best.pth.tar')
+    # what trainer.save_model really writes: performance is the np.float64 evaluate() returned, and the optimizer /
+    # lr_scheduler states travel along (lib/core/trainer.py:393-404,413,503)
+    lin = torch.nn.Linear(2, 2)
+    opt = torch.optim.Adam(lin.parameters(), lr=1e-4)
+    lin(torch.ones(1, 2)).sum().backward()
+    opt.step()
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode='min', factor=0.1, patience=5)
+    sched.step(np.float64(61.5))
+    torch.save({'epoch': 1, 'gen_state_dict': sd, 'performance': np.float64(50.0), 'gen_optimizer': opt.state_dict(),
+                'lr_scheduler': sched.state_dict(), 'disc_motion_state_dict': lin.state_dict(),
+                'disc_motion_optimizer': opt.state_dict()}, tmp_path / 'model_best.pth.tar')
     got = load_generator_state_dict(tmp_path / 'model_best.pth.tar')
     assert list(got) == ['encoder.linear_fwd.bias', 'regressor.fc1.bias']
+    # SPIN-style checkpoint {'model': state_dict} with a numpy scalar next to it (lib/models/tepose.py:116)
+    from tepose_amd.data import load_checkpoint
+    torch.save({'model': {'fc1.bias': torch.full((1024,), 2.0)}, 'best': np.float32(1.5)}, tmp_path / 'spin.pt')
+    assert float(load_checkpoint(tmp_path / 'spin.pt')['model']['fc1.bias'][0]) == 2.0
+    # anything else stays refused (a checkpoint is a download)
+    import fractions
+    torch.save({'gen_state_dict': sd, 'x': fractions.Fraction(1, 2)}, tmp_path / 'bad.pt')
+    with pytest.raises(Exception):
+        load_generator_state_dict(tmp_path / 'bad.pt')

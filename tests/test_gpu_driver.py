@@ -113,3 +113,25 @@ def test_cached_projections_many_clips_split_path(smpl_np):
         for k in ('theta', 'kp_3d'):
             assert a[i][k].shape == b[i][k].shape
             assert (a[i][k] - b[i][k]).abs().max() < 2e-5, (i, k)
+
+
+def test_live_stream_window_32_single_clip_vs_oracle_loop(smpl_np):
+    """BASELINE.json config 5: seqlen 32, one clip, window advancing one frame at a time with theta feedback
+    (demo.py:238-252); every step against the oracle's per-clip loop, cached and uncached drivers."""
+    from oracle import tepose_ref as O
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    L, H, T, N = 2, 128, 32, 44
+    model, state, _ = build_model(L, H, seed=17, device='cuda', smpl_np=smpl_np)
+    w = synth.synthetic_windows(1, N, 901)[0]
+    feats = [torch.from_numpy(w[:, :2048].copy())]
+    th = w[:T - 1, 2048:].copy()
+    inits = [torch.from_numpy(th)]
+    ref = O.run_clip(state, smpl_np, feats[0].numpy(), th, T, L)
+    for cache in (False, True):
+        out = run_clips(model, feats, inits, T, cache_projections=cache)[0]
+        assert out['theta'].shape == (N - T + 1, 85)
+        for k in ('verts', 'kp_3d', 'rotmat'):
+            assert (out[k].cpu() - ref[k]).abs().max() < 1e-4, (cache, k)
+        assert (out['theta'][:, :3].cpu() - ref['theta'][:, :3]).abs().max() < 1e-4
+        assert (out['theta'][:, 75:].cpu() - ref['theta'][:, 75:]).abs().max() < 1e-4

@@ -1,0 +1,69 @@
+"""GPU: bounded randomised parity sweep (the CI form of tests/_fuzz_parity.py): fixed seed, ~40 random (L, H, B, T)
+models / batches spanning every kernel family and dispatch threshold, HIP path vs the fp64 oracle -- encoder features in
+both modes for every configuration, the full forward for B <= 300 -- plus a handful of H = 1024 cases at the batch sizes
+BASELINE.json's configs use (64) and at the scaled-format thresholds (2048, 4096)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from tepose_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(L, H, B, T, seed, smpl_np, J, full):
+    from oracle import tepose_ref as O
+    from tepose_amd.testing import build_model
+    model, state, _ = build_model(L, H, seed=seed, device='cuda', smpl_np=smpl_np)
+    x = synth.synthetic_windows(B, T, seed + 1)
+    xd = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        f = model.encoder(xd)
+        ft = model.encoder(xd, is_train=True)
+        out = model(xd, J_regressor=J)[0] if full else None
+    enc, _ = O.split_state_dict(state, torch.float64)
+    with torch.no_grad():
+        rf = O.encoder_fwd(enc, torch.from_numpy(x).double(), L)
+        rft = O.encoder_fwd(enc, torch.from_numpy(x).double(), L, is_train=True)
+    e1 = (f.cpu().double() - rf).abs().max().item()
+    e2 = (ft.cpu().double() - rft).abs().max().item()
+    e3 = 0.0
+    if out is not None:
+        ref = O.tepose_fwd(state, smpl_np, x, L, J_regressor=smpl_np['J_regressor_h36m'], dtype=torch.float64)
+        e3 = max((out[k].cpu().double() - ref[k]).abs().max().item() for k in ('verts', 'kp_3d', 'rotmat', 'kp_2d'))
+    del model
+    return e1, e2, e3
+
+
+def test_random_configurations_against_fp64_oracle():
+    rng = np.random.RandomState(20261003)
+    smpl_np = synth.synthetic_smpl(0)
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    t0 = time.time()
+    worst, n = 0.0, 0
+    Bs = [1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 769, 1000, 1300, 2048, 2100, 4096, 4200]
+    for i in range(36):
+        L = int(rng.choice([1, 2, 2, 3]))
+        H = int(rng.choice([64, 100, 128, 192, 256, 320]))
+        B = int(Bs[i % len(Bs)] if i < len(Bs) else rng.choice(Bs))       # every batch class at least once
+        T = int(rng.choice([1, 2, 3, 5, 6, 8]))
+        seed = int(rng.randint(1 << 20))
+        e1, e2, e3 = _check(L, H, B, T, seed, smpl_np, J, full=B <= 300)
+        assert max(e1, e2) < 2e-5 and e3 < 1e-4, (L, H, B, T, seed, e1, e2, e3)
+        worst, n = max(worst, e1, e2, e3), n + 1
+        if time.time() - t0 > 55:                       # bounded: CI budget, the sweep order is deterministic
+            break
+    assert n >= 12, n
+    print('fuzz: %d configurations, worst abs error %.2e, %.0f s' % (n, worst, time.time() - t0))
+
+
+@pytest.mark.parametrize('B,T', [(64, 16), (64, 6), (2048, 2), (4096, 2), (37, 6), (16, 16), (128, 4)])
+def test_published_architecture_batches_against_fp64_oracle(B, T):
+    """n_layers = 2, hidden = 1024 (the published checkpoints): BASELINE.json config 2's shape (B = 64, T = 16), the
+    37-clip lock-step shape of the 3DPW-test evaluation, and the batch thresholds of the large-batch kernels."""
+    smpl_np = synth.synthetic_smpl(0)
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    e1, e2, e3 = _check(2, 1024, B, T, 5, smpl_np, J, full=B <= 128)
+    assert max(e1, e2) < 2e-5 and e3 < 1e-4, (B, T, e1, e2, e3)

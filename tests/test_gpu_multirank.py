@@ -1,0 +1,56 @@
+"""GPU: the multi-rank paths on a 1-GPU box -- two ranks share cuda:0 and talk over gloo (the collectives are the
+same calls RCCL serves on a real node).  Both entry points are started the way the driver starts them: a plain
+`python <script> --gpus 2`, which must spawn its own ranks (reference shard axis evaluate.py:214)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=timeout, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]            # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_and_they_agree():
+    B, steps = 256, 2
+    r = _run(['bench.py', '--gpus', '2', '--backend', 'gloo', '--share-device0', '--batch', str(B), '--steps', str(steps),
+              '--warmup', '1', '--no-cpu-baseline', '--no-extra'])
+    assert r['n_gpus'] == 2 and r['steps'] == steps and r['scaling'] == 'weak'
+    assert r['ranks_agree'] is True                      # every rank's probe forward on the broadcast blob
+    assert r['weight_broadcast_ms'] > 0 and r['weight_blob_MB'] > 100
+    assert len(r['per_rank']) == 2
+    assert sorted(int(x[0]) for x in r['per_rank']) == [0, 1]
+    assert sum(int(x[2]) for x in r['per_rank']) == 2 * B * steps          # N * B windows per step counted
+    assert all(x[3] == 1.0 for x in r['per_rank'])       # finite outputs on every rank
+    assert abs(r['value'] - 2 * B * steps / (r['ms_per_step'] * steps / 1e3)) < 1e-6 * r['value']
+    assert r['outputs_finite'] is True
+
+
+def test_single_rank_bench_path_is_unchanged():
+    r = _run(['bench.py', '--batch', '64', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extra'])
+    assert r['n_gpus'] == 1 and 'weight_broadcast_ms' not in r and r['outputs_finite'] is True
+
+
+def test_clip_sharded_evaluation_world2_equals_world1():
+    common = ['tools/evaluate_clips.py', '--layers', '1', '--hidden', '64', '--seqlen', '5', '--clips', '7', '--min-len', '6',
+              '--max-len', '40']
+    one = _run(common)
+    two = _run(common + ['--gpus', '2', '--backend', 'gloo', '--share-device0'])
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and one['clips'] == two['clips'] == 7
+    for k in ('mpjpe', 'mpjpe_pa', 'accel_err', 'mpvpe'):
+        # same clips, each processed whole on one rank: only the lock-step batch composition differs (rounding)
+        assert abs(one['metrics_mm'][k] - two['metrics_mm'][k]) < 1e-3, k
+    st = two['per_rank']
+    assert len(st['seconds']) == 2 and sum(st['clips']) == 7 and sum(st['frames']) == two['frames']
+    assert st['seconds_max_over_mean'] >= 1.0 and two['imbalance_max_over_mean_rank_frames'] >= 1.0

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tepose_amd import synth  # noqa: E402
 from tepose_amd.data import load_eval_db, load_generator_state_dict, split_db_into_clips, synthetic_eval_db  # noqa: E402
 from tepose_amd.distributed import imbalance, partition_clips  # noqa: E402
-from tepose_amd.evaluate import evaluate_clips, gather_and_reduce  # noqa: E402
+from tepose_amd.evaluate import evaluate_clips, gather_and_reduce, gather_rank_stats  # noqa: E402
 from tepose_amd.smpl import SMPL  # noqa: E402
 from tepose_amd.testing import build_model  # noqa: E402
 from tepose_amd.vibe import VIBE  # noqa: E402
@@ -37,7 +37,18 @@ def main():
     ap.add_argument('--min-len', type=int, default=300); ap.add_argument('--max-len', type=int, default=1800)
     ap.add_argument('--backend', default='nccl')
     ap.add_argument('--share-device0', action='store_true', help='testing only: every rank uses cuda:0 (with --backend gloo)')
+    ap.add_argument('--gpus', type=int, default=0, help='start this many ranks (one per GPU) from a plain `python` call')
+    ap.add_argument('--layers', type=int, default=2); ap.add_argument('--hidden', type=int, default=1024)
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # GPU-free parent: the ranks are children of the stock launcher (never an exec of a process that touched HIP)
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ); env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0'); env.setdefault('OMP_NUM_THREADS', '8')
+        raise SystemExit(subprocess.call(
+            [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+             '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = 0 if args.share_device0 else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
@@ -53,11 +64,11 @@ def main():
         lens = (args.min_len + (args.max_len - args.min_len) * synth.uniform01('evalclips', args.clips)).astype(int)
         db, pse = synthetic_eval_db(list(lens), seed=0)
         clips = split_db_into_clips(db, pse)
-    model, _, _ = build_model(2, 1024, seed=0, device=dev, smpl_np=smpl_np, seqlen=T)
-    vstate = synth.synthetic_vibe_state_dict(2, 1024, 1)
+    model, _, _ = build_model(args.layers, args.hidden, seed=0, device=dev, smpl_np=smpl_np, seqlen=T)
+    vstate = synth.synthetic_vibe_state_dict(args.layers, args.hidden, 1)
     mean = {'pose': vstate['regressor.init_pose'][0], 'shape': vstate['regressor.init_shape'][0],
             'cam': vstate['regressor.init_cam'][0]}
-    vibe = VIBE(seqlen=T, n_layers=2, hidden_size=1024, add_linear=True, use_residual=True, pretrained='',
+    vibe = VIBE(seqlen=T, n_layers=args.layers, hidden_size=args.hidden, add_linear=True, use_residual=True, pretrained='',
                 smpl=SMPL.from_tables(smpl_np), smpl_mean_params=mean)
     sd = vibe.state_dict()
     for k, v in vstate.items():
@@ -75,15 +86,18 @@ def main():
     t0 = time.perf_counter()
     recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=rank, world=world)
     torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    mine_s = time.perf_counter() - t0
+    el = torch.tensor([mine_s], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     res = gather_and_reduce(recs)
+    stats = gather_rank_stats(rank, mine_s, [len(c['features']) for c in clips.values()], mine)
     if rank == 0:
         frames = int(sum(len(c['features']) for c in clips.values()))
         lens = [len(c['features']) for c in clips.values()]
         out = {'clips': len(clips), 'frames': frames, 'seqlen': T, 'n_gpus': world, 'seconds': float(el.item()),
                'imbalance_max_over_mean_rank_frames': imbalance(lens, partition_clips(lens, world)),
+               'per_rank': stats,      # seconds, clips, frames and longest clip (= serial window chain) of every rank
                'frames_per_s': frames / float(el.item()), 'metrics_mm': res,
                'data': 'real' if args.db else 'synthetic db + random-init weights (metric values are meaningless)'}
         print(json.dumps(out))
