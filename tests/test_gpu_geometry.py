@@ -55,9 +55,11 @@ def test_rotmat_to_angle_axis_nan_rows_become_zero():
     from tepose_amd.geometry import rotation_matrix_to_angle_axis
     R = torch.eye(3).repeat(3, 1, 1)
     R[1] = float('nan')
-    R[2] = 0.0                                      # t3 = 1, q = (.5, 0, 0, 0): angle 0
+    R[2] = 0.0                                      # the all-zero "rotation" of a degenerate rot6d input: branch c1, y = .5
     aa = rotation_matrix_to_angle_axis(R.cuda()).cpu()
-    assert torch.equal(aa, torch.zeros(3, 3))       # geometry.py:115 pose[torch.isnan(pose)] = 0.0
+    assert torch.equal(aa[:2], torch.zeros(2, 3))   # geometry.py:115 pose[torch.isnan(pose)] = 0.0
+    from oracle import tepose_ref as O
+    assert (aa[2] - O.rotmat_to_angle_axis(R[2:3])[0]).abs().max() < 1e-6 and abs(float(aa[2, 1]) - np.pi) < 1e-6
 
 
 def test_rot6d_to_rotmat_golden_incl_degenerate_rows():
@@ -115,7 +117,10 @@ def test_regressor_kernel_on_degenerate_rot6d_rows_and_per_call_init():
         out = reg(torch.zeros(8, 2048, device='cuda'), init_pose=x6, n_iter=0)[0]
     assert np.abs(out['rotmat'].cpu().numpy().reshape(-1, 3, 3) - G['R6'][:8 * 24]).max() < 1e-6
     assert torch.isfinite(out['theta']).all() and torch.isfinite(out['verts']).all()
-    assert torch.equal(out['theta'][0, 3:6].cpu(), torch.zeros(3))    # R = 0 -> quaternion (.5,0,0,0) -> aa = 0
+    ref_aa = O.rotmat_to_angle_axis(torch.from_numpy(G['R6'][:8 * 24])).reshape(8, 72)
+    aa = out['theta'][:, 3:75].cpu()
+    assert (aa[0, :6] - ref_aa[0, :6]).abs().max() < 1e-6            # R = 0 (joint 0) and b2 = 0 (joint 1 of row 1)
+    assert np.abs(_rodrigues(aa.reshape(-1, 3).numpy()) - _rodrigues(ref_aa.reshape(-1, 3).numpy())).max() < 1e-5
 
     state = synth.synthetic_state_dict(1, 64, 3)
     _, regw = O.split_state_dict(state, torch.float64)
