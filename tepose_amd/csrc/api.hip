@@ -279,6 +279,7 @@ struct EncWs {
   // fp32 buffers too, so that every time slab starts on a swizzle period; the pad rows are never consumed); x0h / x0l: compact planes of the frames a 1-layer model's rec.l0
   // forward direction consumes
   half_t *state_hi, *state_lo, *x0h, *x0l;
+  unsigned* sync = nullptr;   // persistent recurrent kernel (gru_seq.hip): per layer 3 x 32 arrival counters, then a status word
   Planes tailF, tailR;   // relu(last forward state) [B x Hp] and relu(ytop) [B x 2Hp]: A operands of the tail linears
   size_t Bs = 0;       // rows per time slab of gf/grr/grf/sf/sr: B, or B rounded up to 16 on the split path
   struct Buf { const float* base; size_t T, B, C, poff; };   // poff: first half of its mirror inside state_hi/lo
@@ -320,6 +321,8 @@ struct EncWs {
   }
 };
 
+constexpr size_t seq_sync_words(int L) { return (size_t)L * 96 + 32; }   // multiple of 16 bytes: one memset block
+
 void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   const size_t Hp = m->Hp, BT = (size_t)B * T;
   const int L = m->L;
@@ -354,6 +357,7 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   w.x0l = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
   w.tailF = carve_planes(c, B, Hp, h3);
   w.tailR = carve_planes(c, B, 2 * Hp, h3);
+  w.sync = (unsigned*)c.f(h3 ? seq_sync_words(L) : 0);
 }
 
 struct RegWs {
@@ -896,6 +900,10 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     p = src.base + (long)slot * src.frame_stride + (long)dir * H3;
     ld = src.row_stride;
   };
+  // small batches: all T steps of a layer in one persistent launch (gru_seq.hip); its arrival counters are zeroed
+  // by a memset node in front of the first launch of every forward
+  const bool seq = h3 && !sf && w.sync && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
+  if (seq) CK(hipMemsetAsync(w.sync, 0, seq_sync_words(L) * sizeof(unsigned), s));
   for (int l = 0; l < L; ++l) {
     const bool top = l == L - 1;
     float* sf = w.sf[l & 1];
@@ -921,6 +929,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     auto goff = [&](int q) -> long { return (long)q * Bs * H3; };
 
     if (m->prof) { int rc = prof_mark(mm, s); if (rc) return rc; }
+    const bool use_seq = seq && gru_seq_ok(top ? 2 : 3, B, Hp, T);
+    GruSeqArgs sq{};
     for (int st = 0; st < T; ++st) {
       GruArgs a{};
       a.M = B; a.Hp = Hp; a.first = st == 0;
@@ -964,6 +974,26 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       a.ndir = nd;
       const size_t wp[3] = {m->fwd[l].whh_p, m->rec_r[l].whh_p, m->rec_f[l].whh_p};
       const DirW* const dw[3] = {&m->fwd[l], &m->rec_r[l], &m->rec_f[l]};
+      if (use_seq) {                       // record the step; one launch after the loop
+        for (int d = 0; d < nd; ++d) {
+          const EncWs::View vo = w.view(a.d[d].hout);
+          if (!vo.hi) return (int)hipErrorInvalidValue;
+          GruSeqStep& e = sq.st[d][st];
+          e.gi = a.d[d].gi; e.ldgi = (int)a.d[d].ldgi; e.hout = a.d[d].hout; e.ldo = (int)a.d[d].ldo;
+          e.poff = (unsigned)(vo.hi - w.state_hi); e.pkst = (unsigned)vo.kst;
+          if (st == 0) {
+            const half_t* wh = (const half_t*)(Bl + wp[d]);
+            sq.whi[d] = wh; sq.wlo[d] = wh + n128 * Hp; sq.bhh[d] = a.d[d].bhh;
+          }
+        }
+        if (st == T - 1) {
+          sq.w_kst = (long)n128 * 32; sq.phi = w.state_hi; sq.plo = w.state_lo;
+          sq.counters = w.sync + (size_t)l * 96; sq.status = w.sync + (size_t)L * 96;
+          sq.ndir = nd; sq.T = T; sq.M = B; sq.Hp = Hp;
+          CK(launch_gru_seq(sq, s));
+        }
+        continue;
+      }
       CK((hipError_t)step(a, wp, dw));
     }
     if (top) {  // forward direction of the top bi-GRU layer: one cell step from h = 0

@@ -182,6 +182,27 @@ hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s);
 hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s);
 hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s);
 int skinny_h3_max_m();
+// gru_seq.hip: all T cell steps of one layer (up to 3 directions) in one persistent launch for M <= 64 rows, W_hh
+// planes stationary in registers.  Per (direction, step): where the step's gate pre-activations come from and where
+// its new state goes (fp32 + the planes view, as GateDir); step t reads the planes step t-1 wrote.
+constexpr int kSeqMaxT = 36;             // the table travels in the kernel arguments (4 KB)
+struct GruSeqStep {
+  const float* gi; float* hout;          // gi[row*ldgi + g*Hp + j], hout[row*ldo + j]
+  int ldgi, ldo;
+  unsigned poff, pkst;                   // hout's planes: view base offset inside phi / plo (halfs), halfs between 32-column groups
+};
+struct GruSeqArgs {
+  GruSeqStep st[3][kSeqMaxT];
+  const half_t* whi[3]; const half_t* wlo[3]; long w_kst;   // W_hh planes (gate-interleaved tile order), as H3Args
+  const float* bhh[3];
+  half_t *phi, *plo;                     // state planes (hi / lo) that every poff refers to
+  unsigned* counters;                    // 3 x 32 uints, zeroed before the launch: arrivals per direction
+  unsigned* status;                      // set to 1 when a bounded wait gave up
+  int ndir, T, M, Hp;
+};
+bool gru_seq_ok(int ndir, int M, int Hp, int T);
+int gru_seq_max_m();
+hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s);
 // first cell step of a direction (h = 0: no product), writing the same outputs
 struct GateBatch { GateDir d[3]; };
 hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s, int scaled16 = 0);

@@ -1,0 +1,245 @@
+// Persistent recurrent kernel for small batches: ALL T cell steps of one GRU layer (up to 3 independent directions)
+// in ONE launch, W_hh stationary in registers.
+//
+// Why: at B <= 64 a cell step is a weight-streaming problem -- 37.7 MB of W_hh planes per 3-direction step at
+// H = 1024 -- and the step-per-launch kernels (skinny_h3.hip) re-stream them T times from the Infinity Cache
+// (10-12 us per step, 2T+1 dependent launches per forward: 57 % of the B = 1 forward, 38 % at B = 64).  The whole
+// chip's register file holds one layer's W_hh: a workgroup owns 16 hidden units of one direction = the 48 gate rows
+// r, z, n of those units x K = Hp, as fp16 hi / lo planes 196 KB at Hp = 1024 = 96 VGPRs per lane of its 8 waves
+// (each wave one eighth of K, in the lane layout of the B operand of v_mfma_f32_16x16x32_f16).  Hp / 16 workgroups
+// per direction (64 at H = 1024; 192 for a 3-direction layer, one per CU, all resident).
+//
+// Per step a workgroup: waits until every workgroup of ITS direction has published the previous state (one counter
+// per direction -- directions are independent chains, so there is no chip-wide barrier), reads that state's hi / lo
+// planes from L2 straight into MFMA A operands, runs its 3 x MT x KS x 3 MFMAs, adds the 8 waves' partial sums
+// through LDS, applies the cell update for its 16 units and publishes them (fp32 state + planes).  The same
+// arithmetic as skinny_gru_h3_kernel (three fp16 MFMAs per product, fp32 accumulate, gemm_h3.hip) with the same
+// summation order, so results are bit-identical to the step-per-launch path.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md "Valid forms", first row):
+// every handed-off byte is stored write-through (sc1: relaxed agent-scope atomic stores of 4 / 8 bytes), every
+// storing wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane adds to the direction's counter
+// (agent-scope atomic); the consumer's lane 0 polls that counter with sc1 loads, the workgroup barriers, and every
+// load of handed-off bytes is a buffer_load ... sc1 (bypasses this CU's L1, which other CUs' stores never refresh).
+// Counters are zeroed by a memset node before every launch; spins are bounded and report through a status word.
+#include "common.h"
+
+namespace tepose {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float sq_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float sq_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+}
+__device__ __forceinline__ int sq_slot(long row, int q) { return ((q ^ (int)((row >> 2) & 3)) << 3); }
+
+__device__ __forceinline__ h16x8 as_h8(u32x4 v) {
+  union { u32x4 u; h16x8 h; } c;
+  c.u = v;
+  return c.h;
+}
+
+}  // namespace
+
+// MT: 16-row tiles of the batch (M <= 16 MT); KS: K-tiles (of 32) per wave = Hp / 256.
+template <int MT, int KS>
+__global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
+  constexpr int NW = 8;
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
+  const int dir = blockIdx.z;
+  const int Hp = a.Hp, M = a.M, T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int j0 = blockIdx.x * 16;
+  const unsigned cpd = gridDim.x;                 // workgroups of this direction
+
+  // ---- W_hh slice -> registers (once): rows of the gate-interleaved tile order (ROW_GATES_TILED), this wave's K-tiles
+  h16x8 wh[KS][3], wl[KS][3];
+  {
+    const int rbase = (j0 >> 6) * 192 + ((j0 & 63) >> 5) * 96 + (j0 & 31);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const long row = rbase + g * 32 + r16;
+      const long o = row * 32 + sq_slot(row, q);
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const long ko = (long)(wave * KS + c) * a.w_kst;
+        wh[c][g] = *(const h16x8*)(a.whi[dir] + o + ko);
+        wl[c][g] = *(const h16x8*)(a.wlo[dir] + o + ko);
+      }
+    }
+  }
+
+  // ---- epilogue item of this thread: tile i, row rr of the tile, unit pair p (2 consecutive hidden units)
+  const bool item = tid < MT * 128;
+  const int ei = tid >> 7, err = (tid >> 3) & 15, ep = tid & 7;
+  const int erow = ei * 16 + err;                 // batch row
+  const int ej = j0 + 2 * ep;                     // first of the two hidden units
+  const bool live = item && erow < M;
+  float2 br = {0.f, 0.f}, bz = br, bn = br, hp = br;
+  if (live) {
+    br = *(const float2*)(a.bhh[dir] + ej);
+    bz = *(const float2*)(a.bhh[dir] + Hp + ej);
+    bn = *(const float2*)(a.bhh[dir] + 2 * Hp + ej);
+  }
+  // partial sums of (erow, ej..ej+1): MFMA D layout = lane (q' * 16 + col), register e = row q' * 4 + e
+  const int rq = err >> 2, re = err & 3;
+  const float* rbase_e = red + ((ei * 3) * 4 + re) * 64 + rq * 16 + 2 * ep;
+
+  __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.phi, 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.plo, 0, 0x7fffffff, 0x00020000);
+  unsigned* counter = a.counters + dir * 32;      // one 128-byte line per direction
+
+  for (int st = 0; st < T; ++st) {
+    const GruSeqStep& s = a.st[dir][st];
+    // gate pre-activations of this step (written by an earlier kernel: plain loads), issued before the wait
+    float2 gr = {0.f, 0.f}, gz = gr, gn = gr;
+    if (live) {
+      const float* gi = s.gi + (long)erow * s.ldgi + ej;
+      gr = *(const float2*)gi; gz = *(const float2*)(gi + Hp); gn = *(const float2*)(gi + 2 * Hp);
+    }
+    float2 hr = {0.f, 0.f}, hz = hr, hn = hr;
+    if (st > 0) {
+      // every workgroup of this direction has published step st - 1
+      if (tid == 0) {
+        const unsigned want = cpd * (unsigned)st;
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 24)) {             // give up (a workgroup of the direction is not resident / died)
+            __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      const GruSeqStep& pv = a.st[dir][st - 1];
+      const unsigned pbase = pv.poff * 2u;        // byte offset of the previous state's view inside the planes
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const long row = i * 16 + r16;
+        const unsigned ro = pbase + (unsigned)(row * 32 + sq_slot(row, q)) * 2u;
+        h16x8 ah[KS], al[KS];
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          const unsigned o = ro + (unsigned)(wave * KS + c) * pv.pkst * 2u;
+          ah[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_hi, o, 0, 16));
+          al[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_lo, o, 0, 16));
+        }
+        f32x4 acc[3], accx[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], wh[c][g], acc[g], 0, 0, 0);
+            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], wl[c][g], accx[g], 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], wh[c][g], accx[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int ee = 0; ee < 4; ++ee)
+            red[((wave * MT * 3 + i * 3 + g) * 4 + ee) * 64 + lane] = acc[g][ee] + accx[g][ee] * (1.f / kLoScale);
+      }
+      __syncthreads();
+      if (live) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float* rp = rbase_e + (long)w * MT * 3 * 256;
+          const float2 vr = *(const float2*)rp, vz = *(const float2*)(rp + 256), vn = *(const float2*)(rp + 512);
+          hr.x += vr.x; hr.y += vr.y; hz.x += vz.x; hz.y += vz.y; hn.x += vn.x; hn.y += vn.y;
+        }
+      }
+    }
+    if (live) {
+      float hv[2];
+      {
+        const float rg = sq_sigmoid(gr.x + (hr.x + br.x));
+        const float zg = sq_sigmoid(gz.x + (hz.x + bz.x));
+        const float ng = sq_tanh(gn.x + rg * (hn.x + bn.x));
+        hv[0] = (1.f - zg) * ng + zg * hp.x;
+      }
+      {
+        const float rg = sq_sigmoid(gr.y + (hr.y + br.y));
+        const float zg = sq_sigmoid(gz.y + (hz.y + bz.y));
+        const float ng = sq_tanh(gn.y + rg * (hn.y + bn.y));
+        hv[1] = (1.f - zg) * ng + zg * hp.y;
+      }
+      hp.x = hv[0]; hp.y = hv[1];
+      // publish: fp32 state (8 bytes) and its planes (4 + 4 bytes), all write-through
+      union { float f[2]; unsigned long long u; } pk;
+      pk.f[0] = hv[0]; pk.f[1] = hv[1];
+      __hip_atomic_store((unsigned long long*)(s.hout + (long)erow * s.ldo + ej), pk.u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      half_t h0, l0, h1, l1;
+      split_hi_lo(hv[0], h0, l0);
+      split_hi_lo(hv[1], h1, l1);
+      union { h16x2 h; unsigned u; } ph, pl;
+      ph.h = h16x2{h0, h1}; pl.h = h16x2{l0, l1};
+      const long o = (long)s.poff + (long)(ej >> 5) * s.pkst + plane_index(erow, ej & 31, 0);
+      __hip_atomic_store((unsigned*)(a.phi + o), ph.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((unsigned*)(a.plo + o), pl.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (st + 1 < T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+      __syncthreads();                                      // (also: `red` is free for the next step)
+      if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int MT>
+static hipError_t launch_mt(const GruSeqArgs& a, dim3 grid, hipStream_t s) {
+  switch (a.Hp / 256) {
+    case 1: hipLaunchKernelGGL((gru_seq_kernel<MT, 1>), grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((gru_seq_kernel<MT, 2>), grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((gru_seq_kernel<MT, 3>), grid, dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((gru_seq_kernel<MT, 4>), grid, dim3(512), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+int gru_seq_max_m() {
+  static const int v = [] {
+    const char* e = getenv("TEPOSE_SEQ_MAX_M");      // 0 disables the persistent recurrent kernel (A/B runs)
+    const int x = e ? atoi(e) : 64;
+    return x > 64 ? 64 : x;
+  }();
+  return v;
+}
+
+// usable for this layer shape on this device?  Every workgroup must be resident at once (one per CU).
+bool gru_seq_ok(int ndir, int M, int Hp, int T) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  return M >= 1 && M <= gru_seq_max_m() && T >= 2 && T <= kSeqMaxT && Hp % 256 == 0 && Hp <= 1024 && ndir >= 1 &&
+         ndir <= 3 && ndir * (Hp / 16) <= cus;
+}
+
+hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s) {
+  if (!gru_seq_ok(a.ndir, a.M, a.Hp, a.T)) return hipErrorInvalidValue;
+  const dim3 grid(a.Hp / 16, 1, a.ndir);
+  if (a.M <= 16) return launch_mt<1>(a, grid, s);
+  if (a.M <= 32) return launch_mt<2>(a, grid, s);
+  return launch_mt<4>(a, grid, s);
+}
+
+}  // namespace tepose

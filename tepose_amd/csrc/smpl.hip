@@ -115,6 +115,7 @@ hipError_t launch_csr_build(const float* dense, int rows, int cols, int* ptr, in
 // ------------------------------------------------------------------ per-person prep
 // geometry.py:191-233 on M = R^T, then :118-157.
 __device__ __forceinline__ void rotmat_to_aa(const float R[3][3], float aa[3]) {
+#pragma clang fp contract(off)   // same op sequence and roundings as the reference's elementwise torch ops
   const float m00 = R[0][0], m01 = R[1][0], m02 = R[2][0];
   const float m10 = R[0][1], m11 = R[1][1], m12 = R[2][1];
   const float m20 = R[0][2], m21 = R[1][2], m22 = R[2][2];
@@ -143,6 +144,7 @@ __device__ __forceinline__ void rotmat_to_aa(const float R[3][3], float aa[3]) {
 
 // geometry.py:330-344: x.view(-1,3,2): a1 = x[0::2], a2 = x[1::2]; F.normalize(v, eps=1e-6) = v / max(|v|, 1e-6)
 __device__ __forceinline__ void rot6d_to_rotmat(const float* __restrict__ x, float R[3][3]) {
+#pragma clang fp contract(off)   // the reference rounds every product (torch elementwise ops): no fused a2 - dp * b1
   const float a1[3] = {x[0], x[2], x[4]};
   const float a2[3] = {x[1], x[3], x[5]};
   const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-6f);
