@@ -49,6 +49,7 @@ struct tepose_model {
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
+  size_t wlfr_p = 0;                            // planes of [W_lf | W_lr] ([2048][3Hp]): eval mode's (y_fwd + y_rec)/2 as ONE product
   // regressor offsets
   size_t w1a = 0, b1 = 0, w1b = 0, w2 = 0, b2 = 0, wdec = 0, bdec = 0, init = 0;
   size_t w1a_p = 0, w1b_p = 0, w2_p = 0, wdec_p = 0, blendW_p = 0;   // blocked hi|lo planes (split path)
@@ -149,6 +150,7 @@ void layout(tepose_model* m) {
   }
   m->wlf_p = take(cur, (size_t)kFeat * Hp);
   m->wlr_p = take(cur, (size_t)kFeat * 2 * Hp);
+  m->wlfr_p = take(cur, (size_t)kFeat * 3 * Hp);
   layout_tail(m, cur);
 }
 
@@ -280,7 +282,8 @@ struct EncWs {
   // forward direction consumes
   half_t *state_hi, *state_lo, *x0h, *x0l;
   unsigned* sync = nullptr;   // persistent recurrent kernel (gru_seq.hip): per layer 3 x 32 arrival counters, then a status word
-  Planes tailF, tailR;   // relu(last forward state) [B x Hp] and relu(ytop) [B x 2Hp]: A operands of the tail linears
+  Planes tailA, tailF, tailR;   // [relu(last forward state) | relu(ytop)] = [B x 3Hp], A operand of the tail linears; tailF /
+                                // tailR: its K-tile ranges [0, Hp/32) and [Hp/32, 3Hp/32)
   size_t Bs = 0;       // rows per time slab of gf/grr/grf/sf/sr: B, or B rounded up to 16 on the split path
   struct Buf { const float* base; size_t T, B, C, poff; };   // poff: first half of its mirror inside state_hi/lo
   Buf bufs[9]; int nbufs = 0;
@@ -355,8 +358,13 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   w.state_lo = (half_t*)c.f(h3 ? w.plane_halfs / 2 + 64 : 0);
   w.x0h = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
   w.x0l = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
-  w.tailF = carve_planes(c, B, Hp, h3);
-  w.tailR = carve_planes(c, B, 2 * Hp, h3);
+  w.tailA = carve_planes(c, B, 3 * Hp, h3);
+  w.tailF = w.tailA;
+  w.tailR = w.tailA;
+  if (h3 && w.tailA.hi) {
+    w.tailR.hi = w.tailA.hi + (size_t)(Hp / 32) * w.tailA.kst;
+    w.tailR.lo = w.tailA.lo + (size_t)(Hp / 32) * w.tailA.kst;
+  }
   w.sync = (unsigned*)c.f(h3 ? seq_sync_words(L) : 0);
 }
 
@@ -671,6 +679,16 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
   CK((hipError_t)pack(t[3], 1, kFeat, 1, B + m->blr, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
   CK((hipError_t)planes_of(B + m->wlf, kFeat, Hp, B + m->wlf_p, s));
   CK((hipError_t)planes_of(B + m->wlr, kFeat, 2 * Hp, B + m->wlr_p, s));
+  {  // [W_lf | W_lr] side by side along K: K-tiles [0, Hp/32) from linear_fwd, the rest from linear_rec
+    half_t* hi = (half_t*)(B + m->wlfr_p);
+    half_t* lo = hi + (size_t)kFeat * 3 * Hp;
+    const long kst = (long)kFeat * 32;
+    PackArgs a1{t[0], H, kFeat, H, nullptr, kFeat, Hp, hi, lo, kst, ROW_PLAIN, COL_PLAIN, H, Hp};
+    CK(launch_pack(a1, s));
+    PackArgs a2{t[2], 2 * H, kFeat, 2 * H, nullptr, kFeat, 2 * Hp, hi + (size_t)(Hp / 32) * kst, lo + (size_t)(Hp / 32) * kst,
+                kst, ROW_PLAIN, COL_SPLIT2, H, Hp};
+    CK(launch_pack(a2, s));
+  }
   m->enc_packed = true;
   return write_header(m, s);
 }
@@ -813,7 +831,7 @@ int prof_mark(tepose_model* mm, hipStream_t s) {     // next event of the GRU-in
 }
 
 int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_train, float* feat, EncWs& w,
-                 hipStream_t s) {
+                 hipStream_t s, const Planes* feat_planes = nullptr) {
   tepose_model* mm = const_cast<tepose_model*>(m);
   const int L = m->L, Hp = m->Hp;
   const float* Bl = m->blob;
@@ -902,6 +920,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   };
   // small batches: all T steps of a layer in one persistent launch (gru_seq.hip); its arrival counters are zeroed
   // by a memset node in front of the first launch of every forward
+  bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
   const bool seq = h3 && !sf && w.sync && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
   if (seq) CK(hipMemsetAsync(w.sync, 0, seq_sync_words(L) * sizeof(unsigned), s));
   for (int l = 0; l < L; ++l) {
@@ -990,13 +1009,28 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           sq.w_kst = (long)n128 * 32; sq.phi = w.state_hi; sq.plo = w.state_lo;
           sq.counters = w.sync + (size_t)l * 96; sq.status = w.sync + (size_t)L * 96;
           sq.ndir = nd; sq.T = T; sq.M = B; sq.Hp = Hp;
+          sq.rhi = w.tailA.hi; sq.rlo = w.tailA.lo; sq.r_kst = (unsigned)w.tailA.kst;
+          sq.r_off[0] = sq.r_off[1] = sq.r_off[2] = sq.x_roff = kNoPlane;
+          if (top) {
+            // relu(final states) straight into the tail product's A planes: [fwd | rec forward | rec reverse]
+            sq.r_off[0] = 0;
+            sq.r_off[1] = (unsigned)((size_t)(2 * Hp / 32) * w.tailA.kst);
+            // the top layer's forward direction of gru_rec: one cell step from h = 0 (element-wise), same launch
+            const EncWs::View vy = w.view(w.ytop);
+            if (!vy.hi) return (int)hipErrorInvalidValue;
+            sq.x_gi = l == 0 ? src.single : grf; sq.x_ldgi = l == 0 ? (int)src.single_ld : H3;
+            sq.x_bhh = Bl + m->rec_f[l].bhh; sq.x_hout = w.ytop; sq.x_ldo = 2 * Hp;
+            sq.x_poff = (unsigned)(vy.hi - w.state_hi); sq.x_pkst = (unsigned)vy.kst;
+            sq.x_roff = (unsigned)((size_t)(Hp / 32) * w.tailA.kst);
+            tail_planes_done = true;
+          }
           CK(launch_gru_seq(sq, s));
         }
         continue;
       }
       CK((hipError_t)step(a, wp, dw));
     }
-    if (top) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
+    if (top && !use_seq) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
       GruArgs a{};
       a.M = B; a.Hp = Hp; a.first = 1; a.ndir = 1;
       GruDir& d = a.d[0];
@@ -1019,13 +1053,15 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
   const float* hlast = w.pf[(T - 1) & 1];
   if (h3) {
-    CK(launch_split_planes(hlast, Hp, B, Hp, Hp, B, w.tailF.hi, w.tailF.lo, s, 1));
-    CK(launch_split_planes(w.ytop, 2 * Hp, B, 2 * Hp, 2 * Hp, B, w.tailR.hi, w.tailR.lo, s, 1));
+    if (!tail_planes_done) {
+      CK(launch_split_planes(hlast, Hp, B, Hp, Hp, B, w.tailF.hi, w.tailF.lo, s, 1));
+      CK(launch_split_planes(w.ytop, 2 * Hp, B, 2 * Hp, 2 * Hp, B, w.tailR.hi, w.tailR.lo, s, 1));
+    }
     if (!is_train) {
-      CK((hipError_t)h3_mm(w.tailF, Bl + m->wlf_p, kFeat, Hp, w.y1, kFeat, Bl + m->blf, B, kFeat, nullptr, 0, 0.f,
-                           nullptr, s));
-      CK((hipError_t)h3_mm(w.tailR, Bl + m->wlr_p, kFeat, 2 * Hp, feat, kFeat, Bl + m->blr, B, kFeat, w.y1, kFeat,
-                           0.5f, nullptr, s));
+      // (y_fwd + y_rec) / 2 = ([relu(h_fwd) | relu(y_rec0)] [W_lf | W_lr]^T + b_lf + b_lr) / 2: one product, K = 3Hp
+      // (b_lr rides in as an addend row with stride 0)
+      CK((hipError_t)h3_mm(w.tailA, Bl + m->wlfr_p, kFeat, 3 * Hp, feat, kFeat, Bl + m->blf, B, kFeat, Bl + m->blr, 0,
+                           0.5f, feat_planes, s));
     } else {
       CK((hipError_t)h3_mm(w.tailF, Bl + m->wlf_p, kFeat, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat, nullptr, 0,
                            0.f, nullptr, s));
@@ -1053,6 +1089,15 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
 }  // namespace
 
 
+namespace {
+int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
+                     void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes);
+int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
+                   const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta, float* verts,
+                   float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream,
+                   bool feat_planes_ready);
+}  // namespace
+
 int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward) {
   if (!m || !total_ms || !n_forwards || !flops_per_forward) return TEPOSE_E_ARG;
   double tot = 0.0;
@@ -1073,6 +1118,15 @@ int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, 
 
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {
+  return encoder_fwd_impl(m, x, B, T, is_train, feat, workspace, ws_bytes, stream, nullptr, nullptr);
+}
+
+namespace {
+// feat_planes: also leave the feature as hi / lo planes there (the regressor's first A operand), when that region does
+// not overlap a buffer the tail product still reads
+int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
+                     void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes) {
+  if (wrote_planes) *wrote_planes = false;
   if (!m || m->kind != 0 || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
   if ((size_t)B * T > (1u << 30) / 4) return TEPOSE_E_SHAPE;
@@ -1123,7 +1177,14 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
       b.p[0] = H3Args{xh, xl, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT,
                       ld0};
       b.n = 1;
-      CK(launch_gemm_h3(b, s));
+      // few rows (live stream, a handful of clips): the width-first kernel streams the 79 MB of W_ih planes with
+      // N / 48 = 192 workgroups instead of 72 tiles of 128 rows
+      static const int g0_skinny_max = [] {
+        const char* e = getenv("TEPOSE_G0_SKINNY_MAX_M");
+        return e ? atoi(e) : 128;
+      }();
+      if (BT <= g0_skinny_max) CK(launch_skinny_gemm_h3(b.p[0], s));
+      else CK(launch_gemm_h3(b, s));
     } else {
       GemmArgs g = gemm(w.xp, kInputP, Bl + m->wih0, kInputP, w.g0, ld0, Bl + m->bih0, (int)BT, ld0);
       CK(launch_gemm(g, s));
@@ -1151,8 +1212,16 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
   }
 
   G0Src src{w.g0, ld0, (long)T * ld0, 0, 0, nullptr, 0, w.g0c, H3};
-  return encoder_core(m, src, B, T, is_train, feat, w, s);
+  if (feat_planes) {
+    // live at tail time: the tail product's A planes and the fp32 final states; everything carved before them is dead
+    const char* end = (const char*)(feat_planes->lo + (size_t)B * kFeat + 128);
+    const char* first_live = (const char*)(L >= 2 ? w.gf : w.pf[0]);
+    if (!h3 || is_train || end > first_live) feat_planes = nullptr;
+  }
+  if (wrote_planes) *wrote_planes = feat_planes != nullptr;
+  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes);
 }
+}  // namespace
 
 size_t tepose_project_frames_workspace_bytes(const tepose_model* m, int B) {
   if (!m || B < 1) return 0;
@@ -1220,6 +1289,15 @@ int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, i
                               const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta,
                               float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                               void* stream) {
+  return regressor_impl(m, feat, N, n_iter, init_pose, init_shape, init_cam, jreg_packed, theta, verts, kp_3d, kp_2d,
+                        rotmat, workspace, ws_bytes, stream, false);
+}
+
+namespace {
+int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
+                   const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta, float* verts,
+                   float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream,
+                   bool feat_planes_ready) {
   if (!m || !feat || !theta || !verts || !kp_3d || !kp_2d || !rotmat || !workspace || N < 1 || n_iter < 0)
     return TEPOSE_E_ARG;
   if (!m->reg_packed || !m->smpl_packed) return TEPOSE_E_STATE;
@@ -1231,7 +1309,7 @@ int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, i
   const float* Bl = m->blob;
   // xc = cat[x, pose, shape, cam]; fc1(xc) = x W1a^T + b1 (iteration-invariant) + state W1b^T
   if (w.split_fc) {
-    CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
+    if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     CK((hipError_t)h3_mm(w.featP, Bl + m->w1a_p, 1024, kFeat, w.base, 1024, Bl + m->b1, N, 1024, nullptr, 0, 0.f,
                          nullptr, s));
     CK(init_state(Bl + m->init, init_pose, init_shape, init_cam, w.xs, N, s));
@@ -1277,6 +1355,7 @@ int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, i
   CK(launch_smpl_joints(sc, jreg_packed ? &jr : nullptr, verts, w.posed, w.xs, N, kp_3d, kp_2d, s));
   return 0;
 }
+}  // namespace
 
 int tepose_forward(const tepose_model* m, const float* x, int B, int T, const void* jreg_packed, float* theta,
                    float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
@@ -1287,10 +1366,17 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
   float* feat = (float*)workspace;
   char* rest = (char*)workspace + align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
   const size_t rest_bytes = ws_bytes - (size_t)(rest - (char*)workspace);
-  int rc = tepose_encoder_fwd(m, x, B, T, 0, feat, rest, rest_bytes, stream);
+  // the regressor's first A operand (planes of the feature) is written by the encoder's tail product
+  RegWs rw;
+  {
+    Carver c(rest, rest_bytes);
+    carve_regressor(m, B, c, rw);
+  }
+  bool wrote = false;
+  int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, rw.split_fc ? &rw.featP : nullptr, &wrote);
   if (rc) return rc;
-  return tepose_regressor_fwd(m, feat, B, 3, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest, rest_bytes,
-                              stream);
+  return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
+                        rest_bytes, stream, wrote);
 }
 
 int tepose_metrics_joints(const float* pred, const float* target, int N, int J, int pelvis_mode, float* mpjpe,

@@ -199,7 +199,17 @@ struct GruSeqArgs {
   unsigned* counters;                    // 3 x 32 uints, zeroed before the launch: arrivals per direction
   unsigned* status;                      // set to 1 when a bounded wait gave up
   int ndir, T, M, Hp;
+  // optional single cell step from h = 0 of one more direction (the top bi-GRU layer's forward direction consumes only
+  // its first step, tepose.py:80), done by direction 0's workgroups before their loop; x_gi == nullptr: none
+  const float* x_gi; const float* x_bhh; float* x_hout;
+  int x_ldgi, x_ldo;
+  unsigned x_poff, x_pkst;
+  // optional relu(final state) planes = the A operand of the tail linears: view offsets inside rhi / rlo per
+  // direction (and for the extra step), kNoPlane = none; r_kst halfs between 32-column groups
+  half_t *rhi, *rlo;
+  unsigned r_off[3], x_roff, r_kst;
 };
+constexpr unsigned kNoPlane = 0xffffffffu;
 bool gru_seq_ok(int ndir, int M, int Hp, int T);
 int gru_seq_max_m();
 hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s);

@@ -13,8 +13,8 @@
 // per direction -- directions are independent chains, so there is no chip-wide barrier), reads that state's hi / lo
 // planes from L2 straight into MFMA A operands, runs its 3 x MT x KS x 3 MFMAs, adds the 8 waves' partial sums
 // through LDS, applies the cell update for its 16 units and publishes them (fp32 state + planes).  The same
-// arithmetic as skinny_gru_h3_kernel (three fp16 MFMAs per product, fp32 accumulate, gemm_h3.hip) with the same
-// summation order, so results are bit-identical to the step-per-launch path.
+// arithmetic as skinny_gru_h3_kernel (three fp16 MFMAs per product, fp32 accumulate, gemm_h3.hip); only the grouping
+// of the K partial sums differs (8 waves instead of 4).
 //
 // Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md "Valid forms", first row):
 // every handed-off byte is stored write-through (sc1: relaxed agent-scope atomic stores of 4 / 8 bytes), every
@@ -23,6 +23,10 @@
 // load of handed-off bytes is a buffer_load ... sc1 (bypasses this CU's L1, which other CUs' stores never refresh).
 // Counters are zeroed by a memset node before every launch; spins are bounded and report through a status word.
 #include "common.h"
+
+#ifndef TEPOSE_SEQ_ABL
+#define TEPOSE_SEQ_ABL 0   // timing-only ablations (wrong results): 1 no state loads, 2 no MFMA, 4 no wait, 8 no drain/arrive, 16 plain loads
+#endif
 
 namespace tepose {
 
@@ -40,6 +44,15 @@ __device__ __forceinline__ float sq_tanh(float x) {
   return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
 }
 __device__ __forceinline__ int sq_slot(long row, int q) { return ((q ^ (int)((row >> 2) & 3)) << 3); }
+
+// two consecutive values of one row as hi / lo plane pairs (4 bytes each)
+__device__ __forceinline__ void store_planes2(half_t* hi, half_t* lo, float v0, float v1) {
+  half_t h0, l0, h1, l1;
+  split_hi_lo(v0, h0, l0);
+  split_hi_lo(v1, h1, l1);
+  *(h16x2*)hi = h16x2{h0, h1};
+  *(h16x2*)lo = h16x2{l0, l1};
+}
 
 __device__ __forceinline__ h16x8 as_h8(u32x4 v) {
   union { u32x4 u; h16x8 h; } c;
@@ -94,6 +107,24 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   const int rq = err >> 2, re = err & 3;
   const float* rbase_e = red + ((ei * 3) * 4 + re) * 64 + rq * 16 + 2 * ep;
 
+  // ---- the extra direction's single step from h = 0 (element-wise; consumed by later kernels only: plain stores)
+  if (dir == 0 && a.x_gi && live) {
+    const float* gi = a.x_gi + (long)erow * a.x_ldgi + ej;
+    const float2 gr = *(const float2*)gi, gz = *(const float2*)(gi + Hp), gn = *(const float2*)(gi + 2 * Hp);
+    const float2 xr = *(const float2*)(a.x_bhh + ej), xz = *(const float2*)(a.x_bhh + Hp + ej),
+                 xn = *(const float2*)(a.x_bhh + 2 * Hp + ej);
+    float hv[2];
+    hv[0] = (1.f - sq_sigmoid(gz.x + xz.x)) * sq_tanh(gn.x + sq_sigmoid(gr.x + xr.x) * xn.x);
+    hv[1] = (1.f - sq_sigmoid(gz.y + xz.y)) * sq_tanh(gn.y + sq_sigmoid(gr.y + xr.y) * xn.y);
+    *(float2*)(a.x_hout + (long)erow * a.x_ldo + ej) = float2{hv[0], hv[1]};
+    const long po = (long)(ej >> 5) * a.x_pkst + plane_index(erow, ej & 31, 0);
+    store_planes2(a.phi + a.x_poff + po, a.plo + a.x_poff + po, hv[0], hv[1]);
+    if (a.x_roff != kNoPlane) {
+      const long ro = (long)a.x_roff + (long)(ej >> 5) * a.r_kst + plane_index(erow, ej & 31, 0);
+      store_planes2(a.rhi + ro, a.rlo + ro, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f));
+    }
+  }
+
   __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.phi, 0, 0x7fffffff, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.plo, 0, 0x7fffffff, 0x00020000);
   unsigned* counter = a.counters + dir * 32;      // one 128-byte line per direction
@@ -109,7 +140,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
     float2 hr = {0.f, 0.f}, hz = hr, hn = hr;
     if (st > 0) {
       // every workgroup of this direction has published step st - 1
-      if (tid == 0) {
+      if (tid == 0 && !(TEPOSE_SEQ_ABL & 4)) {
         const unsigned want = cpd * (unsigned)st;
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -131,12 +162,25 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
 #pragma unroll
         for (int c = 0; c < KS; ++c) {
           const unsigned o = ro + (unsigned)(wave * KS + c) * pv.pkst * 2u;
+#if TEPOSE_SEQ_ABL & 1
+          ah[c] = as_h8(u32x4{o, o, o, o}); al[c] = ah[c];
+#elif TEPOSE_SEQ_ABL & 16
+          ah[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_hi, o, 0, 0));
+          al[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_lo, o, 0, 0));
+#else
           ah[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_hi, o, 0, 16));
           al[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_lo, o, 0, 16));
+#endif
         }
         f32x4 acc[3], accx[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#if TEPOSE_SEQ_ABL & 2
+#pragma unroll
+        for (int c = 0; c < KS; ++c)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) { acc[g][0] += (float)ah[c][0] * (float)wh[c][g][0]; accx[g][0] += (float)al[c][0] * (float)wl[c][g][0]; }
+#else
 #pragma unroll
         for (int c = 0; c < KS; ++c) {
 #pragma unroll
@@ -148,6 +192,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
           for (int g = 0; g < 3; ++g)
             accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], wh[c][g], accx[g], 0, 0, 0);
         }
+#endif
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -192,11 +237,15 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
       const long o = (long)s.poff + (long)(ej >> 5) * s.pkst + plane_index(erow, ej & 31, 0);
       __hip_atomic_store((unsigned*)(a.phi + o), ph.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store((unsigned*)(a.plo + o), pl.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (st == T - 1 && a.r_off[dir] != kNoPlane) {        // relu(final state): the tail linear's A operand
+        const long ro = (long)a.r_off[dir] + (long)(ej >> 5) * a.r_kst + plane_index(erow, ej & 31, 0);
+        store_planes2(a.rhi + ro, a.rlo + ro, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f));
+      }
     }
     if (st + 1 < T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+      if (!(TEPOSE_SEQ_ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
       __syncthreads();                                      // (also: `red` is free for the next step)
-      if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && !(TEPOSE_SEQ_ABL & 8)) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
