@@ -324,7 +324,14 @@ struct EncWs {
   }
 };
 
-constexpr size_t seq_sync_words(int L) { return (size_t)L * 96 + 32; }   // multiple of 16 bytes: one memset block
+// Arrival counters of the persistent kernels (gru_seq.hip, reg_seq.hip), ONE block zeroed by one memset node per
+// forward.  It is the first carve of the encoder's and of the regressor's workspace, so that inside tepose_forward
+// (both share one region) it is the same memory: [L x 3 x 32 recurrent arrivals | 32 status | 3 x 32 regressor | 32 status].
+inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32; }
+inline unsigned* sync_gru(unsigned* sy, int l) { return sy + (size_t)l * 96; }
+inline unsigned* sync_gru_status(const tepose_model* m, unsigned* sy) { return sy + (size_t)m->L * 96; }
+inline unsigned* sync_reg(const tepose_model* m, unsigned* sy) { return sy + (size_t)m->L * 96 + 32; }
+inline unsigned* sync_reg_status(const tepose_model* m, unsigned* sy) { return sy + (size_t)m->L * 96 + 32 + 96; }
 
 void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   const size_t Hp = m->Hp, BT = (size_t)B * T;
@@ -332,6 +339,7 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   const bool h3 = m->split && B > split_min_m();
   const size_t Bs = h3 ? (size_t)round_up(B, 16) : (size_t)B, BTs = Bs * T;
   w.Bs = Bs;
+  w.sync = (unsigned*)c.f(sync_words(m));
   w.xp = c.f(BT * kInputP);
   w.g0 = c.f(BT * (L >= 2 ? 9 : 6) * Hp);
   w.g0c = c.f(L >= 2 ? 0 : (size_t)B * 3 * Hp);
@@ -365,10 +373,10 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
     w.tailR.hi = w.tailA.hi + (size_t)(Hp / 32) * w.tailA.kst;
     w.tailR.lo = w.tailA.lo + (size_t)(Hp / 32) * w.tailA.kst;
   }
-  w.sync = (unsigned*)c.f(h3 ? seq_sync_words(L) : 0);
 }
 
 struct RegWs {
+  unsigned* sync;                  // see sync_words()
   float *base, *h1, *h2, *xs, *pf, *amat, *posed, *vposed;
   bool split, split_fc;            // split-mode handle with N > 4 rows: blend-shape GEMM / FC stack on the fp16x3 kernels
   Planes featP, xsP, h1P, h2P, pfP;
@@ -377,6 +385,7 @@ struct RegWs {
 void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
   w.split = m->split && N > split_min_m();
   w.split_fc = w.split;            // h3_mm picks the width-first kernel for <= 768 rows, 256-row tiles above
+  w.sync = (unsigned*)c.f(sync_words(m));
   w.featP = carve_planes(c, N, kFeat, w.split_fc);
   w.xsP = carve_planes(c, N, kState, w.split_fc);
   w.h1P = carve_planes(c, N, 1024, w.split_fc);
@@ -430,9 +439,7 @@ int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long
 // v_posed = v_template + shapedirs beta + posedirs^T pose_feature as one GEMM, K = 224
 int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
   const float* Bl = m->blob;
-  if (w.split) {
-    hipError_t e = launch_split_planes(w.pf, kBlendK, N, kBlendK, kBlendK, N, w.pfP.hi, w.pfP.lo, s);
-    if (e != hipSuccess) return (int)e;
+  if (w.split) {      // the prep kernel wrote the pose-feature planes next to the fp32 rows
     return h3_mm(w.pfP, Bl + m->blendW_p, kBlendN, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV, nullptr, 0, 0.f,
                  nullptr, s);
   }
@@ -831,7 +838,7 @@ int prof_mark(tepose_model* mm, hipStream_t s) {     // next event of the GRU-in
 }
 
 int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_train, float* feat, EncWs& w,
-                 hipStream_t s, const Planes* feat_planes = nullptr) {
+                 hipStream_t s, const Planes* feat_planes = nullptr, bool sync_zeroed = false) {
   tepose_model* mm = const_cast<tepose_model*>(m);
   const int L = m->L, Hp = m->Hp;
   const float* Bl = m->blob;
@@ -922,7 +929,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   // by a memset node in front of the first launch of every forward
   bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
   const bool seq = h3 && !sf && w.sync && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
-  if (seq) CK(hipMemsetAsync(w.sync, 0, seq_sync_words(L) * sizeof(unsigned), s));
+  if (seq && !sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
   for (int l = 0; l < L; ++l) {
     const bool top = l == L - 1;
     float* sf = w.sf[l & 1];
@@ -1007,7 +1014,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         }
         if (st == T - 1) {
           sq.w_kst = (long)n128 * 32; sq.phi = w.state_hi; sq.plo = w.state_lo;
-          sq.counters = w.sync + (size_t)l * 96; sq.status = w.sync + (size_t)L * 96;
+          sq.counters = sync_gru(w.sync, l); sq.status = sync_gru_status(m, w.sync);
           sq.ndir = nd; sq.T = T; sq.M = B; sq.Hp = Hp;
           sq.rhi = w.tailA.hi; sq.rlo = w.tailA.lo; sq.r_kst = (unsigned)w.tailA.kst;
           sq.r_off[0] = sq.r_off[1] = sq.r_off[2] = sq.x_roff = kNoPlane;
@@ -1091,11 +1098,12 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
 
 namespace {
 int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
-                     void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes);
+                     void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes,
+                     bool sync_zeroed);
 int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
                    const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta, float* verts,
                    float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream,
-                   bool feat_planes_ready);
+                   bool feat_planes_ready, bool sync_zeroed);
 }  // namespace
 
 int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward) {
@@ -1118,14 +1126,15 @@ int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, 
 
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {
-  return encoder_fwd_impl(m, x, B, T, is_train, feat, workspace, ws_bytes, stream, nullptr, nullptr);
+  return encoder_fwd_impl(m, x, B, T, is_train, feat, workspace, ws_bytes, stream, nullptr, nullptr, false);
 }
 
 namespace {
 // feat_planes: also leave the feature as hi / lo planes there (the regressor's first A operand), when that region does
 // not overlap a buffer the tail product still reads
 int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
-                     void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes) {
+                     void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes,
+                     bool sync_zeroed) {
   if (wrote_planes) *wrote_planes = false;
   if (!m || m->kind != 0 || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
@@ -1219,7 +1228,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
     if (!h3 || is_train || end > first_live) feat_planes = nullptr;
   }
   if (wrote_planes) *wrote_planes = feat_planes != nullptr;
-  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes);
+  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes, sync_zeroed);
 }
 }  // namespace
 
@@ -1290,14 +1299,14 @@ int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, i
                               float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                               void* stream) {
   return regressor_impl(m, feat, N, n_iter, init_pose, init_shape, init_cam, jreg_packed, theta, verts, kp_3d, kp_2d,
-                        rotmat, workspace, ws_bytes, stream, false);
+                        rotmat, workspace, ws_bytes, stream, false, false);
 }
 
 namespace {
 int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
                    const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta, float* verts,
                    float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream,
-                   bool feat_planes_ready) {
+                   bool feat_planes_ready, bool sync_zeroed) {
   if (!m || !feat || !theta || !verts || !kp_3d || !kp_2d || !rotmat || !workspace || N < 1 || n_iter < 0)
     return TEPOSE_E_ARG;
   if (!m->reg_packed || !m->smpl_packed) return TEPOSE_E_STATE;
@@ -1308,7 +1317,25 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   const float* Bl = m->blob;
   // xc = cat[x, pose, shape, cam]; fc1(xc) = x W1a^T + b1 (iteration-invariant) + state W1b^T
-  if (w.split_fc) {
+  if (w.split_fc && N <= reg_seq_max_n()) {
+    // small batches: the whole FC loop in one persistent launch (reg_seq.hip)
+    if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
+    if (!sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
+    RegSeqArgs ra{};
+    ra.fh = w.featP.hi; ra.fl = w.featP.lo; ra.f_kst = w.featP.kst;
+    const half_t* p;
+    p = (const half_t*)(Bl + m->w1a_p); ra.w1a_h = p; ra.w1a_l = p + (size_t)1024 * kFeat;
+    p = (const half_t*)(Bl + m->w1b_p); ra.w1b_h = p; ra.w1b_l = p + (size_t)1024 * kState;
+    p = (const half_t*)(Bl + m->w2_p); ra.w2_h = p; ra.w2_l = p + (size_t)1024 * 1024;
+    p = (const half_t*)(Bl + m->wdec_p); ra.wd_h = p; ra.wd_l = p + (size_t)256 * 1024;
+    ra.b1 = Bl + m->b1; ra.b2 = Bl + m->b2; ra.bdec = Bl + m->bdec;
+    ra.init160 = Bl + m->init; ra.ipose = init_pose; ra.ishape = init_shape; ra.icam = init_cam;
+    ra.h1h = w.h1P.hi; ra.h1l = w.h1P.lo; ra.h2h = w.h2P.hi; ra.h2l = w.h2P.lo; ra.h_kst = w.h1P.kst;
+    ra.xh = w.xsP.hi; ra.xl = w.xsP.lo; ra.x_kst = w.xsP.kst;
+    ra.xs = w.xs; ra.counters = sync_reg(m, w.sync); ra.status = sync_reg_status(m, w.sync);
+    ra.N = N; ra.n_iter = n_iter;
+    CK(launch_reg_seq(ra, s));
+  } else if (w.split_fc) {
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     CK((hipError_t)h3_mm(w.featP, Bl + m->w1a_p, 1024, kFeat, w.base, 1024, Bl + m->b1, N, 1024, nullptr, 0, 0.f,
                          nullptr, s));
@@ -1344,7 +1371,8 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
   sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
   sc.xr_val = Bl + m->smpl.xr_val;
-  CK(launch_smpl_prep(sc, w.xs, N, w.pf, w.amat, w.posed, rotmat, theta, s));
+  CK(launch_smpl_prep(sc, w.xs, N, w.pf, w.amat, w.posed, rotmat, theta, s, w.split ? w.pfP.hi : nullptr,
+                      w.split ? w.pfP.lo : nullptr, w.pfP.kst));
   CK((hipError_t)blend_shapes(m, w, N, s));
   CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
   JregPacked jr{};
@@ -1372,11 +1400,13 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
     Carver c(rest, rest_bytes);
     carve_regressor(m, B, c, rw);
   }
+  if (!rw.sync) return TEPOSE_E_WORKSPACE;
+  CK(hipMemsetAsync(rw.sync, 0, sync_words(m) * sizeof(unsigned), (hipStream_t)stream));   // every arrival counter of this forward
   bool wrote = false;
-  int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, rw.split_fc ? &rw.featP : nullptr, &wrote);
+  int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, rw.split_fc ? &rw.featP : nullptr, &wrote, true);
   if (rc) return rc;
   return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
-                        rest_bytes, stream, wrote);
+                        rest_bytes, stream, wrote, true);
 }
 
 int tepose_metrics_joints(const float* pred, const float* target, int N, int J, int pelvis_mode, float* mpjpe,
@@ -1417,7 +1447,8 @@ int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, cons
   carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
-  CK(launch_smpl_prep_pose(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, N, w.pf, w.amat, w.posed, s));
+  CK(launch_smpl_prep_pose(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, N, w.pf, w.amat, w.posed, s,
+                           w.split ? w.pfP.hi : nullptr, w.split ? w.pfP.lo : nullptr, w.pfP.kst));
   CK((hipError_t)blend_shapes(m, w, N, s));
   CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
   if (joints49) CK(launch_smpl_joints(sc, nullptr, verts, w.posed, nullptr, N, joints49, nullptr, s));
@@ -1434,7 +1465,8 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
   carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
-  CK(launch_smpl_prep_pose(sc, 1, theta + 3, kTheta, theta + 75, kTheta, N, w.pf, w.amat, nullptr, s));
+  CK(launch_smpl_prep_pose(sc, 1, theta + 3, kTheta, theta + 75, kTheta, N, w.pf, w.amat, nullptr, s,
+                           w.split ? w.pfP.hi : nullptr, w.split ? w.pfP.lo : nullptr, w.pfP.kst));
   CK((hipError_t)blend_shapes(m, w, N, s));
   CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
   return 0;

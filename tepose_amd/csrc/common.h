@@ -108,11 +108,13 @@ struct SmplConsts {              // device pointers into the packed blob
 struct JregPacked {              // CSR of the optional 17-row evaluation regressor
   const int* ptr; const int* idx; const float* val;
 };
+// pf_hi / pf_lo: optionally also write the pose-feature rows as blocked planes (view base, pf_kst halfs between 32-column groups)
 hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
-                            float* posed, float* rotmat, float* theta, hipStream_t s);
+                            float* posed, float* rotmat, float* theta, hipStream_t s, void* pf_hi = nullptr,
+                            void* pf_lo = nullptr, long pf_kst = 0);
 hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pose, int pose_ld,
                                  const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
-                                 hipStream_t s);
+                                 hipStream_t s, void* pf_hi = nullptr, void* pf_lo = nullptr, long pf_kst = 0);
 hipError_t launch_lbs_compact(const float* lbsW, int* cidx, float* cval, int* max_nnz, hipStream_t s);
 hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
                             float* verts, hipStream_t s);
@@ -210,6 +212,21 @@ struct GruSeqArgs {
   unsigned r_off[3], x_roff, r_kst;
 };
 constexpr unsigned kNoPlane = 0xffffffffu;
+// reg_seq.hip: the regressor's FC loop (fc1 / fc2 / decoders x n_iter) for N <= 64 rows in one persistent launch
+struct RegSeqArgs {
+  const half_t *fh, *fl; long f_kst;     // feature planes [N x 2048]
+  const half_t *w1a_h, *w1a_l, *w1b_h, *w1b_l, *w2_h, *w2_l, *wd_h, *wd_l;   // weight planes ([1024] rows; decoders [256])
+  const float *b1, *b2, *bdec;
+  const float *init160, *ipose, *ishape, *icam;   // model means [160]; optional per-call rows [N,144] / [N,10] / [N,3]
+  half_t *h1h, *h1l, *h2h, *h2l; long h_kst;      // exchange planes [N x 1024]
+  half_t *xh, *xl; long x_kst;                    // state planes [N x 160]
+  float* xs;                                      // final state [N][160]
+  unsigned* counters;                             // 3 x 32 uints, zeroed before the launch
+  unsigned* status;
+  int N, n_iter;
+};
+int reg_seq_max_n();
+hipError_t launch_reg_seq(const RegSeqArgs& a, hipStream_t s);
 bool gru_seq_ok(int ndir, int M, int Hp, int T);
 int gru_seq_max_m();
 hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s);

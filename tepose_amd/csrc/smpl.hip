@@ -169,7 +169,15 @@ struct PrepIn {
   const float* betas; int betas_ld;   // 10 per row
   const float* cam; int cam_ld;       // 3 per row or nullptr (only copied into theta)
   int mode;
+  half_t *pf_hi, *pf_lo; long pf_kst; // optional: the pose-feature row also as hi / lo planes (the blend-shape product's A operand)
 };
+__device__ __forceinline__ void pf_put(const PrepIn& in, float* f, long p, int col, float v) {
+  f[col] = v;
+  if (in.pf_hi) {
+    const long o = (long)(col >> 5) * in.pf_kst + plane_index(p, col & 31, 0);
+    split_hi_lo(v, in.pf_hi[o], in.pf_lo[o]);
+  }
+}
 __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth, PrepIn in, int N,
                                                         float* __restrict__ pf, float* __restrict__ Amat,
                                                         float* __restrict__ posed,
@@ -270,13 +278,13 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) f[11 + 9 * (j - 1) + 3 * r + cc] = R[r][cc] - (r == cc ? 1.f : 0.f);
+        for (int cc = 0; cc < 3; ++cc) pf_put(in, f, p, 11 + 9 * (j - 1) + 3 * r + cc, R[r][cc] - (r == cc ? 1.f : 0.f));
     } else {
-      f[0] = 1.f;
+      pf_put(in, f, p, 0, 1.f);
 #pragma unroll
-      for (int l = 0; l < 10; ++l) { f[1 + l] = beta[l]; if (th) th[75 + l] = beta[l]; }
+      for (int l = 0; l < 10; ++l) { pf_put(in, f, p, 1 + l, beta[l]); if (th) th[75 + l] = beta[l]; }
 #pragma unroll
-      for (int l = 218; l < kBlendK; ++l) f[l] = 0.f;
+      for (int l = 218; l < kBlendK; ++l) pf_put(in, f, p, l, 0.f);
       if (th && in.cam) { const float* cm = in.cam + (long)p * in.cam_ld; th[0] = cm[0]; th[1] = cm[1]; th[2] = cm[2]; }
     }
   }
@@ -474,9 +482,10 @@ hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const f
 }
 
 hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* pf, float* Amat,
-                            float* posed, float* rotmat, float* theta, hipStream_t s) {
+                            float* posed, float* rotmat, float* theta, hipStream_t s, void* pf_hi, void* pf_lo,
+                            long pf_kst) {
   if (N <= 0) return hipSuccess;
-  PrepIn in{xs, kState, xs + kNPose, kState, xs + 154, kState, 0};
+  PrepIn in{xs, kState, xs + kNPose, kState, xs + 154, kState, 0, (half_t*)pf_hi, (half_t*)pf_lo, pf_kst};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, in, N, pf, Amat,
                      posed, rotmat, theta);
   return hipGetLastError();
@@ -485,9 +494,9 @@ hipError_t launch_smpl_prep(const SmplConsts& c, const float* xs, int N, float* 
 // mode 1: pose = axis-angle [N,72]; mode 2: pose = rotation matrices [N,24,3,3]
 hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pose, int pose_ld,
                                  const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
-                                 hipStream_t s) {
+                                 hipStream_t s, void* pf_hi, void* pf_lo, long pf_kst) {
   if (N <= 0) return hipSuccess;
-  PrepIn in{pose, pose_ld, betas, betas_ld, nullptr, 0, mode};
+  PrepIn in{pose, pose_ld, betas, betas_ld, nullptr, 0, mode, (half_t*)pf_hi, (half_t*)pf_lo, pf_kst};
   hipLaunchKernelGGL(smpl_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c, c.maxdepth, in, N, pf, Amat, posed,
                      (float*)nullptr, (float*)nullptr);
   return hipGetLastError();
