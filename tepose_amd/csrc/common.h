@@ -210,6 +210,7 @@ struct GruSeqArgs {
   // direction (and for the extra step), kNoPlane = none; r_kst halfs between 32-column groups
   half_t *rhi, *rlo;
   unsigned r_off[3], x_roff, r_kst;
+  unsigned long long* stamps;            // diagnostic builds (-DTEPOSE_SEQ_STAMPS): per-step wall-clock stamps of one workgroup
 };
 constexpr unsigned kNoPlane = 0xffffffffu;
 // reg_seq.hip: the regressor's FC loop (fc1 / fc2 / decoders x n_iter) for N <= 64 rows in one persistent launch

@@ -28,6 +28,14 @@
 #define TEPOSE_SEQ_ABL 0   // timing-only ablations (wrong results): 1 no state loads, 2 no MFMA, 4 no wait, 8 no drain/arrive, 16 plain loads
 #endif
 
+#ifdef TEPOSE_SEQ_STAMPS
+#define SEQ_STAMP(k) do { if (a.stamps && blockIdx.x == 5 && tid == 0) a.stamps[((long)dir * kSeqMaxT + st) * 8 + (k)] = wall_clock64(); } while (0)
+#define SEQ_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define SEQ_STAMP(k) do { } while (0)
+#define SEQ_DRAIN() do { } while (0)
+#endif
+
 namespace tepose {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -67,6 +75,8 @@ template <int MT, int KS>
 __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   constexpr int NW = 8;
   __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
+  // this direction's step table: a kernel-argument read per step is a scalar-cache miss (~0.7 us) on the critical path
+  __shared__ __attribute__((aligned(16))) GruSeqStep tab[kSeqMaxT];
   const int dir = blockIdx.z;
   const int Hp = a.Hp, M = a.M, T = a.T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,6 +84,11 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   const int j0 = blockIdx.x * 16;
   const unsigned cpd = gridDim.x;                 // workgroups of this direction
 
+  {
+    const unsigned* src = (const unsigned*)&a.st[dir][0];
+    unsigned* dst = (unsigned*)tab;
+    for (int i = threadIdx.x; i < (int)(a.T * sizeof(GruSeqStep) / 4); i += 512) dst[i] = src[i];
+  }
   // ---- W_hh slice -> registers (once): rows of the gate-interleaved tile order (ROW_GATES_TILED), this wave's K-tiles
   h16x8 wh[KS][3], wl[KS][3];
   {
@@ -94,7 +109,8 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   // ---- epilogue item of this thread: tile i, row rr of the tile, unit pair p (2 consecutive hidden units)
   const bool item = tid < MT * 128;
   const int ei = tid >> 7, err = (tid >> 3) & 15, ep = tid & 7;
-  const int erow = ei * 16 + err;                 // batch row
+  const int m0 = blockIdx.y * (MT * 16);          // first batch row of this workgroup (row slices are independent chains)
+  const int erow = m0 + ei * 16 + err;            // batch row
   const int ej = j0 + 2 * ep;                     // first of the two hidden units
   const bool live = item && erow < M;
   float2 br = {0.f, 0.f}, bz = br, bn = br, hp = br;
@@ -127,10 +143,11 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
 
   __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.phi, 0, 0x7fffffff, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.plo, 0, 0x7fffffff, 0x00020000);
-  unsigned* counter = a.counters + dir * 32;      // one 128-byte line per direction
+  unsigned* counter = a.counters + dir * 32 + blockIdx.y * 16;   // one per (direction, row slice)
+  __syncthreads();                                // `tab` is filled
 
   for (int st = 0; st < T; ++st) {
-    const GruSeqStep& s = a.st[dir][st];
+    const GruSeqStep s = tab[st];
     // gate pre-activations of this step (written by an earlier kernel: plain loads), issued before the wait
     float2 gr = {0.f, 0.f}, gz = gr, gn = gr;
     if (live) {
@@ -138,6 +155,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
       gr = *(const float2*)gi; gz = *(const float2*)(gi + Hp); gn = *(const float2*)(gi + 2 * Hp);
     }
     float2 hr = {0.f, 0.f}, hz = hr, hn = hr;
+    SEQ_STAMP(0);
     if (st > 0) {
       // every workgroup of this direction has published step st - 1
       if (tid == 0 && !(TEPOSE_SEQ_ABL & 4)) {
@@ -151,27 +169,36 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
           }
         }
       }
+      SEQ_STAMP(1);
       __syncthreads();
-      const GruSeqStep& pv = a.st[dir][st - 1];
-      const unsigned pbase = pv.poff * 2u;        // byte offset of the previous state's view inside the planes
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const long row = i * 16 + r16;
+      SEQ_STAMP(2);
+      const unsigned pbase = tab[st - 1].poff * 2u;   // byte offset of the previous state's view inside the planes
+      const unsigned pkst2 = tab[st - 1].pkst * 2u;
+      // A operands of tile i + 1 are in flight while tile i's MFMAs run (a tile's loads take ~1 us through L2)
+      h16x8 ah[2][KS], al[2][KS];
+      auto load_tile = [&](int i, h16x8 (&h)[KS], h16x8 (&l)[KS]) {
+        const long row = m0 + i * 16 + r16;
         const unsigned ro = pbase + (unsigned)(row * 32 + sq_slot(row, q)) * 2u;
-        h16x8 ah[KS], al[KS];
 #pragma unroll
         for (int c = 0; c < KS; ++c) {
-          const unsigned o = ro + (unsigned)(wave * KS + c) * pv.pkst * 2u;
+          const unsigned o = ro + (unsigned)(wave * KS + c) * pkst2;
 #if TEPOSE_SEQ_ABL & 1
-          ah[c] = as_h8(u32x4{o, o, o, o}); al[c] = ah[c];
+          h[c] = as_h8(u32x4{o, o, o, o}); l[c] = h[c];
 #elif TEPOSE_SEQ_ABL & 16
-          ah[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_hi, o, 0, 0));
-          al[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_lo, o, 0, 0));
+          h[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_hi, o, 0, 0));
+          l[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_lo, o, 0, 0));
 #else
-          ah[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_hi, o, 0, 16));
-          al[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_lo, o, 0, 16));
+          h[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_hi, o, 0, 16));
+          l[c] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rs_lo, o, 0, 16));
 #endif
         }
+      };
+      load_tile(0, ah[0], al[0]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i + 1 < MT) load_tile(i + 1, ah[(i + 1) & 1], al[(i + 1) & 1]);
+        const h16x8 (&xh)[KS] = ah[i & 1];
+        const h16x8 (&xl)[KS] = al[i & 1];
         f32x4 acc[3], accx[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -179,18 +206,18 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
 #pragma unroll
         for (int c = 0; c < KS; ++c)
 #pragma unroll
-          for (int g = 0; g < 3; ++g) { acc[g][0] += (float)ah[c][0] * (float)wh[c][g][0]; accx[g][0] += (float)al[c][0] * (float)wl[c][g][0]; }
+          for (int g = 0; g < 3; ++g) { acc[g][0] += (float)xh[c][0] * (float)wh[c][g][0]; accx[g][0] += (float)xl[c][0] * (float)wl[c][g][0]; }
 #else
 #pragma unroll
         for (int c = 0; c < KS; ++c) {
 #pragma unroll
           for (int g = 0; g < 3; ++g) {
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], wh[c][g], acc[g], 0, 0, 0);
-            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], wl[c][g], accx[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[c], wh[c][g], acc[g], 0, 0, 0);
+            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[c], wl[c][g], accx[g], 0, 0, 0);
           }
 #pragma unroll
           for (int g = 0; g < 3; ++g)
-            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], wh[c][g], accx[g], 0, 0, 0);
+            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[c], wh[c][g], accx[g], 0, 0, 0);
         }
 #endif
 #pragma unroll
@@ -199,7 +226,10 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
           for (int ee = 0; ee < 4; ++ee)
             red[((wave * MT * 3 + i * 3 + g) * 4 + ee) * 64 + lane] = acc[g][ee] + accx[g][ee] * (1.f / kLoScale);
       }
+      SEQ_DRAIN();
+      SEQ_STAMP(3);
       __syncthreads();
+      SEQ_STAMP(4);
       if (live) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -242,10 +272,13 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
         store_planes2(a.rhi + ro, a.rlo + ro, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f));
       }
     }
+    SEQ_STAMP(5);
     if (st + 1 < T) {
       if (!(TEPOSE_SEQ_ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+      SEQ_STAMP(6);
       __syncthreads();                                      // (also: `red` is free for the next step)
       if (tid == 0 && !(TEPOSE_SEQ_ABL & 8)) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      SEQ_STAMP(7);
     }
   }
 }
@@ -271,23 +304,43 @@ int gru_seq_max_m() {
   return v;
 }
 
-// usable for this layer shape on this device?  Every workgroup must be resident at once (one per CU).
-bool gru_seq_ok(int ndir, int M, int Hp, int T) {
+static int device_cus() {
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     return n;
   }();
+  return cus;
+}
+
+// usable for this layer shape on this device?  Every workgroup must be resident at once (one per CU).
+bool gru_seq_ok(int ndir, int M, int Hp, int T) {
+  const int cus = device_cus();
   return M >= 1 && M <= gru_seq_max_m() && T >= 2 && T <= kSeqMaxT && Hp % 256 == 0 && Hp <= 1024 && ndir >= 1 &&
          ndir <= 3 && ndir * (Hp / 16) <= cus;
 }
 
-hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s) {
+hipError_t launch_gru_seq(const GruSeqArgs& a0, hipStream_t s) {
+  GruSeqArgs a = a0;
+#ifdef TEPOSE_SEQ_STAMPS
+  {
+    const char* e = getenv("TEPOSE_SEQ_STAMP_PTR");     // device buffer of 3 * kSeqMaxT * 8 uint64 (tools/seq_stamps.py)
+    a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
+  }
+#else
+  a.stamps = nullptr;
+#endif
   if (!gru_seq_ok(a.ndir, a.M, a.Hp, a.T)) return hipErrorInvalidValue;
-  const dim3 grid(a.Hp / 16, 1, a.ndir);
+  dim3 grid(a.Hp / 16, 1, a.ndir);
   if (a.M <= 16) return launch_mt<1>(a, grid, s);
   if (a.M <= 32) return launch_mt<2>(a, grid, s);
+  // 33..64 rows: a step is bound by the 4 KB per row of state planes every workgroup reads.  Where the chip has room
+  // (a 2-direction layer at H = 1024: 128 workgroups), two workgroups share a unit slice and take 32 rows each.
+  if ((int)grid.x * a.ndir * 2 <= device_cus()) {
+    grid.y = 2;
+    return launch_mt<2>(a, grid, s);
+  }
   return launch_mt<4>(a, grid, s);
 }
 
