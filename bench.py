@@ -50,17 +50,44 @@ def synthetic_windows_device(B, T, seed, device):
 
 
 def pmc_traffic(B, T, split):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes of this same command (profiles/rNN_traffic_{split,exact}.json; FETCH_SIZE x2 + WRITE_SIZE,
-    MI355X_MICROARCH.md HBM section).  None when the workload differs from the profiled one."""
+    """(bytes, provenance): HBM-side bytes per launch of the dominant kernel.  NOT measured in this run -- PMC counters
+    need their own rocprofv3 passes -- but read from the newest committed pass of this same command
+    (profiles/rNN_traffic_{split,exact}.json; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section).
+    (None, reason) when the workload differs from the profiled one."""
     import glob
     if (B, T) != (8192, 16):
-        return None
+        return None, 'no PMC pass committed for this batch / window length'
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic_%s.json' % ('split' if split else 'exact'))))
     if not files:
-        return None
+        return None, 'no PMC pass committed'
     with open(files[-1]) as f:
-        return json.load(f).get('traffic_bytes_per_launch')
+        d = json.load(f)
+    return d.get('traffic_bytes_per_launch'), ('constant from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, '
+                                               'FETCH x2-corrected; not collected in this run)' % os.path.relpath(files[-1], ROOT))
+
+
+# every weight of the published architecture (n_layers=2, hidden=1024) touched once, fp32-equivalent bytes (the fp16 hi + lo
+# planes are the same 4 bytes per element): W_ih / W_hh of the consumed directions and layers, tail linears, regressor FCs,
+# blend-shape table, skin weights
+WEIGHT_BYTES = 4.0 * (3 * 3072 * 2133 + 3 * 3072 * 1024 + 3072 * 1024 + 2 * 3072 * 2048 + 2 * 3072 * 1024 +
+                      2048 * 1024 + 2048 * 2048 + 1024 * 2205 + 1024 * 1024 + 157 * 1024 + 20670 * 218) + 6890 * 4 * 8.0
+
+
+def small_batch_roofline(b, t, ms):
+    """A forward of a few windows is neither HBM- nor MFMA-bound: it is a chain of 2T dependent recurrent steps plus a
+    dozen dependent launches.  Both roofline fractions, with the bytes / FLOPs they are priced on."""
+    bytes_min = WEIGHT_BYTES + b * (t * 2133 * 4.0 + 85 * 4 + 6890 * 12 + 14 * 20 + 216 * 4)
+    gbps = bytes_min / (ms * 1e-3) / 1e9
+    out = {'ms_per_forward': ms, 'windows_per_s': b / ms * 1e3,
+           'algorithmic_bytes': bytes_min, 'achieved_GBps': gbps, 'frac_of_hbm_8TBps': gbps / 8000.0,
+           'dependent_recurrent_steps': 2 * t, 'us_per_dependent_step_if_all_time_were_steps': ms * 1e3 / (2 * t)}
+    if t in GFLOP_PER_WINDOW:
+        tf = b * GFLOP_PER_WINDOW[t] / (ms * 1e-3) / 1e3
+        out['algorithmic_tflops'] = tf
+        out['frac_of_split_mfma_peak'] = tf / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS)
+    out['bound'] = 'latency (2T-step recurrence; weights read once: byte floor %.0f us, MFMA floor %.0f us)' % (
+        bytes_min / 8e12 * 1e6, b * GFLOP_PER_WINDOW.get(t, 0) * 1e9 / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS * 1e12) * 1e6)
+    return out
 
 
 def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=None):
@@ -255,7 +282,7 @@ def main():
             'value': windows / t_max, 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if (os.environ.get('TEPOSE_EXACT_FP32', '0') not in ('', '0') or B <= 4) else
+            'dtype': 'f32' if os.environ.get('TEPOSE_EXACT_FP32', '0') not in ('', '0') else
                      'f32 in/out/accumulate; matmul products as 3 fp16 MFMAs on the hi+lo fp16 halves of each fp32 '
                      'operand (22 significant bits per operand; measured closer to fp64 than the fp32 MFMA chain); '
                      'TEPOSE_EXACT_FP32=1 = every product on the fp32 MFMA, reported here as exact_fp32_mode',
@@ -269,13 +296,15 @@ def main():
         if T in GFLOP_PER_WINDOW:
             res['whole_path_tflops'] = windows * GFLOP_PER_WINDOW[T] / t_max / 1e3
             res['whole_path_frac_of_f32_mfma_peak'] = res['whole_path_tflops'] / (PEAK_F32_MFMA_TFLOPS * world)   # > 1 is possible in split mode
-        split = os.environ.get('TEPOSE_EXACT_FP32', '0') in ('', '0') and B > 4
+        split = os.environ.get('TEPOSE_EXACT_FP32', '0') in ('', '0')
         if k_n > 0:
             ach = k_flops / (k_ms / k_n * 1e-3) / 1e12
             if split:
                 peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
+                tr, tr_src = pmc_traffic(B, T, True)
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                                   'traffic': pmc_traffic(B, T, True),
+                                   'traffic': tr, 'traffic_source': tr_src,
+                                   'algorithmic_bytes': float(B * T) * 2133 * 4 + 9216.0 * 2133 * 4 + float(B * T) * 9216 * 4,
                                    'kernel': 'gemm_h3s_kernel (single-accumulator split GEMM, 256x256 tiles; layer-0 input projection, M=%d N=9216 K=2133)'
                                              % (B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n,
@@ -284,8 +313,9 @@ def main():
                                            'MFMA %.1f / %d; executed MFMA rate = %.0f TFLOP/s'
                                            % (SPLIT_PRODUCTS, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS, ach * SPLIT_PRODUCTS)}
             else:
+                tr, tr_src = pmc_traffic(B, T, False)
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                   'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(B, T, False),
+                                   'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': tr, 'traffic_source': tr_src,
                                    'kernel': 'gemm_f32_kernel<false> (layer-0 input projection, M=%d N=9216 K=2133)'
                                              % (B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n}
@@ -328,8 +358,8 @@ def main():
         if world == 1 and not args.no_extra:
             # the other BASELINE.json shapes, outside the timed region (informational, not `value`)
             extra = {}
-            for name, (b, t, reps) in {'b64_T16': (64, 16, 50), 'b1_T16': (1, 16, 200), 'b1_T32_stream': (1, 32, 200),
-                                       'b1_T6': (1, 6, 200)}.items():
+            for name, (b, t, reps) in {'cfgB_b64_T16': (64, 16, 100), 'cfgA_b1_T16': (1, 16, 300), 'cfgE_b1_T32_stream': (1, 32, 300),
+                                       'b1_T6': (1, 6, 300), 'b37_T6_3dpw_lockstep': (37, 6, 100)}.items():
                 xe = synthetic_windows_device(b, t, 77, device)
                 with torch.no_grad():
                     for _ in range(5):
@@ -340,7 +370,11 @@ def main():
                         model(xe, J_regressor=J)
                     torch.cuda.synchronize()
                 ms = (time.perf_counter() - te) / reps * 1e3
-                extra[name] = {'ms_per_forward': ms, 'windows_per_s': b / ms * 1e3}
+                extra[name] = small_batch_roofline(b, t, ms)
+            extra['note'] = ('BASELINE.json configs 1 / 2 / 5 (synthetic stand-ins: random-init weights, synthetic features; the '
+                             'licence-gated 3DPW data and repr_wpw_3dpw checkpoint are absent, so MPJPE vs that checkpoint is '
+                             'UNMEASURED); the recurrent layers and the regressor loop run as persistent kernels '
+                             '(csrc/gru_seq.hip, csrc/reg_seq.hip)')
             res['other_shapes'] = extra
             _t('other shapes done')
         if world == 1 and not args.no_cpu_baseline:

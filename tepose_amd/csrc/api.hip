@@ -57,6 +57,8 @@ struct tepose_model {
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
   bool split = true;                            // batches of more than split_min_m() rows run their matmuls on the fp16x3 split kernels
+  bool split_env = true;                        // what the environment asked for; `split` also needs every packed weight inside
+  bool enc_range_ok = true, reg_range_ok = true, smpl_range_ok = true;   // the fp16 range (|w| < 2^15), checked at pack time
   int s_min_b = 2048;                           // scaled-format recurrent path from this batch size
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
@@ -202,10 +204,24 @@ int write_header(tepose_model* m, hipStream_t s) {
   h.magic = kBlobMagic; h.abi = TEPOSE_ABI_VERSION; h.kind = (uint32_t)m->kind; h.L = (uint32_t)m->L; h.H = (uint32_t)m->H;
   h.Hp = (uint32_t)m->Hp;
   h.sections = ((m->kind == 0 ? m->enc_packed : m->vibe_packed) ? 1u : 0u) | (m->reg_packed ? 2u : 0u) |
-               (m->smpl_packed ? 4u : 0u);
+               (m->smpl_packed ? 4u : 0u) | ((m->enc_range_ok && m->reg_range_ok && m->smpl_range_ok) ? 0u : 8u);
   h.layout_floats_lo = (uint32_t)(m->blob_floats & 0xffffffffu); h.layout_floats_hi = (uint32_t)((uint64_t)m->blob_floats >> 32);
   CK(hipMemcpyAsync(m->blob + m->hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
   CK(hipStreamSynchronize(s));                      // h is a stack object (pack time only)
+  return 0;
+}
+
+// Pack-time range guard of the split-precision path: a weight of magnitude >= 2^15 (or inf) has no fp16 hi half, so a
+// handle holding one runs every product on the exact-fp32 kernels instead (as TEPOSE_EXACT_FP32=1) -- never a silent inf.
+// One device reduction + read-back over the section's fp32 copy; pack time only.
+int range_check(tepose_model* m, size_t first, size_t end, bool* ok, hipStream_t s) {
+  float* scratch = m->blob + m->hdr + 32;
+  CK(launch_absmax(m->blob + first, end - first, scratch, s));
+  float wmax = 0.f;
+  CK(hipMemcpyAsync(&wmax, scratch, sizeof(float), hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  *ok = wmax < 32768.f;
+  m->split = m->split_env && m->enc_range_ok && m->reg_range_ok && m->smpl_range_ok;
   return 0;
 }
 
@@ -281,6 +297,7 @@ struct EncWs {
   // fp32 buffers too, so that every time slab starts on a swizzle period; the pad rows are never consumed); x0h / x0l: compact planes of the frames a 1-layer model's rec.l0
   // forward direction consumes
   half_t *state_hi, *state_lo, *x0h, *x0l;
+  float *rs = nullptr, *rs0 = nullptr;   // per-row scales of the input planes (launch_split_rows): [B*T] and, 1-layer models, [B]
   unsigned* sync = nullptr;   // persistent recurrent kernel (gru_seq.hip): per layer 3 x 32 arrival counters, then a status word
   Planes tailA, tailF, tailR;   // [relu(last forward state) | relu(ytop)] = [B x 3Hp], A operand of the tail linears; tailF /
                                 // tailR: its K-tile ranges [0, Hp/32) and [Hp/32, 3Hp/32)
@@ -366,6 +383,8 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   w.state_lo = (half_t*)c.f(h3 ? w.plane_halfs / 2 + 64 : 0);
   w.x0h = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
   w.x0l = (half_t*)c.f(h3 && L == 1 ? (size_t)B * kInputP / 2 + 64 : 0);
+  w.rs = c.f(h3 ? BT : 0);
+  w.rs0 = c.f(h3 && L == 1 ? (size_t)B : 0);
   w.tailA = carve_planes(c, B, 3 * Hp, h3);
   w.tailF = w.tailA;
   w.tailR = w.tailA;
@@ -418,14 +437,14 @@ GemmArgs gemm(const float* A, long lda, const float* W, int Kp, float* C, long l
 // C = (A W^T + bias + addend) * scale on the split-precision kernel: A as blocked planes, W = blocked planes of a
 // packed [Np][Kp] blob matrix (hi plane, then lo plane); `out`: also write C as planes (the next product's A)
 int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long ldc, const float* bias, int M, int N,
-          const float* addend, long ldadd, float scale, const Planes* out, hipStream_t s) {
+          const float* addend, long ldadd, float scale, const Planes* out, hipStream_t s, const float* row_scale = nullptr) {
   H3Batch b{};
   const half_t* wh = (const half_t*)w_planes;
   H3Args& p = b.p[0];
   p.Ah = A.hi; p.Al = A.lo; p.a_kst = A.kst;
   p.Wh = wh; p.Wl = wh + (size_t)Np * Kp; p.w_kst = (long)Np * 32; p.Kp = Kp;
   p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N;
-  p.addend = addend; p.ldadd = ldadd; p.scale = scale;
+  p.addend = addend; p.ldadd = ldadd; p.scale = scale; p.row_scale = row_scale;
   if (out) { p.Chi = out->hi; p.Clo = out->lo; p.c_kst = out->kst; }
   // few rows: width-first kernel (skinny_h3.hip), except the short-K / very wide blend-shape product, which already
   // makes 162 tiles of the big kernel
@@ -452,7 +471,7 @@ int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
 // numerics / dispatch knobs, read once per handle at creation (both model kinds)
 static void read_env_knobs(tepose_model* m) {
   const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
-  m->split = !(e && atoi(e) != 0);
+  m->split = m->split_env = !(e && atoi(e) != 0);
   e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
   m->g0_single_acc = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
@@ -529,6 +548,8 @@ int tepose_adopt_blob(tepose_model* m) {
   m->vibe_packed = m->kind == 1 && (h.sections & 1u);
   m->reg_packed = (h.sections & 2u) != 0;
   m->smpl_packed = (h.sections & 4u) != 0;
+  m->enc_range_ok = m->reg_range_ok = m->smpl_range_ok = !(h.sections & 8u);   // bit 3: a weight outside the fp16 range
+  m->split = m->split_env && m->enc_range_ok;
   m->maxdepth = kNJ - 1;   // upper bound; chain levels past the real depth are no-ops
   int max_nnz = kNJ;
   CK(hipMemcpy(&max_nnz, m->blob + m->smpl.lbs_nnz, sizeof(int), hipMemcpyDeviceToHost));   // set-up time only
@@ -567,6 +588,7 @@ int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, vo
   CK((hipError_t)pack(w[4 * L], H, kFeat, H, B + m->vlin_w, kFeat, Hp, ROW_PLAIN, COL_PLAIN, H, Hp, s));
   CK((hipError_t)pack(w[4 * L + 1], 1, kFeat, 1, B + m->vlin_b, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
   m->vibe_packed = true;
+  CK((hipError_t)range_check(m, m->vibe[0].wih, m->w1a, &m->enc_range_ok, s));
   return write_header(m, s);
 }
 
@@ -697,6 +719,7 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
     CK(launch_pack(a2, s));
   }
   m->enc_packed = true;
+  CK((hipError_t)range_check(m, m->wih0, m->wih0_p, &m->enc_range_ok, s));
   return write_header(m, s);
 }
 
@@ -729,6 +752,7 @@ int tepose_pack_regressor(tepose_model* m, const float* const* w, int n_w, void*
   CK((hipError_t)planes_of(B + m->w2, 1024, 1024, B + m->w2_p, s));
   CK((hipError_t)planes_of(B + m->wdec, 256, 1024, B + m->wdec_p, s));
   m->reg_packed = true;
+  CK((hipError_t)range_check(m, m->w1a, m->smpl.J0, &m->reg_range_ok, s));
   return write_header(m, s);
 }
 
@@ -765,6 +789,7 @@ int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shap
   CK(launch_csr_build(J_regressor_extra, 9, kNV, (int*)(B + m->smpl.xr_ptr), (int*)(B + m->smpl.xr_idx),
                       B + m->smpl.xr_val, 9 * kNV, s));
   m->smpl_packed = true;
+  CK((hipError_t)range_check(m, m->smpl.J0, m->smpl.lbs_cidx, &m->smpl_range_ok, s));
   return write_header(m, s);
 }
 
@@ -1160,8 +1185,8 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
   // large batches of an L >= 2 model: the single-accumulator kernel (its input planes carry scale 1: same fp16 range
   // as the other layout; elements below 2^-3 keep an absolute error <= 2^-25 instead of a relative one)
   const bool g0s = h3 && m->g0_single_acc && L >= 2 && BT >= 8192;
-  if (g0s) CK(launch_split_planes16(x, kInput, BT, kInput, kInputP, BT, 1.f, xh, xl, s));
-  else if (h3) CK(launch_pad_input_planes(x, xh, xl, BT, s));
+  // the caller's windows -> planes with one power-of-two scale per row (any finite fp32 magnitude; DESIGN 4b "range")
+  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s));
   else CK(launch_pad_input(x, w.xp, BT, s));
   {
     tepose_model* mm = const_cast<tepose_model*>(m);
@@ -1179,12 +1204,13 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       const size_t rows256 = (size_t)round_up(9 * Hp, 256);
       const half_t* sh = (const half_t*)(Bl + m->wih0_s);
       H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
-                Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0};
+                Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0, w.rs};
       CK(launch_gemm_h3s(a, s));
     } else if (h3) {
       H3Batch b{};
       b.p[0] = H3Args{xh, xl, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT,
                       ld0};
+      b.p[0].row_scale = w.rs;
       b.n = 1;
       // few rows (live stream, a handful of clips): the width-first kernel streams the 79 MB of W_ih planes with
       // N / 48 = 192 workgroups instead of 72 tiles of 128 rows
@@ -1208,9 +1234,10 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
     if (h3) {
       H3Batch b{};
       // frames T-1 of every window as compact planes; W rows 6Hp.. of the stacked layer-0 block
-      CK(launch_split_planes(x + (long)(T - 1) * kInput, (long)T * kInput, B, kInput, kInputP, B, w.x0h, w.x0l, s));
+      CK(launch_split_rows(x + (long)(T - 1) * kInput, (long)T * kInput, B, kInput, kInputP, B, 0, w.x0h, w.x0l, w.rs0, s));
       b.p[0] = H3Args{w.x0h, w.x0l, (long)B * 32, w0h + (size_t)6 * Hp * 32, w0l + (size_t)6 * Hp * 32,
                       (long)rows0 * 32, kInputP, w.g0c, (long)H3, Bl + m->bih0 + 6 * Hp, B, H3};
+      b.p[0].row_scale = w.rs0;
       b.n = 1;
       CK(launch_gemm_h3(b, s));
     } else {
@@ -1235,8 +1262,8 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
 size_t tepose_project_frames_workspace_bytes(const tepose_model* m, int B) {
   if (!m || B < 1) return 0;
   const size_t xbytes = align_up((size_t)B * kInputP * sizeof(float), 256);
-  // padded fp32 rows, plus their hi / lo planes when the product runs on the split-precision kernel
-  return (m->split && B > split_min_m()) ? 2 * xbytes + 512 : xbytes;
+  // padded fp32 rows, plus their hi / lo planes and per-row scales when the product runs on the split-precision kernel
+  return (m->split && B > split_min_m()) ? 2 * xbytes + 512 + align_up((size_t)B * sizeof(float), 256) : xbytes;
 }
 
 int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld, const float* theta, long theta_ld,
@@ -1253,9 +1280,10 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
     P.hi = (half_t*)((char*)workspace + xbytes);
     P.lo = (half_t*)((char*)workspace + xbytes + xbytes / 2);
     P.kst = (long)B * 32;
-    CK(launch_split_planes(xp, kInputP, B, kInputP, kInputP, B, P.hi, P.lo, s));
+    float* rs = (float*)((char*)workspace + 2 * xbytes + 512);
+    CK(launch_split_rows(xp, kInputP, B, kInputP, kInputP, B, 0, P.hi, P.lo, rs, s));
     CK((hipError_t)h3_mm(P, m->blob + m->wih0_p, round_up(9 * m->Hp, 128), kInputP, out, out_ld, m->blob + m->bih0, B,
-                         9 * m->Hp, nullptr, 0, 0.f, nullptr, s));
+                         9 * m->Hp, nullptr, 0, 0.f, nullptr, s, rs));
     return 0;
   }
   GemmArgs g = gemm(xp, kInputP, m->blob + m->wih0, kInputP, out, out_ld, m->blob + m->bih0, B, 9 * m->Hp);

@@ -166,6 +166,8 @@ struct H3Args {
   const float* addend; long ldadd;
   float scale;                        // 0 = no scaling
   half_t *Chi, *Clo; long c_kst;      // view base (row 0, column 0), halfs between 32-column groups
+  const float* row_scale;             // optional [M]: the A planes hold row m divided by row_scale[m] (launch_split_rows);
+                                      // the product of row m is multiplied back before bias / addend
 };
 struct GateDir {
   const float* gi; long ldgi;         // x W_ih^T + b_ih, [row*ldgi + g*Hp + j]
@@ -239,6 +241,13 @@ hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows
 // (relu?)src[rows][ld] fp32 (K valid columns) -> blocked planes of [R x Kp], rows < R
 hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int Kp, long R, void* hi, void* lo,
                                hipStream_t s, int relu = 0);
+// Caller-supplied rows (the [.,2133] windows) -> planes with one power-of-two scale per row: row m is stored as
+// x[m] * 2^e_m with max|x[m]| * 2^e_m in [2^13, 2^14) (zero / non-finite rows: e = 0), row_scale[m] = 2^-e_m.  Any
+// finite fp32 input is representable (no fp16 overflow at |x| >= 65504, no precision loss for tiny features); the
+// consuming product multiplies row m's result by row_scale[m].  fmt16: the scaled [K/16][R][16] format of gemm_h3s.hip
+// (hi = fp16(v), lo = fp16(v - hi)), else the blocked [K/32][R][32] format (lo = fp16((v - hi) * 2^11)).
+hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
+                             float* row_scale, hipStream_t s);
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);
@@ -256,6 +265,7 @@ struct H3SArgs {
   const float* bias;                     // [N] or nullptr
   float inv_scale;                       // 1 / (pA * pW)
   int M, N;
+  const float* row_scale;                // optional [M], as H3Args::row_scale (then pA = 1)
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s);                                // state planes a GRU step writes

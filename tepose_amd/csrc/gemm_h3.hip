@@ -88,6 +88,76 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
   return hipGetLastError();
 }
 
+// One wave per row: the row (Kp <= 64 * 2 * NP values) is read once into registers, its largest magnitude picks a
+// power-of-two scale, and the scaled row leaves as hi / lo plane pairs (4-byte stores, as split_planes_kernel).
+template <int NP, bool F16>
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ src, long ld, long rows, int K, int Kp,
+                                                         long R, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                         float* __restrict__ row_scale) {
+  typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;                                  // wave-uniform
+  const float* x = src + row * ld;
+  float v0[NP], v1[NP];
+  float m = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int k = 2 * (lane + 64 * i);
+    v0[i] = k < K ? x[k] : 0.f;
+    v1[i] = k + 1 < K ? x[k + 1] : 0.f;
+    m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));        // fmaxf drops NaN: tracked separately
+    bad |= !(fabsf(v0[i]) <= 3.0e38f) || !(fabsf(v1[i]) <= 3.0e38f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  bad = __any(bad);
+  float sc = 1.f, inv = 1.f;
+  if (m > 0.f && !bad) {
+    int ex;
+    (void)frexpf(m, &ex);                                   // m = f * 2^ex, f in [0.5, 1)
+    int e = 14 - ex;                                        // m * 2^e in [2^13, 2^14)
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    sc = ldexpf(1.f, e);
+    inv = ldexpf(1.f, -e);
+  }
+  if (lane == 0) row_scale[row] = inv;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int k = 2 * (lane + 64 * i);
+    if (k >= Kp) continue;
+    const float a0 = v0[i] * sc, a1 = v1[i] * sc;
+    if (F16) {
+      const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+      const long o = plane16_index(row, k, R);
+      *(h16x2v*)(hi + o) = h16x2v{h0, h1};
+      *(h16x2v*)(lo + o) = h16x2v{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)};
+    } else {
+      half_t h0, l0, h1, l1;
+      split_hi_lo(a0, h0, l0);
+      split_hi_lo(a1, h1, l1);
+      const long o = plane_index(row, k, R);
+      *(h16x2v*)(hi + o) = h16x2v{h0, h1};
+      *(h16x2v*)(lo + o) = h16x2v{l0, l1};
+    }
+  }
+}
+
+hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
+                             float* row_scale, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (Kp > 64 * 2 * 17 || (Kp & 1)) return hipErrorInvalidValue;        // the [., 2144] input rows
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (fmt16)
+    hipLaunchKernelGGL((split_rows_kernel<17, true>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
+                       (_Float16*)lo, row_scale);
+  else
+    hipLaunchKernelGGL((split_rows_kernel<17, false>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
+                       (_Float16*)lo, row_scale);
+  return hipGetLastError();
+}
+
 hipError_t launch_pad_input_planes(const float* x, void* hi, void* lo, long rows, hipStream_t s) {
   return launch_split_planes(x, kInput, rows, kInput, kInputP, rows, hi, lo, s);
 }
@@ -497,6 +567,7 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
 #endif
         if (row < a.M && col < a.N) {
           f32x4v v = *(const f32x4v*)(tile + rl * TC + c4 * 4);
+          if (a.row_scale) v *= a.row_scale[row];
           const int nv = min(4, a.N - col);
 #pragma unroll
           for (int c = 0; c < 4; ++c)

@@ -318,19 +318,25 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
       }
     }
   } else {
+    float bv[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
       const int col = n0 + wn * 32 * WNT + j * 32 + r;
-      if (col >= a.N) continue;
-      const float bv = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < WMF; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (row < a.M) a.C[(long)row * a.ldc + col] = acc[i][j][e] * a.inv_scale + bv;
-        }
+      bv[j] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * WMF + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= a.M) continue;
+        const float rs = a.row_scale ? a.row_scale[row] * a.inv_scale : a.inv_scale;   // per-row input scale (launch_split_rows)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          const int col = n0 + wn * 32 * WNT + j * 32 + r;
+          if (col < a.N) a.C[(long)row * a.ldc + col] = acc[i][j][e] * rs + bv[j];
+        }
+      }
   }
 }
 

@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3Args a) {
       for (int w = 0; w < NW; ++w) v += red[((w * MT * 3 + i * 3 + t) * 4 + e) * 64 + lane];
       const int row = m0 + i * 16 + q * 4 + e, col = n0 + t * 16 + r16;
       if (row < a.M && col < a.N) {
+        if (a.row_scale) v *= a.row_scale[row];
         if (a.bias) v += a.bias[col];
         if (a.addend) v += a.addend[(long)row * a.ldadd + col];
         v *= sc;

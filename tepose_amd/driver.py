@@ -9,6 +9,8 @@ clips still running.  Clips are processed longest-first, which keeps the active 
 Host side is tensor plumbing only (slice / copy on the device); every window step is one
 `TePose.forward` = one call into libtepose_hip.so.
 """
+import os
+
 import torch
 
 
@@ -44,6 +46,8 @@ def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('thet
     outs = {k: [None] * C for k in keep}
     bufs = {}
     use_cache = (C >= 4) if cache_projections == 'auto' else bool(cache_projections)     # measured crossover
+    if cache_projections == 'auto' and os.environ.get('TEPOSE_DRIVER_CACHE', '') in ('0', '1'):    # A/B and debugging
+        use_cache = os.environ['TEPOSE_DRIVER_CACHE'] == '1'
     if use_cache:
         eng = model._engine
         with torch.cuda.device(dev):

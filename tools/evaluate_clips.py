@@ -39,6 +39,8 @@ def main():
     ap.add_argument('--share-device0', action='store_true', help='testing only: every rank uses cuda:0 (with --backend gloo)')
     ap.add_argument('--gpus', type=int, default=0, help='start this many ranks (one per GPU) from a plain `python` call')
     ap.add_argument('--layers', type=int, default=2); ap.add_argument('--hidden', type=int, default=1024)
+    ap.add_argument('--as-rank', type=int, default=-1, help='debug: process the share of this rank of --of-world in ONE process')
+    ap.add_argument('--of-world', type=int, default=2)
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # GPU-free parent: the ranks are children of the stock launcher (never an exec of a process that touched HIP)
@@ -84,7 +86,10 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=rank, world=world)
+    if args.as_rank >= 0:
+        recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=args.as_rank, world=args.of_world)
+    else:
+        recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=rank, world=world)
     torch.cuda.synchronize()
     mine_s = time.perf_counter() - t0
     el = torch.tensor([mine_s], device=dev, dtype=torch.float64)
