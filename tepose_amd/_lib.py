@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('TEPOSE_AMD_LIB', os.path.join(_HERE, 'libtepose_hip.so'))   # override: A/B builds
+LIB_PATH = (os.environ.get("TEPOSE_AMD_LIB") or os.path.join(_HERE, 'libtepose_hip.so'))   # override: A/B builds
 
 # every symbol include/tepose_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

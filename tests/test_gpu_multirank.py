@@ -50,9 +50,23 @@ def test_clip_sharded_evaluation_world2_equals_world1():
     assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and one['clips'] == two['clips'] == 7
     for k in ('mpjpe', 'mpjpe_pa', 'accel_err', 'mpvpe'):
         # same clips, each processed whole on one rank: only the lock-step batch composition differs (rounding of
-        # different kernels, amplified by the theta feedback of ~35 window steps); the two ranks of this test also SHARE
-        # one GPU, which is not a deployment configuration (known issues)
-        assert abs(one['metrics_mm'][k] - two['metrics_mm'][k]) < 2e-4 * abs(one['metrics_mm'][k]) + 1e-3, k
+        # different kernels, amplified by the theta feedback of ~35 window steps)
+        assert abs(one['metrics_mm'][k] - two['metrics_mm'][k]) < 2e-5 * abs(one['metrics_mm'][k]) + 1e-3, k
     st = two['per_rank']
     assert len(st['seconds']) == 2 and sum(st['clips']) == 7 and sum(st['frames']) == two['frames']
     assert st['seconds_max_over_mean'] >= 1.0 and two['imbalance_max_over_mean_rank_frames'] >= 1.0
+
+
+def test_two_processes_sharing_the_gpu_get_bit_identical_results():
+    """Two processes on ONE GPU, each repeating every module of the small evaluation pipeline and comparing bitwise with
+    its own first result.  With packed-fp32 VALU instructions in the binary 1-3 % of the SMPL launches came back with a
+    wrong x for 16 consecutive vertices (gfx950 under context switching; DESIGN.md "shared-GPU erratum") -- the library is
+    built without them (__graft_entry__.HIPCC_EXTRA), and this must stay at zero mismatches."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    procs = [subprocess.Popen([sys.executable, 'tools/race_probe.py', ROOT, '700'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        last = [l for l in out.splitlines() if l.startswith('mismatches')][-1]
+        assert all(int(v) == 0 for v in last.replace('}', '').split(':')[1:] for v in [v.split(',')[0]]), out[-1500:]
