@@ -88,55 +88,79 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
   return hipGetLastError();
 }
 
-// One wave per row: the row (Kp <= 64 * 2 * NP values) is read once into registers, its largest magnitude picks a
-// power-of-two scale, and the scaled row leaves as hi / lo plane pairs (4-byte stores, as split_planes_kernel).
+// A block converts 8 consecutive rows.  Phase 1: wave w reads rows 2w, 2w+1 whole (NP pairs per lane and row, coalesced),
+// takes each row's largest magnitude, picks its power-of-two scale and parks the scaled row in LDS.  Phase 2: the block
+// walks the K-tiles; one wave instruction writes the 8 rows x 16 k (scaled format) or 4 rows x 32 k (blocked format) of a
+// K-tile = 256 contiguous bytes per plane (a row-at-a-time conversion writes 32-byte pieces: 1.0 vs 0.4 ms at cfg-C).
+constexpr int kRowsLd = 2148;        // LDS row stride (floats): 2144 + 4 keeps the 8 rows of a tile off each other's banks
 template <int NP, bool F16>
 __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ src, long ld, long rows, int K, int Kp,
                                                          long R, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                          float* __restrict__ row_scale) {
   typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;                                  // wave-uniform
-  const float* x = src + row * ld;
-  float v0[NP], v1[NP];
-  float m = 0.f;
-  bool bad = false;
+  __shared__ __attribute__((aligned(16))) float buf[8 * kRowsLd];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row0 = (long)blockIdx.x * 8;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int k = 2 * (lane + 64 * i);
-    v0[i] = k < K ? x[k] : 0.f;
-    v1[i] = k + 1 < K ? x[k + 1] : 0.f;
-    m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));        // fmaxf drops NaN: tracked separately
-    bad |= !(fabsf(v0[i]) <= 3.0e38f) || !(fabsf(v1[i]) <= 3.0e38f);
+  for (int rr = 0; rr < 2; ++rr) {
+    const int lr = 2 * wave + rr;
+    const long row = row0 + lr;
+    if (row >= rows) continue;                                // wave-uniform
+    const float* x = src + row * ld;
+    float v0[NP], v1[NP];
+    float m = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int k = 2 * (lane + 64 * i);
+      v0[i] = k < K ? x[k] : 0.f;
+      v1[i] = k + 1 < K ? x[k + 1] : 0.f;
+      m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));        // fmaxf drops NaN: tracked separately
+      bad |= !(fabsf(v0[i]) <= 3.0e38f) || !(fabsf(v1[i]) <= 3.0e38f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    bad = __any(bad);
+    float sc = 1.f, inv = 1.f;
+    if (m > 0.f && !bad) {
+      int ex;
+      (void)frexpf(m, &ex);                                   // m = f * 2^ex, f in [0.5, 1)
+      int e = 14 - ex;                                        // m * 2^e in [2^13, 2^14)
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      sc = ldexpf(1.f, e);
+      inv = ldexpf(1.f, -e);
+    }
+    if (lane == 0) row_scale[row] = inv;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int k = 2 * (lane + 64 * i);
+      if (k < Kp) *(float2*)(buf + lr * kRowsLd + k) = float2{v0[i] * sc, v1[i] * sc};
+    }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  bad = __any(bad);
-  float sc = 1.f, inv = 1.f;
-  if (m > 0.f && !bad) {
-    int ex;
-    (void)frexpf(m, &ex);                                   // m = f * 2^ex, f in [0.5, 1)
-    int e = 14 - ex;                                        // m * 2^e in [2^13, 2^14)
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    sc = ldexpf(1.f, e);
-    inv = ldexpf(1.f, -e);
-  }
-  if (lane == 0) row_scale[row] = inv;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int k = 2 * (lane + 64 * i);
-    if (k >= Kp) continue;
-    const float a0 = v0[i] * sc, a1 = v1[i] * sc;
-    if (F16) {
-      const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+  __syncthreads();
+  if (F16) {
+    const int lr = lane >> 3, kp = lane & 7;                  // 8 rows x 8 pairs = one 16-wide K-tile
+    const long row = row0 + lr;
+    for (int kt = wave; kt < Kp / 16; kt += 4) {
+      if (row >= rows) continue;
+      const int k = kt * 16 + 2 * kp;
+      const float2 a = *(const float2*)(buf + lr * kRowsLd + k);
+      const _Float16 h0 = (_Float16)a.x, h1 = (_Float16)a.y;
       const long o = plane16_index(row, k, R);
       *(h16x2v*)(hi + o) = h16x2v{h0, h1};
-      *(h16x2v*)(lo + o) = h16x2v{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)};
-    } else {
+      *(h16x2v*)(lo + o) = h16x2v{(_Float16)(a.x - (float)h0), (_Float16)(a.y - (float)h1)};
+    }
+  } else {
+    const int lr4 = lane >> 4, kp = lane & 15;                // 4 rows x 16 pairs = half of a 32-wide K-tile's 8 rows
+    for (int u = wave; u < 2 * (Kp / 32); u += 4) {
+      const int kt = u >> 1, lr = (u & 1) * 4 + lr4;
+      const long row = row0 + lr;
+      if (row >= rows) continue;
+      const int k = kt * 32 + 2 * kp;
+      const float2 a = *(const float2*)(buf + lr * kRowsLd + k);
       half_t h0, l0, h1, l1;
-      split_hi_lo(a0, h0, l0);
-      split_hi_lo(a1, h1, l1);
+      split_hi_lo(a.x, h0, l0);
+      split_hi_lo(a.y, h1, l1);
       const long o = plane_index(row, k, R);
       *(h16x2v*)(hi + o) = h16x2v{h0, h1};
       *(h16x2v*)(lo + o) = h16x2v{l0, l1};
@@ -147,8 +171,8 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
                              float* row_scale, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  if (Kp > 64 * 2 * 17 || (Kp & 1)) return hipErrorInvalidValue;        // the [., 2144] input rows
-  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (Kp > 64 * 2 * 17 || Kp > kRowsLd || (Kp & 31)) return hipErrorInvalidValue;        // the [., 2144] input rows
+  const dim3 grid((unsigned)((rows + 7) / 8));
   if (fmt16)
     hipLaunchKernelGGL((split_rows_kernel<17, true>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
                        (_Float16*)lo, row_scale);
