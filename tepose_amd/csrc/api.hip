@@ -952,6 +952,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   };
   // small batches: all T steps of a layer in one persistent launch (gru_seq.hip); its arrival counters are zeroed
   // by a memset node in front of the first launch of every forward
+  const bool scaled_fmt = sf;         // (the layer loop below reuses the name `sf` for a state buffer)
   bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
   const bool seq = h3 && !sf && w.sync && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
   if (seq && !sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
@@ -967,12 +968,47 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       const float* inf = w.sf[(l - 1) & 1];
       const float* inr = w.sr[(l - 1) & 1];
       const int MT = (int)(Bs * T);       // every slab row, pad rows included (their results are never read)
+      const int Mf = top ? B : MT;         // the top layer's forward direction of gru_rec consumes one step only
+      if (h3 && !scaled_fmt) {
+        // the three products of a layer in as few launches as their shapes allow (each alone under-fills the chip:
+        // 64-192 workgroups): width-first kernel for <= skinny_max_m() rows, 128/256-row tiles above
+        const EncWs::View vf = w.view(inf), vr = w.view(inr);
+        if (!vf.hi || !vr.hi) return (int)hipErrorInvalidValue;
+        auto mk = [&](const EncWs::View& v, int K, size_t w_planes, size_t bias, float* out, int M) {
+          H3Args a{};
+          const half_t* wh = (const half_t*)(Bl + w_planes);
+          a.Ah = v.hi; a.Al = v.lo; a.a_kst = v.kst; a.Wh = wh; a.Wl = wh + n128 * K; a.w_kst = (long)n128 * 32; a.Kp = K;
+          a.C = out; a.ldc = H3; a.bias = Bl + bias; a.M = M; a.N = H3;
+          return a;
+        };
+        H3Args pa[3] = {mk(vf, Hp, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, MT),
+                        mk(vr, 2 * Hp, m->rec_r[l].wih_p, m->rec_r[l].bih, w.grr, MT),
+                        mk(vr, 2 * Hp, m->rec_f[l].wih_p, m->rec_f[l].bih, w.grf, Mf)};
+        H3ArgsBatch sk{};
+        H3Batch big{};
+        for (H3Args& a : pa) {
+          if (a.M <= skinny_max_m()) {
+            // width-first kernel: only the B real rows of every 16-row-padded time slab (B = 1: 16 rows instead of 256)
+            if (a.M == MT && Bs != B) { a.M = B * T; a.grp_rows = B; a.grp_stride = (int)Bs; }
+            sk.p[sk.n++] = a;
+          }
+          else if (big.n == 0 || (big.p[0].M == a.M && big.p[0].N == a.N)) big.p[big.n++] = a;
+          else {                           // a big product of another shape: its own launch
+            H3Batch one{};
+            one.p[0] = a; one.n = 1;
+            CK(launch_gemm_h3(one, s));
+          }
+        }
+        if (big.n) CK(launch_gemm_h3(big, s));
+        if (sk.n) CK(launch_skinny_gemm_h3_batch(sk, s));
+      } else {
       CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].wih_s, m->fwd[l].wih_scale, m->fwd[l].bih,
                           w.gf, MT));
       CK((hipError_t)proj(inr, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].wih_s, m->rec_r[l].wih_scale,
                           m->rec_r[l].bih, w.grr, MT));
       CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].wih_s, m->rec_f[l].wih_scale,
-                          m->rec_f[l].bih, w.grf, top ? B : MT));
+                          m->rec_f[l].bih, w.grf, Mf));
+      }
       gf = w.gf; grr = w.grr; grf = w.grf;
       ldg = H3;
     }

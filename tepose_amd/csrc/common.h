@@ -168,6 +168,10 @@ struct H3Args {
   half_t *Chi, *Clo; long c_kst;      // view base (row 0, column 0), halfs between 32-column groups
   const float* row_scale;             // optional [M]: the A planes hold row m divided by row_scale[m] (launch_split_rows);
                                       // the product of row m is multiplied back before bias / addend
+  // optional row grouping (width-first kernel only): logical row m lives at physical row (m / grp_rows) * grp_stride +
+  // m % grp_rows of A and C -- the time slabs of the state buffers are padded to 16 rows, and at B = 1 fifteen of
+  // every sixteen rows are padding that a product over the physical rows would stream W against
+  int grp_rows, grp_stride;           // 0: identity
 };
 struct GateDir {
   const float* gi; long ldgi;         // x W_ih^T + b_ih, [row*ldgi + g*Hp + j]
@@ -185,6 +189,8 @@ hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s);
 // the same step for small M (skinny_h3.hip): width-first blocks, K split over the waves, operands streamed to VGPRs
 hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s);
 hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s);
+struct H3ArgsBatch { H3Args p[3]; int n; };                       // independent products (own M, N, K) in one launch
+hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s);
 int skinny_h3_max_m();
 // gru_seq.hip: all T cell steps of one layer (up to 3 directions) in one persistent launch for M <= 64 rows, W_hh
 // planes stationary in registers.  Per (direction, step): where the step's gate pre-activations come from and where

@@ -148,18 +148,22 @@ __global__ void __launch_bounds__(256) skinny_gru_h3_kernel(H3Batch batch, int M
 // Small-M product C = (A W^T + bias + addend) * scale on the same operands (optionally also written as planes):
 // a block owns 16*MT rows x 48 columns, K split over the 4 waves exactly as above.
 template <int MT>
-__global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3Args a) {
+__global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) {
   constexpr int NW = 4;
+  const H3Args& a = batch.p[blockIdx.z];          // up to 3 independent products per launch (their own M, N, K)
+  if ((int)blockIdx.x * 48 >= a.N || (int)blockIdx.y * 16 * MT >= a.M) return;   // the grid covers the largest one
   __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 48, m0 = blockIdx.y * 16 * MT;
   const int r16 = lane & 15, q = lane >> 4;
   const long wrows = a.w_kst / 32;               // rows the W planes hold (padded to the 128-row tile, zero past N)
 
+  const int gr = a.grp_rows, gs = a.grp_stride;
+  auto phys = [&](int m) -> long { return gr ? (long)(m / gr) * gs + m % gr : (long)m; };
   const half_t *ah[MT], *al[MT], *wh[3], *wl[3];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const long row = min(m0 + i * 16 + r16, a.M - 1);
+    const long row = phys(min(m0 + i * 16 + r16, a.M - 1));
     const long o = row * 32 + slot_off(row, q);
     ah[i] = a.Ah + o; al[i] = a.Al + o;
   }
@@ -236,13 +240,14 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3Args a) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[((w * MT * 3 + i * 3 + t) * 4 + e) * 64 + lane];
-      const int row = m0 + i * 16 + q * 4 + e, col = n0 + t * 16 + r16;
-      if (row < a.M && col < a.N) {
+      const int lrow = m0 + i * 16 + q * 4 + e, col = n0 + t * 16 + r16;
+      if (lrow < a.M && col < a.N) {
+        const long row = phys(lrow);
         if (a.row_scale) v *= a.row_scale[row];
         if (a.bias) v += a.bias[col];
-        if (a.addend) v += a.addend[(long)row * a.ldadd + col];
+        if (a.addend) v += a.addend[row * a.ldadd + col];
         v *= sc;
-        a.C[(long)row * a.ldc + col] = v;
+        a.C[row * a.ldc + col] = v;
         if (a.Chi) {
           const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
           split_hi_lo(v, a.Chi[o], a.Clo[o]);
@@ -252,15 +257,23 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3Args a) {
   }
 }
 
-hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s) {
-  if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  const int nt = (a.N + 47) / 48;
-  if (a.M <= 32) {
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1), dim3(256), 0, s, a);
+hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
+  int maxM = 0, maxN = 0;
+  for (int i = 0; i < b.n; ++i) { maxM = b.p[i].M > maxM ? b.p[i].M : maxM; maxN = b.p[i].N > maxN ? b.p[i].N : maxN; }
+  if (b.n <= 0 || maxM <= 0 || maxN <= 0) return hipSuccess;
+  const int nt = (maxN + 47) / 48;
+  if (maxM <= 32) {
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else {
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (a.M + 63) / 64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (maxM + 63) / 64, b.n), dim3(256), 0, s, b);
   }
   return hipGetLastError();
+}
+
+hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s) {
+  H3ArgsBatch b{};
+  b.p[0] = a; b.n = 1;
+  return launch_skinny_gemm_h3_batch(b, s);
 }
 
 hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s) {
