@@ -298,6 +298,7 @@ struct EncWs {
   // forward direction consumes
   half_t *state_hi, *state_lo, *x0h, *x0l;
   float *rs = nullptr, *rs0 = nullptr;   // per-row scales of the input planes (launch_split_rows): [B*T] and, 1-layer models, [B]
+  unsigned long long* gran = nullptr;    // {tag, hi|lo} granule buffers of the persistent kernel's B <= 16 mode
   unsigned* sync = nullptr;   // persistent recurrent kernel (gru_seq.hip): per layer 3 x 32 arrival counters, then a status word
   Planes tailA, tailF, tailR;   // [relu(last forward state) | relu(ytop)] = [B x 3Hp], A operand of the tail linears; tailF /
                                 // tailR: its K-tile ranges [0, Hp/32) and [Hp/32, 3Hp/32)
@@ -345,6 +346,10 @@ struct EncWs {
 // forward.  It is the first carve of the encoder's and of the regressor's workspace, so that inside tepose_forward
 // (both share one region) it is the same memory: [L x 3 x 32 recurrent arrivals | 32 status | 3 x 32 regressor | 32 status].
 inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32; }
+// floats of the granule buffers: [3 directions][2 buffers][16 rows][Hp] uint64, only where the persistent kernel can run
+inline size_t seq_gran_words(const tepose_model* m, int B) {
+  return (m->split && B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
+}
 inline unsigned* sync_gru(unsigned* sy, int l) { return sy + (size_t)l * 96; }
 inline unsigned* sync_gru_status(const tepose_model* m, unsigned* sy) { return sy + (size_t)m->L * 96; }
 inline unsigned* sync_reg(const tepose_model* m, unsigned* sy) { return sy + (size_t)m->L * 96 + 32; }
@@ -357,6 +362,8 @@ void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   const size_t Bs = h3 ? (size_t)round_up(B, 16) : (size_t)B, BTs = Bs * T;
   w.Bs = Bs;
   w.sync = (unsigned*)c.f(sync_words(m));
+  // granule buffers of the persistent recurrent kernel (B <= 16), right behind the counters: one memset zeroes both
+  w.gran = (unsigned long long*)c.f(seq_gran_words(m, B));
   w.xp = c.f(BT * kInputP);
   w.g0 = c.f(BT * (L >= 2 ? 9 : 6) * Hp);
   w.g0c = c.f(L >= 2 ? 0 : (size_t)B * 3 * Hp);
@@ -955,7 +962,9 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const bool scaled_fmt = sf;         // (the layer loop below reuses the name `sf` for a state buffer)
   bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
   const bool seq = h3 && !sf && w.sync && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
-  if (seq && !sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
+  const size_t gran_bytes = seq_gran_words(m, B) * sizeof(float);
+  if (seq && !sync_zeroed)
+    CK(hipMemsetAsync(w.sync, 0, align_up(sync_words(m) * sizeof(unsigned), 256) + (w.gran ? gran_bytes : 0), s));
   for (int l = 0; l < L; ++l) {
     const bool top = l == L - 1;
     float* sf = w.sf[l & 1];
@@ -1077,6 +1086,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           sq.w_kst = (long)n128 * 32; sq.phi = w.state_hi; sq.plo = w.state_lo;
           sq.counters = sync_gru(w.sync, l); sq.status = sync_gru_status(m, w.sync);
           sq.ndir = nd; sq.T = T; sq.M = B; sq.Hp = Hp;
+          sq.gran = gran_bytes ? w.gran : nullptr; sq.tag_base = (unsigned)l * 64u;
           sq.rhi = w.tailA.hi; sq.rlo = w.tailA.lo; sq.r_kst = (unsigned)w.tailA.kst;
           sq.r_off[0] = sq.r_off[1] = sq.r_off[2] = sq.x_roff = kNoPlane;
           if (top) {
@@ -1465,7 +1475,9 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
     carve_regressor(m, B, c, rw);
   }
   if (!rw.sync) return TEPOSE_E_WORKSPACE;
-  CK(hipMemsetAsync(rw.sync, 0, sync_words(m) * sizeof(unsigned), (hipStream_t)stream));   // every arrival counter of this forward
+  // every arrival counter (and, for B <= 16, every granule) of this forward: one memset node
+  CK(hipMemsetAsync(rw.sync, 0, align_up(sync_words(m) * sizeof(unsigned), 256) + seq_gran_words(m, B) * sizeof(float),
+                    (hipStream_t)stream));
   bool wrote = false;
   int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, rw.split_fc ? &rw.featP : nullptr, &wrote, true);
   if (rc) return rc;

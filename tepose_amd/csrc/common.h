@@ -219,7 +219,13 @@ struct GruSeqArgs {
   half_t *rhi, *rlo;
   unsigned r_off[3], x_roff, r_kst;
   unsigned long long* stamps;            // diagnostic builds (-DTEPOSE_SEQ_STAMPS): per-step wall-clock stamps of one workgroup
+  // M <= 16: the state travels between workgroups as 8-byte {tag, hi|lo} granules -- the data is the flag (one round trip
+  // per step instead of store drain + counter + poll + load).  gran: [3 directions][2 buffers][16 rows][Hp] uint64, zeroed
+  // before the forward; a step's tag = tag_base + step + 1 (tag_base separates the layers of one forward).  nullptr: counters.
+  unsigned long long* gran;
+  unsigned tag_base;
 };
+constexpr size_t kSeqGranRows = 16;
 constexpr unsigned kNoPlane = 0xffffffffu;
 // reg_seq.hip: the regressor's FC loop (fc1 / fc2 / decoders x n_iter) for N <= 64 rows in one persistent launch
 struct RegSeqArgs {
@@ -238,6 +244,7 @@ int reg_seq_max_n();
 hipError_t launch_reg_seq(const RegSeqArgs& a, hipStream_t s);
 bool gru_seq_ok(int ndir, int M, int Hp, int T);
 int gru_seq_max_m();
+int gru_seq_gran_max_m();
 hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s);
 // first cell step of a direction (h = 0: no product), writing the same outputs
 struct GateBatch { GateDir d[3]; };

@@ -658,6 +658,21 @@ hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw
 hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   const int tilesM = (b.p[0].M + 255) / 256, tilesN = (b.p[0].N + 127) / 128;
+  static const int tile_dbg = [] { const char* e = getenv("TEPOSE_H3_TILE"); return e ? atoi(e) : 0; }();   // A/B: force a tile shape
+  if (tile_dbg == 64) {
+    const int tm = (b.p[0].M + 63) / 64;
+    hipLaunchKernelGGL((gemm_h3_kernel<1, 2, 3, false, false, 2>), dim3(tm * tilesN, b.n), dim3(256), 0, s, b, tm, tilesN);
+    return hipGetLastError();
+  }
+  if (tile_dbg == 192) {
+    const int tm = (b.p[0].M + 127) / 128, tn = (b.p[0].N + 191) / 192;
+    hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 3, false, false>), dim3(tm * tn, b.n), dim3(512), 0, s, b, tm, tn);
+    return hipGetLastError();
+  }
+  if (tile_dbg == 256) {
+    hipLaunchKernelGGL((gemm_h3_kernel<2, 2, 3, false, false>), dim3(tilesM * tilesN, b.n), dim3(512), 0, s, b, tilesM, tilesN);
+    return hipGetLastError();
+  }
   if (b.p[0].M <= 2048 && tilesM * tilesN * b.n < 1024) {     // few rows and < 4 rounds of 256-row tiles: 128-row
     // tiles quantise better (B=64: layer-0 projection 288 -> 576 tiles; B=64 forward 0.95 -> 0.89 ms)
     const int tm = (b.p[0].M + 127) / 128;

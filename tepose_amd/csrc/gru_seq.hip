@@ -71,10 +71,13 @@ __device__ __forceinline__ h16x8 as_h8(u32x4 v) {
 }  // namespace
 
 // MT: 16-row tiles of the batch (M <= 16 MT); KS: K-tiles (of 32) per wave = Hp / 256.
-template <int MT, int KS>
+template <int MT, int KS, bool GR = false>
 __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   constexpr int NW = 8;
   __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
+  // granule mode: per wave, its K-slice of the previous state as hi / lo rows [16][32 KS (+8 pad)] for the A fragments
+  constexpr int GLD = 32 * KS + 8;
+  __shared__ __attribute__((aligned(16))) half_t gst[GR ? NW * 2 * 16 * GLD : 8];
   // this direction's step table: a kernel-argument read per step is a scalar-cache miss (~0.7 us) on the critical path
   __shared__ __attribute__((aligned(16))) GruSeqStep tab[kSeqMaxT];
   const int dir = blockIdx.z;
@@ -144,6 +147,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.phi, 0, 0x7fffffff, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.plo, 0, 0x7fffffff, 0x00020000);
   unsigned* counter = a.counters + dir * 32 + blockIdx.y * 16;   // one per (direction, row slice)
+  if (GR) for (int i = tid; i < NW * 2 * 16 * GLD; i += 512) gst[i] = (half_t)0.f;
   __syncthreads();                                // `tab` is filled
 
   for (int st = 0; st < T; ++st) {
@@ -157,6 +161,65 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
     float2 hr = {0.f, 0.f}, hz = hr, hn = hr;
     SEQ_STAMP(0);
     if (st > 0) {
+      if constexpr (GR) {
+        // sweep this wave's K-slice of the previous state until every granule carries this step's tag
+        const unsigned want = a.tag_base + (unsigned)st;
+        const unsigned long long* gsrc = a.gran + ((size_t)(dir * 2 + ((st - 1) & 1)) * kSeqGranRows) * Hp + wave * 32 * KS + 2 * lane;
+        const bool mine = 2 * lane < 32 * KS;
+        half_t* gh = gst + (wave * 2) * 16 * GLD;
+        half_t* gl = gh + 16 * GLD;
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+          unsigned long long g0[16], g1[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)                       // every row's loads in flight together (M is uniform)
+            if (r < M && mine) {
+              g0[r] = __hip_atomic_load(gsrc + (size_t)r * Hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              g1[r] = __hip_atomic_load(gsrc + (size_t)r * Hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (r < M && mine) {
+              ok &= (unsigned)(g0[r] >> 32) == want && (unsigned)(g1[r] >> 32) == want;
+              // low word of a granule = hi half | lo half << 16
+              *(unsigned*)(gh + r * GLD + 2 * lane) = ((unsigned)g0[r] & 0xffffu) | (((unsigned)g1[r] & 0xffffu) << 16);
+              *(unsigned*)(gl + r * GLD + 2 * lane) = (((unsigned)g0[r] >> 16) & 0xffffu) | ((unsigned)g1[r] & 0xffff0000u);
+            }
+          if (__all(ok)) break;
+          if (++spins > (1u << 22)) {
+            if (lane == 0) __hip_atomic_store(a.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        SEQ_STAMP(1);
+        SEQ_STAMP(2);
+        h16x8 xh[KS], xl[KS];
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          xh[c] = *(const h16x8*)(gh + r16 * GLD + 32 * c + 8 * q);
+          xl[c] = *(const h16x8*)(gl + r16 * GLD + 32 * c + 8 * q);
+        }
+        f32x4 acc[3], accx[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[c], wh[c][g], acc[g], 0, 0, 0);
+            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[c], wl[c][g], accx[g], 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[c], wh[c][g], accx[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int ee = 0; ee < 4; ++ee)
+            red[((wave * MT * 3 + g) * 4 + ee) * 64 + lane] = acc[g][ee] + accx[g][ee] * (1.f / kLoScale);
+      } else {
       // every workgroup of this direction has published step st - 1
       if (tid == 0 && !(TEPOSE_SEQ_ABL & 4)) {
         const unsigned want = cpd * (unsigned)st;
@@ -226,6 +289,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
           for (int ee = 0; ee < 4; ++ee)
             red[((wave * MT * 3 + i * 3 + g) * 4 + ee) * 64 + lane] = acc[g][ee] + accx[g][ee] * (1.f / kLoScale);
       }
+      }
       SEQ_DRAIN();
       SEQ_STAMP(3);
       __syncthreads();
@@ -254,19 +318,35 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
         hv[1] = (1.f - zg) * ng + zg * hp.y;
       }
       hp.x = hv[0]; hp.y = hv[1];
-      // publish: fp32 state (8 bytes) and its planes (4 + 4 bytes), all write-through
-      union { float f[2]; unsigned long long u; } pk;
-      pk.f[0] = hv[0]; pk.f[1] = hv[1];
-      __hip_atomic_store((unsigned long long*)(s.hout + (long)erow * s.ldo + ej), pk.u, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
       half_t h0, l0, h1, l1;
       split_hi_lo(hv[0], h0, l0);
       split_hi_lo(hv[1], h1, l1);
       union { h16x2 h; unsigned u; } ph, pl;
       ph.h = h16x2{h0, h1}; pl.h = h16x2{l0, l1};
       const long o = (long)s.poff + (long)(ej >> 5) * s.pkst + plane_index(erow, ej & 31, 0);
+      if constexpr (GR) {
+        // the other workgroups read granules {tag, hi | lo << 16}: ONE 8-byte write-through store each, nothing to drain;
+        // the fp32 state and the planes are for later kernels (plain stores)
+        if (st + 1 < T) {
+          unsigned long long* gd = a.gran + ((size_t)(dir * 2 + (st & 1)) * kSeqGranRows + erow) * Hp + ej;
+          const unsigned long long tg = (unsigned long long)(a.tag_base + (unsigned)st + 1u) << 32;
+          union { half_t h; unsigned short u; } c0, c1, c2, c3;
+          c0.h = h0; c1.h = l0; c2.h = h1; c3.h = l1;
+          __hip_atomic_store(gd, tg | c0.u | ((unsigned)c1.u << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(gd + 1, tg | c2.u | ((unsigned)c3.u << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *(float2*)(s.hout + (long)erow * s.ldo + ej) = float2{hv[0], hv[1]};
+        *(unsigned*)(a.phi + o) = ph.u;
+        *(unsigned*)(a.plo + o) = pl.u;
+      } else {
+      // publish: fp32 state (8 bytes) and its planes (4 + 4 bytes), all write-through
+      union { float f[2]; unsigned long long u; } pk;
+      pk.f[0] = hv[0]; pk.f[1] = hv[1];
+      __hip_atomic_store((unsigned long long*)(s.hout + (long)erow * s.ldo + ej), pk.u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store((unsigned*)(a.phi + o), ph.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store((unsigned*)(a.plo + o), pl.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (st == T - 1 && a.r_off[dir] != kNoPlane) {        // relu(final state): the tail linear's A operand
         const long ro = (long)a.r_off[dir] + (long)(ej >> 5) * a.r_kst + plane_index(erow, ej & 31, 0);
         store_planes2(a.rhi + ro, a.rlo + ro, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f));
@@ -274,13 +354,28 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
     }
     SEQ_STAMP(5);
     if (st + 1 < T) {
+      if constexpr (GR) {
+        __syncthreads();                                    // `red` is free for the next step
+      } else {
       if (!(TEPOSE_SEQ_ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
       SEQ_STAMP(6);
       __syncthreads();                                      // (also: `red` is free for the next step)
       if (tid == 0 && !(TEPOSE_SEQ_ABL & 8)) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       SEQ_STAMP(7);
+      }
     }
   }
+}
+
+static hipError_t launch_gran(const GruSeqArgs& a, dim3 grid, hipStream_t s) {
+  switch (a.Hp / 256) {
+    case 1: hipLaunchKernelGGL((gru_seq_kernel<1, 1, true>), grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((gru_seq_kernel<1, 2, true>), grid, dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((gru_seq_kernel<1, 3, true>), grid, dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((gru_seq_kernel<1, 4, true>), grid, dim3(512), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 template <int MT>
@@ -293,6 +388,15 @@ static hipError_t launch_mt(const GruSeqArgs& a, dim3 grid, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+int gru_seq_gran_max_m() {
+  static const int v = [] {
+    const char* e = getenv("TEPOSE_SEQ_GRAN_MAX_M");   // rows up to which the state travels as tagged granules (0: never)
+    const int x = e ? atoi(e) : 4;                     // measured: B = 1 -14 %, B = 4 -5 %, B = 8 +20 % per forward
+    return x > 16 ? 16 : x;
+  }();
+  return v;
 }
 
 int gru_seq_max_m() {
@@ -333,6 +437,7 @@ hipError_t launch_gru_seq(const GruSeqArgs& a0, hipStream_t s) {
 #endif
   if (!gru_seq_ok(a.ndir, a.M, a.Hp, a.T)) return hipErrorInvalidValue;
   dim3 grid(a.Hp / 16, 1, a.ndir);
+  if (a.M <= gru_seq_gran_max_m() && a.gran) return launch_gran(a, grid, s);
   if (a.M <= 16) return launch_mt<1>(a, grid, s);
   if (a.M <= 32) return launch_mt<2>(a, grid, s);
   // 33..64 rows: a step is bound by the 4 KB per row of state planes every workgroup reads.  Where the chip has room

@@ -26,8 +26,9 @@ def _model(L, H, seed, smpl_np):
     return build_model(L, H, seed=seed, device='cuda', smpl_np=smpl_np)
 
 
-# (L, H, B, T): H % 256 == 0 and 4 < B <= 64 take the persistent kernel
-SHAPES = [(2, 1024, 5, 6), (2, 1024, 64, 16), (2, 1024, 37, 6), (2, 1024, 16, 16), (2, 1024, 17, 3), (2, 1024, 33, 2),
+# (L, H, B, T): H % 256 == 0 and B <= 64 take the persistent kernel (B <= 4: states handed over as tagged granules)
+SHAPES = [(2, 1024, 1, 16), (2, 1024, 2, 5), (2, 1024, 3, 32), (2, 1024, 4, 6), (1, 512, 1, 7), (3, 256, 4, 3), (2, 768, 2, 36),
+          (2, 1024, 5, 6), (2, 1024, 64, 16), (2, 1024, 37, 6), (2, 1024, 16, 16), (2, 1024, 17, 3), (2, 1024, 33, 2),
           (2, 256, 17, 5), (1, 512, 33, 4), (3, 256, 64, 3), (2, 768, 16, 7), (1, 1024, 48, 5), (2, 1024, 8, 36),
           (2, 1024, 6, 32), (3, 512, 9, 4)]
 
@@ -49,13 +50,14 @@ def test_encoder_on_persistent_kernel_vs_oracle(L, H, B, T, smpl_np):
     assert (feat_tr.cpu().double() - ref_tr).abs().max() < 2e-5
 
 
-def test_repeated_forwards_are_identical_under_a_competing_stream(smpl_np):
-    """200 forwards at B = 64 / T = 16 while another stream hammers HBM and the CUs: every result must equal the first
+@pytest.mark.parametrize('B', [64, 1, 3])
+def test_repeated_forwards_are_identical_under_a_competing_stream(B, smpl_np):
+    """200 forwards at B = 64 (counters) and B = 1, 3 (granules), T = 16, while another stream hammers HBM and the CUs: every result must equal the first
     bit for bit (a stale read of a handed-off state, or a hand-off that depends on arrival order, shows as a difference),
     and the first must match the oracle."""
     from oracle import tepose_ref as O
     model, state, _ = _model(2, 1024, 3, smpl_np)
-    x = synth.synthetic_windows(64, 16, 5)
+    x = synth.synthetic_windows(B, 16, 5)
     xd = torch.from_numpy(x).cuda()
     side = torch.cuda.Stream()
     junk = torch.randn(64 << 20, device='cuda')
