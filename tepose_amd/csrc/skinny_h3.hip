@@ -147,20 +147,22 @@ __global__ void __launch_bounds__(256) skinny_gru_h3_kernel(H3Batch batch, int M
 
 // Small-M product C = (A W^T + bias + addend) * scale on the same operands (optionally also written as planes):
 // a block owns 16*MT rows x 48 columns, K split over the 4 waves exactly as above.
-template <int MT>
+// NT: 16-column tiles per block (3 = 48 columns; 1 = 16 columns for narrow products of few rows, where 48-column blocks
+// would leave most CUs without a weight stream: N = 2048 -> 43 blocks vs 128)
+template <int MT, int NT = 3>
 __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) {
   constexpr int NW = 4;
   const H3Args& a = batch.p[blockIdx.z];          // up to 3 independent products per launch (their own M, N, K)
-  if ((int)blockIdx.x * 48 >= a.N || (int)blockIdx.y * 16 * MT >= a.M) return;   // the grid covers the largest one
-  __shared__ __attribute__((aligned(16))) float red[NW * MT * 3 * 256];
+  if ((int)blockIdx.x * (16 * NT) >= a.N || (int)blockIdx.y * 16 * MT >= a.M) return;   // the grid covers the largest one
+  __shared__ __attribute__((aligned(16))) float red[NW * MT * NT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * 48, m0 = blockIdx.y * 16 * MT;
+  const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * 16 * MT;
   const int r16 = lane & 15, q = lane >> 4;
   const long wrows = a.w_kst / 32;               // rows the W planes hold (padded to the 128-row tile, zero past N)
 
   const int gr = a.grp_rows, gs = a.grp_stride;
   auto phys = [&](int m) -> long { return gr ? (long)(m / gr) * gs + m % gr : (long)m; };
-  const half_t *ah[MT], *al[MT], *wh[3], *wl[3];
+  const half_t *ah[MT], *al[MT], *wh[NT], *wl[NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const long row = phys(min(m0 + i * 16 + r16, a.M - 1));
@@ -168,7 +170,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) 
     ah[i] = a.Ah + o; al[i] = a.Al + o;
   }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < NT; ++t) {
     const long row = min((long)(n0 + t * 16 + r16), wrows - 1);
     const long o = row * 32 + slot_off(row, q);
     wh[t] = a.Wh + o; wl[t] = a.Wl + o;
@@ -176,13 +178,13 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) 
   const int KT = a.Kp / kPlaneK;
   const int c0 = (wave * KT) / NW, c1 = ((wave + 1) * KT) / NW;
 
-  f32x4 acc[MT][3], accx[MT][3];
+  f32x4 acc[MT][NT], accx[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < NT; ++t) { acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  struct Chunk { h16x8 ah[MT], al[MT], wh[3], wl[3]; };
+  struct Chunk { h16x8 ah[MT], al[MT], wh[NT], wl[NT]; };
   auto load = [&](int c, Chunk& k) {
     const long ao = (long)c * a.a_kst, wo = (long)c * a.w_kst;
 #pragma unroll
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) 
       k.al[i] = *(const h16x8*)(al[i] + ao);
     }
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NT; ++t) {
       k.wh[t] = *(const h16x8*)(wh[t] + wo);
       k.wl[t] = *(const h16x8*)(wl[t] + wo);
     }
@@ -200,14 +202,14 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) 
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < NT; ++t) {
         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.ah[i], k.wh[t], acc[i][t], 0, 0, 0);
         accx[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.ah[i], k.wl[t], accx[i][t], 0, 0, 0);
       }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
         accx[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.al[i], k.wh[t], accx[i][t], 0, 0, 0);
   };
   if (c0 < c1) {
@@ -226,20 +228,20 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) 
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int ee = 0; ee < 4; ++ee)
-        red[((wave * MT * 3 + i * 3 + t) * 4 + ee) * 64 + lane] = acc[i][t][ee] + accx[i][t][ee] * (1.f / kLoScale);
+        red[((wave * MT * NT + i * NT + t) * 4 + ee) * 64 + lane] = acc[i][t][ee] + accx[i][t][ee] * (1.f / kLoScale);
   __syncthreads();
   const int e = threadIdx.x >> 6;                // accumulator register of the element this thread finishes
   const float sc = a.scale != 0.f ? a.scale : 1.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NT; ++t) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) v += red[((w * MT * 3 + i * 3 + t) * 4 + e) * 64 + lane];
+      for (int w = 0; w < NW; ++w) v += red[((w * MT * NT + i * NT + t) * 4 + e) * 64 + lane];
       const int lrow = m0 + i * 16 + q * 4 + e, col = n0 + t * 16 + r16;
       if (lrow < a.M && col < a.N) {
         const long row = phys(lrow);
@@ -262,7 +264,9 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
   for (int i = 0; i < b.n; ++i) { maxM = b.p[i].M > maxM ? b.p[i].M : maxM; maxN = b.p[i].N > maxN ? b.p[i].N : maxN; }
   if (b.n <= 0 || maxM <= 0 || maxN <= 0) return hipSuccess;
   const int nt = (maxN + 47) / 48;
-  if (maxM <= 32) {
+  if (maxM <= 32 && nt * b.n < 96) {          // few rows, narrow product: 16-column blocks put a weight stream on 3x the CUs
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
+  } else if (maxM <= 32) {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (maxM + 63) / 64, b.n), dim3(256), 0, s, b);
