@@ -13,6 +13,8 @@ import os
 
 import torch
 
+from .engine import on_device
+
 
 @torch.no_grad()
 def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('theta', 'kp_3d', 'verts', 'rotmat'),
@@ -50,7 +52,7 @@ def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('thet
         use_cache = os.environ['TEPOSE_DRIVER_CACHE'] == '1'
     if use_cache:
         eng = model._engine
-        with torch.cuda.device(dev):
+        with on_device(dev):
             eng.pack_encoder(model.encoder, dev)
             eng.pack_regressor(model.regressor, dev)
         ring_n = max(T - 1, 1)
@@ -62,7 +64,7 @@ def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('thet
             out = newest if theta is None else ring[:, frame % ring_n]
             eng.project_frames(F[:, frame].data_ptr(), F.stride(0), None if theta is None else TH[:, frame].data_ptr(),
                                TH.stride(0), b, out.data_ptr(), out.stride(0), pws)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             for t in range(T - 1):
                 project(t, True, C)
     else:
@@ -70,7 +72,7 @@ def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('thet
     for j in range(steps[0]):
         b = sum(1 for s in steps if s > j)                # active clips form the prefix [0, b)
         if use_cache:
-            with torch.cuda.device(dev):
+            with on_device(dev):
                 if j > 0:
                     project(j + T - 2, True, b)           # previous newest frame, theta now known
                 project(j + T - 1, None, b)               # newest frame, theta slots zero

@@ -11,7 +11,28 @@ from .synth import NUM_VERTS
 
 
 def _sig(tensors):
-    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+    # (address, in-place version) of every tensor: `.to()` / `load_state_dict` / an optimiser step change one of the two
+    # (the address also identifies the device); ~0.2 us per tensor, checked on every forward
+    return tuple([(t.data_ptr(), t._version) for t in tensors])
+
+
+class on_device:
+    """`with torch.cuda.device(d)` only when d is not the current device already (the context manager costs ~10 us per
+    forward, comparable to a launch-bound B = 1 forward's whole host budget)."""
+    __slots__ = ('ctx',)
+
+    def __init__(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.ctx = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*a)
+        return False
 
 
 def _dev_f32(t, device):
@@ -36,6 +57,8 @@ class Engine:
         self.device = None
         self._sig_enc = self._sig_reg = self._sig_smpl = None
         self._ws = None
+        self._ws_need = {}
+        self.packed_generation = 0     # bumped by every (re)pack: the workspace size can depend on what was packed
         self._jreg_cache = {}
         self.profiling = False
 
@@ -70,6 +93,7 @@ class Engine:
         self.blob, self.device = blob, blob.device
         _lib.check(self.lib.tepose_set_blob(self.handle, blob.data_ptr(), blob.numel()), 'tepose_set_blob')
         _lib.check(self.lib.tepose_adopt_blob(self.handle), 'tepose_adopt_blob')
+        self.packed_generation += 1
         self._sig_enc = _sig(self._enc_tensors(model.encoder))
         self._sig_reg = _sig(self._reg_tensors(model.regressor))
         self._sig_smpl = (id(model.regressor.smpl),) + _sig(self._smpl_tensors(model.regressor.smpl))
@@ -77,14 +101,15 @@ class Engine:
         self._jreg_cache = {}
 
     def _enc_tensors(self, enc):
-        ts = []
-        for l in range(self.n_layers):
-            ts += [getattr(enc.gru_fwd, '%s_l%d' % (k, l)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
-        for l in range(self.n_layers):
-            for sfx in ('', '_reverse'):
-                ts += [getattr(enc.gru_rec, '%s_l%d%s' % (k, l, sfx))
-                       for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
-        return ts + [enc.linear_fwd.weight, enc.linear_fwd.bias, enc.linear_rec.weight, enc.linear_rec.bias]
+        names = getattr(self, '_enc_names', None)
+        if names is None:                      # parameter names in the C ABI's order, built once
+            fwd = ['%s_l%d' % (k, l) for l in range(self.n_layers) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            rec = ['%s_l%d%s' % (k, l, sfx) for l in range(self.n_layers) for sfx in ('', '_reverse')
+                   for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            names = self._enc_names = (fwd, rec)
+        gf, gr = enc.gru_fwd._parameters, enc.gru_rec._parameters
+        return [gf[n] for n in names[0]] + [gr[n] for n in names[1]] + \
+            [enc.linear_fwd.weight, enc.linear_fwd.bias, enc.linear_rec.weight, enc.linear_rec.bias]
 
     @staticmethod
     def _reg_tensors(reg):
@@ -112,6 +137,7 @@ class Engine:
         arr = _lib.ptr_array([t.data_ptr() for t in keep])
         _lib.check(self.lib.tepose_pack_encoder(self.handle, arr, len(keep), self._stream()), 'tepose_pack_encoder')
         self._sig_enc = sig
+        self.packed_generation += 1
 
     def pack_regressor(self, reg, device):
         self._ensure_blob(device)
@@ -123,6 +149,7 @@ class Engine:
             _lib.check(self.lib.tepose_pack_regressor(self.handle, arr, len(keep), self._stream()),
                        'tepose_pack_regressor')
             self._sig_reg = sig
+            self.packed_generation += 1
         self.pack_smpl(reg.smpl, device)
 
     def pack_smpl(self, smpl, device):
@@ -137,12 +164,13 @@ class Engine:
             _lib.check(self.lib.tepose_pack_smpl(self.handle, *[t.data_ptr() for t in keep], par, self._stream()),
                        'tepose_pack_smpl')
             self._sig_smpl = sig
+            self.packed_generation += 1
 
     def jreg(self, J, device):
         """Packed CSR of an evaluation joint regressor [17,6890] (any device; cached)."""
         if J is None:
             return None, 0
-        key = (J.data_ptr(), J._version, str(J.device))
+        key = (J.data_ptr(), J._version, J.device.type)
         hit = self._jreg_cache.get(key)
         if hit is None:
             if tuple(J.shape) != (17, NUM_VERTS):
@@ -157,7 +185,12 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def workspace(self, B, T, device):
-        need = int(self.lib.tepose_workspace_bytes(self.handle, int(B), int(T)))
+        k = (int(B), int(T), self.packed_generation)
+        need = self._ws_need.get(k)
+        if need is None:
+            need = self._ws_need[k] = int(self.lib.tepose_workspace_bytes(self.handle, int(B), int(T)))
+            if len(self._ws_need) > 64:
+                self._ws_need = {k: need}
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
@@ -197,19 +230,24 @@ class Engine:
             self._stream()), 'tepose_regressor_fwd_init')
         return out
 
+    @staticmethod
+    def _outputs(N, nj, dev):
+        """The five output tensors of N rows: fresh, contiguous, independently freeable (as the reference's are)."""
+        return {
+            'theta': torch.empty((N, 85), dtype=torch.float32, device=dev),
+            'verts': torch.empty((N, NUM_VERTS, 3), dtype=torch.float32, device=dev),
+            'kp_2d': torch.empty((N, nj, 2), dtype=torch.float32, device=dev),
+            'kp_3d': torch.empty((N, nj, 3), dtype=torch.float32, device=dev),
+            'rotmat': torch.empty((N, 24, 3, 3), dtype=torch.float32, device=dev),
+        }
+
     def forward(self, x, J_regressor):
         B, T = x.shape[:2]
         dev = x.device
         ws = self.workspace(B, T, dev)
         _, jp = self.jreg(J_regressor, dev)
         nj = 14 if J_regressor is not None else 49
-        out = {
-            'theta': torch.empty((B, 85), dtype=torch.float32, device=dev),
-            'verts': torch.empty((B, NUM_VERTS, 3), dtype=torch.float32, device=dev),
-            'kp_2d': torch.empty((B, nj, 2), dtype=torch.float32, device=dev),
-            'kp_3d': torch.empty((B, nj, 3), dtype=torch.float32, device=dev),
-            'rotmat': torch.empty((B, 24, 3, 3), dtype=torch.float32, device=dev),
-        }
+        out = self._outputs(B, nj, dev)
         _lib.check(self.lib.tepose_forward(
             self.handle, x.data_ptr(), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
             out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
@@ -273,6 +311,7 @@ class Engine:
         _lib.check(self.lib.tepose_pack_vibe_encoder(self.handle, arr, len(keep), self._stream()),
                    'tepose_pack_vibe_encoder')
         self._sig_enc = sig
+        self.packed_generation += 1
 
     def vibe_encoder_fwd(self, x, use_residual):
         B, N = x.shape[:2]

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .engine import Engine, warn_if_training
+from .engine import Engine, on_device, warn_if_training
 from .smpl import SMPL, SMPL_MEAN_PARAMS, SMPL_MODEL_DIR, H36M_TO_J14  # noqa: F401
 
 
@@ -48,7 +48,7 @@ class Regressor(nn.Module):
             raise RuntimeError('tepose_amd runs on MI355X only: move the model and input to a cuda device')
         x = x.float().contiguous()
         eng = self._engine
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             eng.pack_regressor(self, x.device)
             use_j = J_regressor if (not is_train and J_regressor is not None) else None
             return [eng.regressor_fwd(x, n_iter, use_j, init=(init_pose, init_shape, init_cam))]

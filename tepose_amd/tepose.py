@@ -12,7 +12,7 @@ import os.path as osp
 import torch
 import torch.nn as nn
 
-from .engine import Engine, check_input, regroup_outputs, warn_if_training
+from .engine import Engine, check_input, on_device, regroup_outputs, warn_if_training
 from .smpl import BASE_DATA_DIR
 from .spin import Regressor, warm_start_from_spin
 
@@ -34,7 +34,7 @@ class TemporalEncoder(nn.Module):
     def forward(self, x, is_train=False):
         warn_if_training(self, x)
         x = check_input(x)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             self._engine.pack_encoder(self, x.device)
             return self._engine.encoder_fwd(x, is_train)
 
@@ -61,7 +61,7 @@ class TePose(nn.Module):
         if batch_size == 0 or x.shape[1] == 0:
             raise ValueError('empty batch / zero-length window: torch.nn.GRU in the reference rejects it too')
         eng = self._engine
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             eng.pack_encoder(self.encoder, x.device)
             eng.pack_regressor(self.regressor, x.device)
             if not is_train:

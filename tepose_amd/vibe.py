@@ -8,7 +8,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .engine import Engine, regroup_outputs
+from .engine import Engine, on_device, regroup_outputs
 from .spin import Regressor, warm_start_from_spin
 
 
@@ -32,7 +32,7 @@ class TemporalEncoder(nn.Module):
         if f != 2048:
             raise ValueError('VIBE encoder input must be [N, T, 2048]')
         x = x.float().contiguous()
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             self._engine.pack_vibe_encoder(self, x.device)
             y = self._engine.vibe_encoder_fwd(x, self.use_residual)
         return y.view(n, t, 2048)
