@@ -178,6 +178,11 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
  * verts[N,6890,3]; joints49[N,49,3] (may be NULL).  Needs tepose_pack_smpl only.          */
 int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, const float* betas, int N,
                     float* verts, float* joints49, void* workspace, size_t ws_bytes, void* stream);
+/* MEASUREMENT ONLY (tools/smpl_per_person_bench.py): the same vertices as tepose_smpl_fwd(pose2rot=1)
+ * with blend shapes + skinning done by one wavefront per person (BASELINE.json's sketch of the SMPL stage) instead of a
+ * GEMM over 128-person tiles + a skinning kernel.  Never called by the product path.                                   */
+int tepose_smpl_fwd_per_person(const tepose_model* m, const float* pose, const float* betas, int N, float* verts,
+                               void* workspace, size_t ws_bytes, void* stream);
 /* mpvpe[N] = mean_v |pred_verts - target_verts| in mm (eval_utils.py:173-175).             */
 int tepose_metrics_verts(const float* pred_verts, const float* target_verts, int N, float* mpvpe,
                          void* stream);

@@ -20,7 +20,7 @@ SYMBOLS = [
     'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
-    'tepose_project_frames_workspace_bytes',
+    'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
 ]
 
 _lib = None
@@ -80,6 +80,7 @@ def load():
     lib.tepose_smpl_verts_from_theta.argtypes = [c_void_p, fp, c_int, fp, fp, c_size_t, c_void_p]
     lib.tepose_metrics_verts.argtypes = [fp, fp, c_int, fp, c_void_p]
     lib.tepose_smpl_fwd.argtypes = [c_void_p, c_int, fp, fp, c_int, fp, fp, fp, c_size_t, c_void_p]
+    lib.tepose_smpl_fwd_per_person.argtypes = [c_void_p, fp, fp, c_int, fp, fp, c_size_t, c_void_p]
     lib.tepose_filter_one_euro.argtypes = [fp, c_int, c_int, c_float, c_float, c_float, c_void_p]
     lib.tepose_filter_slerp.argtypes = [fp, fp, c_int, c_int, c_double, c_void_p]
     lib.tepose_project_frames_workspace_bytes.argtypes = [c_void_p, c_int]

@@ -1531,6 +1531,21 @@ int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, cons
   return 0;
 }
 
+int tepose_smpl_fwd_per_person(const tepose_model* m, const float* pose, const float* betas, int N, float* verts,
+                               void* workspace, size_t ws_bytes, void* stream) {
+  if (!m || !pose || !betas || !verts || !workspace || N < 1) return TEPOSE_E_ARG;
+  if (!m->smpl_packed) return TEPOSE_E_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  Carver c(workspace, ws_bytes);
+  RegWs w;
+  carve_regressor(m, N, c, w);
+  if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
+  SmplConsts sc = smpl_consts(m);
+  CK(launch_smpl_prep_pose(sc, 1, pose, 72, betas, 10, N, w.pf, w.amat, w.posed, s));
+  CK(launch_smpl_person(sc, w.pf, w.amat, N, verts, s));
+  return 0;
+}
+
 int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int N, float* verts, void* workspace,
                                  size_t ws_bytes, void* stream) {
   if (!m || !theta || !verts || !workspace || N < 1) return TEPOSE_E_ARG;

@@ -507,6 +507,62 @@ hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pos
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ measurement only: blend shapes + skinning per person
+// BASELINE.json's north star sketches SMPL as "a single wavefront-per-person kernel".  This is that kernel for the two
+// heavy stages (the prep kernel already is one wave per person): a wave owns a person, walks the 6890 vertices 64 at a
+// time, forms v_posed = blendW[3v+c][:] . pf[p][:] (224 terms per coordinate, the person's pose feature in LDS) and
+// skins it with the person's 24 transforms (LDS).  Every person streams the whole 18.5 MB blend table through L2; the
+// product path instead reads it once per 128-person tile as a GEMM on the matrix cores.  Exported only through
+// tepose_smpl_fwd_per_person for tools/smpl_per_person_bench.py: never on the product path.
+__global__ void __launch_bounds__(256) smpl_person_kernel(const float* __restrict__ blendW, const int* __restrict__ cidx,
+                                                          const float* __restrict__ cval, const float* __restrict__ pf,
+                                                          const float* __restrict__ Amat, int N, float* __restrict__ verts) {
+  __shared__ __attribute__((aligned(16))) float spf[4][kBlendK];
+  __shared__ __attribute__((aligned(16))) float sA[4][kNJ * 12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= N) return;                                       // wave-uniform; no block-wide barrier below
+  for (int i = lane; i < kBlendK; i += 64) spf[wave][i] = pf[(long)p * kBlendK + i];
+  for (int i = lane; i < kNJ * 12; i += 64) sA[wave][i] = Amat[(long)p * kNJ * 12 + i];
+  __builtin_amdgcn_wave_barrier();
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  for (int v = lane; v < kNV; v += 64) {
+    float x[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f4* w = (const f4*)(blendW + (long)(3 * v + c) * kBlendK);
+      float acc = 0.f;
+      for (int k = 0; k < kBlendK / 4; ++k) {
+        const f4 wv = w[k], fv = *(const f4*)(spf[wave] + 4 * k);
+        acc += wv[0] * fv[0] + wv[1] * fv[1] + wv[2] * fv[2] + wv[3] * fv[3];
+      }
+      x[c] = acc;
+    }
+    float t[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) t[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = cidx[v * 4 + k] * 12;
+      const float wgt = cval[v * 4 + k];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) t[e] += wgt * sA[wave][j + e];
+    }
+    float* o = verts + ((long)p * kNV + v) * 3;
+    o[0] = t[0] * x[0] + t[1] * x[1] + t[2] * x[2] + t[3];
+    o[1] = t[4] * x[0] + t[5] * x[1] + t[6] * x[2] + t[7];
+    o[2] = t[8] * x[0] + t[9] * x[1] + t[10] * x[2] + t[11];
+  }
+}
+
+hipError_t launch_smpl_person(const SmplConsts& c, const float* pf, const float* Amat, int N, float* verts, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  if (!c.lbs_sparse) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smpl_person_kernel, dim3((N + 3) / 4), dim3(256), 0, s, c.blendW, c.lbs_cidx, c.lbs_cval, pf, Amat, N,
+                     verts);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ geometry building blocks
 // lib/utils/geometry.py:68-233 and :330-344 as callers use them on their own (lib/utils/demo_utils.py:112,
 // lib/data_utils/threedpw_utils.py:98); the same device functions the prep kernel inlines.
