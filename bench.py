@@ -62,6 +62,7 @@ def pmc_traffic(B, T, split):
         return None, 'no PMC pass committed'
     with open(files[-1]) as f:
         d = json.load(f)
+    pmc_traffic.gru = d.get('gru_step')          # the fused GRU step's pass of the same run, for roofline_gru_steps
     return d.get('traffic_bytes_per_launch'), ('constant from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, '
                                                'FETCH x2-corrected; not collected in this run)' % os.path.relpath(files[-1], ROOT))
 
@@ -328,6 +329,12 @@ def main():
                                                    ': the %d step launches of one forward (5T+1 consumed cell steps, '
                                                    'first-step matmuls skipped but counted)' % (2 * T + 1),
                                          'ms_per_forward': g_ms / g_n}
+            gt = getattr(pmc_traffic, 'gru', None)
+            if split and gt and (B, T) == (8192, 16):
+                res['roofline_gru_steps'].update({
+                    'traffic_per_3_direction_step': gt['traffic_bytes_per_launch'],
+                    'algorithmic_bytes_per_3_direction_step': gt['algorithmic_bytes_per_launch'],
+                    'traffic_ratio': gt['ratio'], 'traffic_source': 'same committed PMC passes as roofline.traffic'})
         if bcast_ms is not None:
             res['weight_broadcast_ms'] = bcast_ms
             res['weight_blob_MB'] = eng.packed_bytes / 1e6
