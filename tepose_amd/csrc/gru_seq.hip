@@ -80,6 +80,8 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   __shared__ __attribute__((aligned(16))) half_t gst[GR ? NW * 2 * 16 * GLD : 8];
   // this direction's step table: a kernel-argument read per step is a scalar-cache miss (~0.7 us) on the critical path
   __shared__ __attribute__((aligned(16))) GruSeqStep tab[kSeqMaxT];
+  __shared__ unsigned gave_up;       // a bounded wait expired: everything this workgroup publishes from now on is NaN
+  if (threadIdx.x == 0) gave_up = 0;
   const int dir = blockIdx.z;
   const int Hp = a.Hp, M = a.M, T = a.T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -187,8 +189,8 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
               *(unsigned*)(gl + r * GLD + 2 * lane) = (((unsigned)g0[r] >> 16) & 0xffffu) | ((unsigned)g1[r] & 0xffff0000u);
             }
           if (__all(ok)) break;
-          if (++spins > (1u << 22)) {
-            if (lane == 0) __hip_atomic_store(a.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > (1u << 20)) {                       // ~1 s: a workgroup of the direction is not resident
+            if (lane == 0) { __hip_atomic_store(a.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); gave_up = 1; }
             break;
           }
         }
@@ -226,8 +228,9 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) {             // give up (a workgroup of the direction is not resident / died)
+          if (++spins > (1u << 21)) {             // ~2 s: give up (a workgroup of the direction is not resident / died)
             __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = 1;
             break;
           }
         }
@@ -317,6 +320,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
         const float ng = sq_tanh(gn.y + rg * (hn.y + bn.y));
         hv[1] = (1.f - zg) * ng + zg * hp.y;
       }
+      if (gave_up) { hv[0] = hv[1] = __builtin_nanf(""); }   // never a plausible-looking wrong state: NaN to the outputs
       hp.x = hv[0]; hp.y = hv[1];
       half_t h0, l0, h1, l1;
       split_hi_lo(hv[0], h0, l0);

@@ -36,7 +36,7 @@ __device__ __forceinline__ void rs_wait(unsigned* counter, unsigned want, unsign
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 24)) {
+      if (++spins > (1u << 21)) {                         // ~2 s: give up; the state turns NaN (see the final store)
         __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -257,8 +257,10 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
       if (it + 1 < a.n_iter) rs_arrive(c_xs, tid);
     }
   }
-  // final state for the SMPL kernels (next launch: plain store); the 3 pad columns stay 0
+  // final state for the SMPL kernels (next launch: plain store); the 3 pad columns stay 0.  If any wait of this launch
+  // gave up (status word set by whichever workgroup timed out), the state is NaN rather than plausible and wrong.
   if (dec && live) {
+    if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) xs.x = xs.y = __builtin_nanf("");
     float* o = a.xs + (long)erow * kState + ec;
     o[0] = ec < kNPose + 13 ? xs.x : 0.f;
     o[1] = ec + 1 < kNPose + 13 ? xs.y : 0.f;
