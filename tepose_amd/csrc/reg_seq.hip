@@ -77,7 +77,8 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
   // epilogue item: (row, column pair)
   const bool item = tid < MT * 128;
   const int ei = tid >> 7, err = (tid >> 3) & 15, ep = tid & 7;
-  const int erow = ei * 16 + err, ec = n0 + 2 * ep;
+  const int m0 = blockIdx.y * (MT * 16);               // row slices are independent chains with their own counters
+  const int erow = m0 + ei * 16 + err, ec = n0 + 2 * ep;
   const bool live = item && erow < N;
   const int rq = err >> 2, re = err & 3;
   const float* rbase = red + (ei * 4 + re) * 64 + rq * 16 + 2 * ep;
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
       const h16x8 wl = *(const h16x8*)(a.w1a_l + wo + (long)kt * (1024 * 32));
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const long row = min(i * 16 + r16, N - 1);
+        const long row = min(m0 + i * 16 + r16, N - 1);
         const long o = row * 32 + rs_slot(row, q) + (long)kt * a.f_kst;
         mma(*(const h16x8*)(a.fh + o), *(const h16x8*)(a.fl + o), wh, wl, acc[i], accx[i]);
       }
@@ -175,9 +176,9 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
     const long o = (long)(ec >> 5) * a.x_kst + plane_index(erow, ec & 31, 0);
     rs_publish2(a.xh + o, a.xl + o, xs.x, xs.y);
   }
-  unsigned* c_xs = a.counters;          // arrivals: 10 per state version
-  unsigned* c_h1 = a.counters + 32;     // 64 per iteration
-  unsigned* c_h2 = a.counters + 64;
+  unsigned* c_xs = a.counters + blockIdx.y * 8;          // arrivals: 10 per state version (per row slice)
+  unsigned* c_h1 = a.counters + 32 + blockIdx.y * 8;     // 64 per iteration
+  unsigned* c_h2 = a.counters + 64 + blockIdx.y * 8;
   if (dec) rs_arrive(c_xs, tid);
 
   __amdgpu_buffer_rsrc_t r_xh = __builtin_amdgcn_make_buffer_rsrc((void*)a.xh, 0, 0x7fffffff, 0x00020000);
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
       if (wave < 5) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const long row = min(i * 16 + r16, N - 1);
+          const long row = min(m0 + i * 16 + r16, N - 1);
           const unsigned o = (unsigned)(row * 32 + rs_slot(row, q) + (long)wave * a.x_kst) * 2u;
           mma(rs_h8(__builtin_amdgcn_raw_buffer_load_b128(r_xh, o, 0, 16)),
               rs_h8(__builtin_amdgcn_raw_buffer_load_b128(r_xl, o, 0, 16)), w1bh, w1bl, acc[i], accx[i]);
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
       zero(acc, accx);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const long row = min(i * 16 + r16, N - 1);
+        const long row = min(m0 + i * 16 + r16, N - 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const unsigned o = (unsigned)(row * 32 + rs_slot(row, q) + (long)(wave * 4 + c) * a.h_kst) * 2u;
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
       zero(acc, accx);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const long row = min(i * 16 + r16, N - 1);
+        const long row = min(m0 + i * 16 + r16, N - 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const unsigned o = (unsigned)(row * 32 + rs_slot(row, q) + (long)(wave * 4 + c) * a.h_kst) * 2u;
@@ -280,7 +281,7 @@ hipError_t launch_reg_seq(const RegSeqArgs& a, hipStream_t s) {
   if (a.N < 1 || a.N > 64) return hipErrorInvalidValue;
   if (a.N <= 16) hipLaunchKernelGGL((reg_seq_kernel<1>), dim3(64), dim3(512), 0, s, a);
   else if (a.N <= 32) hipLaunchKernelGGL((reg_seq_kernel<2>), dim3(64), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((reg_seq_kernel<4>), dim3(64), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((reg_seq_kernel<2>), dim3(64, 2), dim3(512), 0, s, a);   // 33..64 rows: two 32-row slices, 128 workgroups
   return hipGetLastError();
 }
 

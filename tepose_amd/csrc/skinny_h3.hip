@@ -259,6 +259,11 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) 
   }
 }
 
+static bool narrow64() {
+  static const bool v = [] { const char* e = getenv("TEPOSE_SKINNY_NARROW64"); return e ? atoi(e) != 0 : true; }();
+  return v;
+}
+
 hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
   int maxM = 0, maxN = 0;
   for (int i = 0; i < b.n; ++i) { maxM = b.p[i].M > maxM ? b.p[i].M : maxM; maxN = b.p[i].N > maxN ? b.p[i].N : maxN; }
@@ -268,6 +273,8 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
   } else if (maxM <= 32) {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
+  } else if (maxM <= 64 && nt * b.n < 96 && narrow64()) {
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
   } else {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (maxM + 63) / 64, b.n), dim3(256), 0, s, b);
   }
