@@ -21,7 +21,15 @@
 // storing wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane adds to the direction's counter
 // (agent-scope atomic); the consumer's lane 0 polls that counter with sc1 loads, the workgroup barriers, and every
 // load of handed-off bytes is a buffer_load ... sc1 (bypasses this CU's L1, which other CUs' stores never refresh).
-// Counters are zeroed by a memset node before every launch; spins are bounded and report through a status word.
+// Counters are zeroed by a memset node before every launch; spins are bounded (a launch that gives up reports through a
+// status word and publishes NaN from then on).
+//
+// 33..64 rows of a 2-direction layer: two workgroups share a unit slice and take 32 rows each (row slices are independent
+// chains with their own counters).  <= 4 rows (template flag GR): no counters at all -- the state travels as 8-byte
+// {tag, hi | lo << 16} granules, the data is the flag: a consumer wave sweeps its K-slice with sc1 loads until every tag
+// equals the step's, re-packs the halves into A fragments through wave-private LDS and goes (one round trip per step
+// instead of drain + atomic + poll + load).  Two granule buffers alternate; the forward's memset node zeroes them, and
+// tags are layer * 64 + step + 1, so no granule of another step, layer or forward can match.
 #include "common.h"
 
 #ifndef TEPOSE_SEQ_ABL

@@ -11,7 +11,8 @@
 // W2 / Wdec / W1b slices stay in registers for all iterations; h1, h2 and xs travel between workgroups as hi / lo planes
 // through L2 with the hand-off protocol of gru_seq.hip (write-through stores, drained, one arrival counter per edge,
 // sc1 loads).  Same arithmetic as the step-per-launch path: three fp16 MFMAs per product on the hi / lo halves, fp32
-// accumulation, operands split exactly once where they are produced.
+// accumulation, operands split exactly once where they are produced.  33..64 rows: two 32-row slices (grid.y = 2, 128
+// workgroups), each an independent chain with its own counters.
 #include "common.h"
 
 namespace tepose {

@@ -18,9 +18,11 @@ worst = 0.0
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 300
 n = 0
 while time.time() < t_end:
-    L = int(rng.choice([1, 2, 2, 3])); H = int(rng.choice([64, 100, 128, 192, 256, 320]))
+    L = int(rng.choice([1, 2, 2, 3])); H = int(rng.choice([64, 100, 128, 192, 256, 320, 256, 512, 768, 1024]))   # % 256 == 0: persistent kernels
     B = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 769, 1000, 1300, 2048, 2100, 4096, 4200]))
-    T = int(rng.choice([1, 2, 3, 5, 6, 8]))
+    T = int(rng.choice([1, 2, 3, 5, 6, 8, 16, 33]))
+    if H >= 512 and B > 300:
+        B = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 17, 32, 33, 48, 64, 65]))      # keep the fp64 oracle of big models affordable
     seed = int(rng.randint(1 << 20))
     model, state, _ = build_model(L, H, seed=seed, device='cuda', smpl_np=smpl_np)
     x = synth.synthetic_windows(B, T, seed + 1)
