@@ -350,6 +350,9 @@ inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 
 inline size_t seq_gran_words(const tepose_model* m, int B) {
   return (m->split && B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
 }
+inline size_t sync_zero_bytes(const tepose_model* m, int B) {      // counters + granules: the block a forward clears
+  return align_up(sync_words(m) * sizeof(unsigned), 256) + seq_gran_words(m, B) * sizeof(float);
+}
 inline unsigned* sync_gru(unsigned* sy, int l) { return sy + (size_t)l * 96; }
 inline unsigned* sync_gru_status(const tepose_model* m, unsigned* sy) { return sy + (size_t)m->L * 96; }
 inline unsigned* sync_reg(const tepose_model* m, unsigned* sy) { return sy + (size_t)m->L * 96 + 32; }
@@ -963,8 +966,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
   const bool seq = h3 && !sf && w.sync && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
   const size_t gran_bytes = seq_gran_words(m, B) * sizeof(float);
-  if (seq && !sync_zeroed)
-    CK(hipMemsetAsync(w.sync, 0, align_up(sync_words(m) * sizeof(unsigned), 256) + (w.gran ? gran_bytes : 0), s));
+  if (seq && !sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
   for (int l = 0; l < L; ++l) {
     const bool top = l == L - 1;
     float* sf = w.sf[l & 1];
@@ -1170,7 +1172,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
 namespace {
 int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                      void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes,
-                     bool sync_zeroed);
+                     bool zero_sync);
 int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
                    const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta, float* verts,
                    float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream,
@@ -1205,7 +1207,7 @@ namespace {
 // not overlap a buffer the tail product still reads
 int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                      void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes,
-                     bool sync_zeroed) {
+                     bool zero_sync) {
   if (wrote_planes) *wrote_planes = false;
   if (!m || m->kind != 0 || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
@@ -1232,8 +1234,11 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
   // as the other layout; elements below 2^-3 keep an absolute error <= 2^-25 instead of a relative one)
   const bool g0s = h3 && m->g0_single_acc && L >= 2 && BT >= 8192;
   // the caller's windows -> planes with one power-of-two scale per row (any finite fp32 magnitude; DESIGN 4b "range")
-  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s));
+  // (with zero_sync the kernel also clears the forward's arrival counters / granules: it is the forward's first kernel)
+  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, zero_sync ? (void*)w.sync : nullptr,
+                               zero_sync ? sync_zero_bytes(m, B) : 0));
   else CK(launch_pad_input(x, w.xp, BT, s));
+  if (zero_sync && !h3) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
   {
     tepose_model* mm = const_cast<tepose_model*>(m);
     if (m->prof) {
@@ -1301,7 +1306,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
     if (!h3 || is_train || end > first_live) feat_planes = nullptr;
   }
   if (wrote_planes) *wrote_planes = feat_planes != nullptr;
-  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes, sync_zeroed);
+  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes, zero_sync);     // cleared above when asked
 }
 }  // namespace
 
@@ -1475,9 +1480,8 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
     carve_regressor(m, B, c, rw);
   }
   if (!rw.sync) return TEPOSE_E_WORKSPACE;
-  // every arrival counter (and, for B <= 16, every granule) of this forward: one memset node
-  CK(hipMemsetAsync(rw.sync, 0, align_up(sync_words(m) * sizeof(unsigned), 256) + seq_gran_words(m, B) * sizeof(float),
-                    (hipStream_t)stream));
+  // every arrival counter (and, for B <= 4, every granule) of this forward is cleared by its first kernel (the input
+  // split), or by one memset node where that kernel does not run
   bool wrote = false;
   int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, rw.split_fc ? &rw.featP : nullptr, &wrote, true);
   if (rc) return rc;

@@ -222,12 +222,12 @@ struct GruSeqArgs {
   unsigned r_off[3], x_roff, r_kst;
   unsigned long long* stamps;            // diagnostic builds (-DTEPOSE_SEQ_STAMPS): per-step wall-clock stamps of one workgroup
   // M <= 16: the state travels between workgroups as 8-byte {tag, hi|lo} granules -- the data is the flag (one round trip
-  // per step instead of store drain + counter + poll + load).  gran: [3 directions][2 buffers][16 rows][Hp] uint64, zeroed
+  // per step instead of store drain + counter + poll + load).  gran: [3 directions][2 buffers][4 rows][Hp] uint64, zeroed
   // before the forward; a step's tag = tag_base + step + 1 (tag_base separates the layers of one forward).  nullptr: counters.
   unsigned long long* gran;
   unsigned tag_base;
 };
-constexpr size_t kSeqGranRows = 16;
+constexpr size_t kSeqGranRows = 4;       // granule mode serves <= 4 rows (gru_seq_gran_max_m)
 constexpr unsigned kNoPlane = 0xffffffffu;
 // reg_seq.hip: the regressor's FC loop (fc1 / fc2 / decoders x n_iter) for N <= 64 rows in one persistent launch
 struct RegSeqArgs {
@@ -261,8 +261,10 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 // finite fp32 input is representable (no fp16 overflow at |x| >= 65504, no precision loss for tiny features); the
 // consuming product multiplies row m's result by row_scale[m].  fmt16: the scaled [K/16][R][16] format of gemm_h3s.hip
 // (hi = fp16(v), lo = fp16(v - hi)), else the blocked [K/32][R][32] format (lo = fp16((v - hi) * 2^11)).
+// zero / zero_bytes (multiple of 16): the kernel also clears that block -- the forward's arrival counters and granules,
+// when this is the forward's first kernel (saves the memset node).
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
-                             float* row_scale, hipStream_t s);
+                             float* row_scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0);
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);

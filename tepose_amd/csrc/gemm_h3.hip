@@ -96,9 +96,12 @@ constexpr int kRowsLd = 2148;        // LDS row stride (floats): 2144 + 4 keeps 
 template <int NP, bool F16>
 __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ src, long ld, long rows, int K, int Kp,
                                                          long R, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                         float* __restrict__ row_scale) {
+                                                         float* __restrict__ row_scale, uint4* __restrict__ zero,
+                                                         long zero_n) {
   typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float buf[8 * kRowsLd];
+  // the forward's arrival counters / granules (first kernel of a forward: later kernels see them cleared)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero[i] = uint4{0u, 0u, 0u, 0u};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row0 = (long)blockIdx.x * 8;
 #pragma unroll
@@ -169,16 +172,17 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
 }
 
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
-                             float* row_scale, hipStream_t s) {
+                             float* row_scale, hipStream_t s, void* zero, size_t zero_bytes) {
   if (rows <= 0) return hipSuccess;
+  if (zero_bytes % 16 != 0) return hipErrorInvalidValue;
   if (Kp > 64 * 2 * 17 || Kp > kRowsLd || (Kp & 31)) return hipErrorInvalidValue;        // the [., 2144] input rows
   const dim3 grid((unsigned)((rows + 7) / 8));
   if (fmt16)
     hipLaunchKernelGGL((split_rows_kernel<17, true>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
-                       (_Float16*)lo, row_scale);
+                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
   else
     hipLaunchKernelGGL((split_rows_kernel<17, false>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
-                       (_Float16*)lo, row_scale);
+                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
   return hipGetLastError();
 }
 

@@ -181,15 +181,15 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
         unsigned spins = 0;
         for (;;) {
           bool ok = true;
-          unsigned long long g0[16], g1[16];
+          unsigned long long g0[kSeqGranRows], g1[kSeqGranRows];
 #pragma unroll
-          for (int r = 0; r < 16; ++r)                       // every row's loads in flight together (M is uniform)
+          for (int r = 0; r < (int)kSeqGranRows; ++r)        // every row's loads in flight together (M is uniform)
             if (r < M && mine) {
               g0[r] = __hip_atomic_load(gsrc + (size_t)r * Hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               g1[r] = __hip_atomic_load(gsrc + (size_t)r * Hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
+          for (int r = 0; r < (int)kSeqGranRows; ++r)
             if (r < M && mine) {
               ok &= (unsigned)(g0[r] >> 32) == want && (unsigned)(g1[r] >> 32) == want;
               // low word of a granule = hi half | lo half << 16
@@ -406,7 +406,7 @@ int gru_seq_gran_max_m() {
   static const int v = [] {
     const char* e = getenv("TEPOSE_SEQ_GRAN_MAX_M");   // rows up to which the state travels as tagged granules (0: never)
     const int x = e ? atoi(e) : 4;                     // measured: B = 1 -14 %, B = 4 -5 %, B = 8 +20 % per forward
-    return x > 16 ? 16 : x;
+    return x > (int)kSeqGranRows ? (int)kSeqGranRows : x;
   }();
   return v;
 }
