@@ -70,3 +70,36 @@ def test_two_processes_sharing_the_gpu_get_bit_identical_results():
         assert p.returncode == 0, err[-2000:]
         last = [l for l in out.splitlines() if l.startswith('mismatches')][-1]
         assert all(int(v) == 0 for v in last.replace('}', '').split(':')[1:] for v in [v.split(',')[0]]), out[-1500:]
+
+
+def test_adopt_blob_rejects_a_foreign_blob_and_accepts_its_own():
+    """The packed blob carries a header (magic, ABI, model kind, L, H, layout size, packed sections): a blob received by
+    broadcast is adopted only by a handle of the same model -- a TePose blob must not configure a VIBE handle, nor a handle
+    of another size (tepose_adopt_blob used to set every packed flag blindly)."""
+    import torch
+    from tepose_amd import _lib, synth
+    from tepose_amd.engine import Engine
+    from tepose_amd.testing import build_model
+    smpl_np = synth.synthetic_smpl(0)
+    model, _, _ = build_model(1, 64, seed=2, device='cuda', smpl_np=smpl_np)
+    x = torch.from_numpy(synth.synthetic_windows(2, 4, 3)).cuda()
+    with torch.no_grad():
+        ref = model(x)[0]['verts'].clone()
+    blob = model._engine.blob
+    lib = _lib.load()
+    # same model: a fresh handle adopts the blob and reproduces the forward
+    twin, _, _ = build_model(1, 64, seed=99, device='cuda', smpl_np=smpl_np)          # other weights: would differ if it packed its own
+    twin._engine.adopt_blob(blob.clone(), twin)
+    with torch.no_grad():
+        assert torch.equal(twin(x)[0]['verts'], ref)
+    # other size / other kind: refused with TEPOSE_E_STATE (-4)
+    for eng in (Engine(2, 64), Engine(1, 128), Engine(1, 64, 'vibe')):
+        big = torch.zeros(max(eng.packed_bytes, blob.numel()), dtype=torch.uint8, device='cuda')
+        big[:blob.numel()] = blob
+        assert lib.tepose_set_blob(eng.handle, big.data_ptr(), big.numel()) == 0
+        assert lib.tepose_adopt_blob(eng.handle) == -4
+    # garbage: refused
+    eng = Engine(1, 64)
+    junk = torch.randint(0, 255, (eng.packed_bytes,), dtype=torch.uint8, device='cuda')
+    assert lib.tepose_set_blob(eng.handle, junk.data_ptr(), junk.numel()) == 0
+    assert lib.tepose_adopt_blob(eng.handle) == -4
