@@ -454,7 +454,10 @@ hipError_t launch_gru_seq(const GruSeqArgs& a0, hipStream_t s) {
   if (a.M <= 32) return launch_mt<2>(a, grid, s);
   // 33..64 rows: a step is bound by the 4 KB per row of state planes every workgroup reads.  Where the chip has room
   // (a 2-direction layer at H = 1024: 128 workgroups), two workgroups share a unit slice and take 32 rows each.
-  if ((int)grid.x * a.ndir * 2 <= device_cus()) {
+  static const bool row_split = [] { const char* e = getenv("TEPOSE_SEQ_ROWSPLIT"); return e && atoi(e) != 0; }();
+  // (opt-in: it needs EVERY CU of the chip resident at once, which a second process's launch on the same GPU can deny
+  // until the bounded wait expires -- tools/soak_seq.py run twice concurrently; -15 us per forward at B = 64 when it is safe)
+  if (row_split && (int)grid.x * a.ndir * 2 <= device_cus()) {
     grid.y = 2;
     return launch_mt<2>(a, grid, s);
   }
