@@ -103,3 +103,18 @@ def test_adopt_blob_rejects_a_foreign_blob_and_accepts_its_own():
     junk = torch.randint(0, 255, (eng.packed_bytes,), dtype=torch.uint8, device='cuda')
     assert lib.tepose_set_blob(eng.handle, junk.data_ptr(), junk.numel()) == 0
     assert lib.tepose_adopt_blob(eng.handle) == -4
+
+
+def test_two_processes_running_persistent_kernels_stay_bit_identical():
+    """Both processes run the persistent recurrent / regressor kernels (n_layers = 2, hidden = 1024, B = 1 .. 64) on ONE GPU:
+    every forward must equal the process's first one bit for bit -- no hand-off may depend on who else holds CUs, and no
+    bounded wait may expire (launches need at most 192 of the 256 CUs by default)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    procs = [subprocess.Popen([sys.executable, 'tools/soak_seq.py', '240'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err[-2000:]
+        last = [l for l in out.splitlines() if l.startswith('soak mismatches')][-1]
+        counts = [int(v.split(',')[0].strip(' }')) for v in last.split(':')[1:]]
+        assert len(counts) >= 10 and sum(counts) == 0, last
