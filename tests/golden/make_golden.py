@@ -150,6 +150,35 @@ def run_case(T_mod, name, L, H, B, T, use_jreg, seed_w=0, seed_x=1234):
     print('wrote', name, {k: v.shape for k, v in d.items()})
 
 
+def regressor_init_case(P_mod, name, N, n_iter, use_jreg, seed_w=3):
+    """The reference's Regressor.forward with per-call init_pose / init_shape / init_cam and a non-default n_iter
+    (lib/models/spin.py:240-251): the API the reference offers beyond what TePose.forward uses."""
+    reg = P_mod.Regressor().eval()
+    sd_np = synth.synthetic_state_dict(1, 64, seed_w)
+    sd = reg.state_dict()
+    for k in sd:
+        kk = 'regressor.' + k
+        if kk in sd_np:
+            assert tuple(sd[k].shape) == sd_np[kk].shape, (k, sd[k].shape, sd_np[kk].shape)
+            sd[k] = torch.from_numpy(sd_np[kk])
+    reg.load_state_dict(sd, strict=True)
+    feat = torch.from_numpy(synth.normal('gold/feat%d' % N, (N, 2048), std=0.5))
+    ip = torch.from_numpy(synth.normal('gold/ip%d' % N, (N, 144), std=0.7))
+    ish = torch.from_numpy(synth.normal('gold/is%d' % N, (N, 10), std=0.5))
+    ic = torch.from_numpy(synth.normal('gold/ic%d' % N, (N, 3), std=0.1)) + torch.tensor([0.9, 0., 0.])
+    J = torch.from_numpy(SMPL_NP['J_regressor_h36m']) if use_jreg else None
+    with torch.no_grad():
+        out = reg(feat, init_pose=ip, init_shape=ish, init_cam=ic, n_iter=n_iter, J_regressor=J)[0]
+        only_pose = reg(feat, init_pose=ip, n_iter=n_iter, J_regressor=J)[0]       # the other two from the mean parameters
+    d = {'meta': np.array([N, n_iter, int(use_jreg), seed_w], dtype=np.int64),
+         'theta': out['theta'].numpy(), 'kp_2d': out['kp_2d'].numpy(), 'kp_3d': out['kp_3d'].numpy(),
+         'rotmat': out['rotmat'].numpy(), 'theta_only_pose': only_pose['theta'].numpy(),
+         'kp_3d_only_pose': only_pose['kp_3d'].numpy()}
+    d.update(verts_digest(out['verts'].numpy()))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **d)
+    print('wrote', name, {k: v.shape for k, v in d.items()})
+
+
 def driver_case(T_mod, name, L, H, N, T, seed_w, seed_x):
     """One clip through the reference's own autoregressive loop (evaluate.py:247-269,
     written out here as the caller does it, model = the reference TePose)."""
@@ -333,6 +362,8 @@ def main():
     run_case(T_mod, 'tepose_L3H64_B2T4_j14', 3, 64, 2, 4, True, seed_w=4, seed_x=78)
     driver_case(T_mod, 'driver_L2H128_N40T6', 2, 128, 40, 6, 6, 555)
     driver_case(T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
+    regressor_init_case(P_mod, 'regressor_init_N5_it2_j14', 5, 2, True)
+    regressor_init_case(P_mod, 'regressor_init_N3_it0_j49', 3, 0, False)
     vibe_case('vibe_L2H128_B2N20', 2, 128, 2, 20, 8, 901)
     vibe_case('vibe_L1H64_B1N5', 1, 64, 1, 5, 9, 902)
     metrics_case()

@@ -139,3 +139,31 @@ def test_regressor_kernel_on_degenerate_rot6d_rows_and_per_call_init():
     for k in ('rotmat', 'verts', 'kp_3d'):
         assert (got[k].cpu().double() - ref[k]).abs().max() < 1e-4, k
     assert (got['theta'][:, :3].cpu().double() - ref['theta'][:, :3]).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('name', ['regressor_init_N5_it2_j14', 'regressor_init_N3_it0_j49'])
+def test_regressor_per_call_init_vs_reference_golden(name):
+    """The HIP regressor with per-call initial states against vectors produced by the REFERENCE's Regressor class called
+    that way (tests/golden/make_golden.py::regressor_init_case)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', name + '.npz'))
+    N, n_iter, use_j, seed_w = [int(v) for v in g['meta']]
+    smpl_np = synth.synthetic_smpl(0)
+    from tepose_amd.testing import build_model
+    model, _, _ = build_model(1, 64, seed=seed_w, device='cuda', smpl_np=smpl_np)
+    reg = model.regressor
+    feat = torch.from_numpy(synth.normal('gold/feat%d' % N, (N, 2048), std=0.5)).cuda()
+    ip = torch.from_numpy(synth.normal('gold/ip%d' % N, (N, 144), std=0.7)).cuda()
+    ish = torch.from_numpy(synth.normal('gold/is%d' % N, (N, 10), std=0.5)).cuda()
+    ic = (torch.from_numpy(synth.normal('gold/ic%d' % N, (N, 3), std=0.1)) + torch.tensor([0.9, 0., 0.])).cuda()
+    J = torch.from_numpy(smpl_np['J_regressor_h36m']) if use_j else None
+    with torch.no_grad():
+        out = reg(feat, init_pose=ip, init_shape=ish, init_cam=ic, n_iter=n_iter, J_regressor=J)[0]
+        only = reg(feat, init_pose=ip, n_iter=n_iter, J_regressor=J)[0]
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.abs(o['rotmat'] - g['rotmat']).max() < 1e-4
+    assert np.abs(o['kp_3d'] - g['kp_3d']).max() < 1e-4
+    assert np.abs(o['kp_2d'] - g['kp_2d']).max() < 5e-4
+    assert np.abs(o['verts'][:, ::53] - g['verts_sub']).max() < 1e-4
+    assert np.abs(o['theta'][:, :3] - g['theta'][:, :3]).max() < 1e-4 and np.abs(o['theta'][:, 75:] - g['theta'][:, 75:]).max() < 1e-4
+    assert np.abs(_rodrigues(o['theta'][:, 3:75].reshape(-1, 3)) - _rodrigues(g['theta'][:, 3:75].reshape(-1, 3))).max() < 1e-4
+    assert np.abs(only['kp_3d'].cpu().numpy() - g['kp_3d_only_pose']).max() < 1e-4

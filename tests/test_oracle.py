@@ -218,3 +218,28 @@ def test_oracle_filters_match_reference_golden():
     assert np.abs(hat - g['pose_hat']).max() < 1e-5
     Rs = O.slerp_smooth(g['R'], 0.3)
     assert np.abs(Rs - g['R_smooth']).max() < 1e-5         # direct vs eigen-based matrix->quaternion
+
+
+@pytest.mark.parametrize('name', ['regressor_init_N5_it2_j14', 'regressor_init_N3_it0_j49'])
+def test_regressor_per_call_init_golden(name, smpl_np):
+    """Regressor.forward(x, init_pose=, init_shape=, init_cam=, n_iter=) of the REFERENCE class (spin.py:240-251) against
+    the oracle's restatement of it."""
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    N, n_iter, use_j, seed_w = [int(v) for v in g['meta']]
+    state = synth.synthetic_state_dict(1, 64, seed_w)
+    _, reg = O.split_state_dict(state)
+    smpl = O.smpl_tensors(smpl_np)
+    feat = torch.from_numpy(synth.normal('gold/feat%d' % N, (N, 2048), std=0.5))
+    ip = torch.from_numpy(synth.normal('gold/ip%d' % N, (N, 144), std=0.7))
+    ish = torch.from_numpy(synth.normal('gold/is%d' % N, (N, 10), std=0.5))
+    ic = torch.from_numpy(synth.normal('gold/ic%d' % N, (N, 3), std=0.1)) + torch.tensor([0.9, 0., 0.])
+    J = torch.from_numpy(smpl_np['J_regressor_h36m']) if use_j else None
+    with torch.no_grad():
+        out = O.regressor_fwd(reg, smpl, feat, J, n_iter=n_iter, init=(ip, ish, ic))
+        only = O.regressor_fwd(reg, smpl, feat, J, n_iter=n_iter, init=(ip, None, None))
+    assert np.abs(out['rotmat'].numpy() - g['rotmat']).max() < 1e-5
+    assert np.abs(out['kp_3d'].numpy() - g['kp_3d']).max() < 1e-5
+    assert np.abs(out['verts'].numpy()[:, ::53] - g['verts_sub']).max() < 1e-5
+    assert np.abs(out['theta'].numpy()[:, :3] - g['theta'][:, :3]).max() < 1e-5
+    assert np.abs(out['theta'].numpy()[:, 75:] - g['theta'][:, 75:]).max() < 1e-5
+    assert np.abs(only['kp_3d'].numpy() - g['kp_3d_only_pose']).max() < 1e-5
