@@ -148,15 +148,21 @@ int tepose_forward_cached(const tepose_model* m, const float* ring_base, int rin
 
 /* ---- VIBE bootstrap encoder (lib/models/vibe.py:27-117; used by evaluate.py:89-107,233-245
  * and demo.py:104-130,229-237 to predict the first seqlen-1 frames) ----------------------
- * A handle made by tepose_create_vibe holds: uni-directional GRU(2048 -> hidden, n_layers),
- * Linear(hidden -> 2048) on relu(y), residual add, plus the same regressor / SMPL sections
+ * A handle made by tepose_create_vibe_ex holds: GRU(2048 -> hidden, n_layers, bidirectional),
+ * Linear(D*hidden -> 2048) on relu(y) when bidirectional or add_linear (vibe.py:43-47; D = 2 when
+ * bidirectional), residual add when the output is 2048 wide, plus the same regressor / SMPL sections
  * as a TePose handle (tepose_pack_regressor / tepose_pack_smpl / tepose_regressor_fwd work
- * on it).  w = { for l: gru.weight_ih_l{l}, weight_hh, bias_ih, bias_hh ; linear.weight,
- * linear.bias }, n_w = 4*L + 2.                                                          */
+ * on it).  w = { for l, for direction (forward, then reverse): gru.weight_ih, weight_hh, bias_ih,
+ * bias_hh ; then linear.weight, linear.bias when present }, n_w = 4*L*D (+ 2) -- nn.GRU's parameter order.
+ * tepose_create_vibe(n_layers, hidden) = tepose_create_vibe_ex(n_layers, hidden, 0, 1): the configuration
+ * both reference callers build (evaluate.py:93-101).                                            */
 int tepose_create_vibe(int n_layers, int hidden, tepose_model** out);
+int tepose_create_vibe_ex(int n_layers, int hidden, int bidirectional, int add_linear, tepose_model** out);
 int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, void* stream);
 size_t tepose_vibe_workspace_bytes(const tepose_model* m, int B, int N);
-/* x[B,N,2048] -> feat[B*N,2048] (row b*N+t) = linear(relu(gru(x))) (+ x when use_residual). */
+/* width F of the encoder's output rows: 2048 with the linear, hidden without (0: not a VIBE handle) */
+int tepose_vibe_feature_dim(const tepose_model* m);
+/* x[B,N,2048] -> feat[B*N,F] (row b*N+t) = linear(relu(gru(x))) or gru(x), + x when use_residual and F = 2048. */
 int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N, int use_residual,
                             float* feat, void* workspace, size_t ws_bytes, void* stream);
 

@@ -308,25 +308,30 @@ def run_clip(state, smpl_np, feats, theta_init, seqlen, n_layers, J_regressor=No
 
 
 def vibe_encoder_fwd(sd, x, n_layers, use_residual=True):
-    """VIBE TemporalEncoder.forward (lib/models/vibe.py:52-65), uni-directional, add_linear:
-    y = linear(relu(gru(x))) (+ x).  sd keys: gru.weight_ih_l0 ..., linear.weight, linear.bias.
-    x [B,N,2048] -> [B,N,2048]."""
+    """VIBE TemporalEncoder.forward (lib/models/vibe.py:52-65): y = gru(x); when the module has a linear (bidirectional or
+    add_linear, vibe.py:43-47) y = linear(relu(y)); y += x when use_residual and y is 2048 wide.  The configuration is read
+    off the keys: gru.*_reverse => bidirectional, linear.weight => linear.  x [B,N,2048] -> [B,N,2048 or hidden]."""
     seq = x.transpose(0, 1)
+    bidir = 'gru.weight_ih_l0_reverse' in sd
     for l in range(n_layers):
-        seq = _scan(seq, sd, 'gru.@_l%d' % l)
-    y = F.relu(seq) @ sd['linear.weight'].t() + sd['linear.bias']
-    if use_residual:
+        f = _scan(seq, sd, 'gru.@_l%d' % l)
+        seq = torch.cat([f, _scan(seq.flip(0), sd, 'gru.@_l%d_reverse' % l).flip(0)], dim=2) if bidir else f
+    y = seq
+    if 'linear.weight' in sd:
+        y = F.relu(y) @ sd['linear.weight'].t() + sd['linear.bias']
+    if use_residual and y.shape[-1] == 2048:
         y = y + x.transpose(0, 1)
     return y.transpose(0, 1)
 
 
-def vibe_fwd(state, smpl_np, x, n_layers, J_regressor=None, dtype=torch.float32):
+def vibe_fwd(state, smpl_np, x, n_layers, J_regressor=None, dtype=torch.float32, use_residual=True):
     """VIBE.forward (lib/models/vibe.py:104-117): per-frame regressor over the encoder output."""
     enc, reg = split_state_dict(state, dtype)
     smpl = smpl_tensors(smpl_np, dtype)
     x = _t(x, dtype)
     with torch.no_grad():
-        feat = vibe_encoder_fwd(enc, x, n_layers).reshape(-1, 2048)
+        feat = vibe_encoder_fwd(enc, x, n_layers, use_residual)
+        feat = feat.reshape(-1, feat.shape[-1])
         out = regressor_fwd(reg, smpl, feat, None if J_regressor is None else _t(J_regressor, dtype))
     out['feature'] = feat
     return out

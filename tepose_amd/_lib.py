@@ -16,7 +16,7 @@ SYMBOLS = [
     'tepose_packed_bytes', 'tepose_set_blob', 'tepose_adopt_blob', 'tepose_pack_encoder', 'tepose_pack_regressor',
     'tepose_pack_smpl', 'tepose_jreg_packed_bytes', 'tepose_pack_jreg', 'tepose_workspace_bytes',
     'tepose_encoder_fwd', 'tepose_regressor_fwd', 'tepose_forward', 'tepose_gemm_workspace_bytes',
-    'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read', 'tepose_create_vibe',
+    'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read', 'tepose_create_vibe', 'tepose_create_vibe_ex', 'tepose_vibe_feature_dim',
     'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
@@ -72,6 +72,8 @@ def load():
     lib.tepose_gemm_f32.argtypes = [fp, c_long, fp, c_long, fp, fp, c_long, c_int, c_int, c_int, c_int,
                                     fp, c_size_t, c_void_p]
     lib.tepose_create_vibe.argtypes = [c_int, c_int, POINTER(c_void_p)]
+    lib.tepose_create_vibe_ex.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_void_p)]
+    lib.tepose_vibe_feature_dim.argtypes = [c_void_p]
     lib.tepose_pack_vibe_encoder.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     lib.tepose_vibe_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.tepose_vibe_workspace_bytes.restype = c_size_t

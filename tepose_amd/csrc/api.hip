@@ -31,7 +31,9 @@ struct SmplOff {
 
 struct tepose_model {
   int kind = 0;                                 // 0 = TePose, 1 = VIBE bootstrap encoder
-  std::vector<DirW> vibe;                       // VIBE: per-layer uni-GRU weights
+  std::vector<DirW> vibe;                       // VIBE: per-layer GRU weights; wih / bih hold the stacked rows of both
+                                                // directions ([dir][3Hp]), whh / bhh of direction d sit at + d * their size
+  bool vibe_bidir = false, vibe_linear = true;  // vibe.py:27-47: bidirectional GRU; Linear(D*hidden -> 2048) on relu(y)
   size_t vlin_w = 0, vlin_b = 0;
   bool vibe_packed = false;
   int L = 0, H = 0, Hp = 0;
@@ -83,19 +85,21 @@ size_t take(size_t& cur, size_t n) {
 void layout_tail(tepose_model* m, size_t cur);
 
 void layout_vibe(tepose_model* m) {
-  const size_t Hp = m->Hp, L = m->L;
+  const size_t Hp = m->Hp, L = m->L, D = m->vibe_bidir ? 2 : 1;
   size_t cur = 0;
   m->hdr = take(cur, 64);
-  const size_t n128 = round_up(3 * (int)Hp, 128);
+  const size_t n128 = round_up(3 * (int)(D * Hp), 128);
   m->vibe.assign(L, DirW());
   for (size_t l = 0; l < L; ++l) {
-    m->vibe[l].wih = take(cur, n128 * (l == 0 ? (size_t)kFeat : Hp));
-    m->vibe[l].bih = take(cur, 3 * Hp);
-    m->vibe[l].whh = take(cur, 3 * Hp * Hp);
-    m->vibe[l].bhh = take(cur, 3 * Hp);
+    m->vibe[l].wih = take(cur, n128 * (l == 0 ? (size_t)kFeat : D * Hp));
+    m->vibe[l].bih = take(cur, D * 3 * Hp);
+    m->vibe[l].whh = take(cur, D * 3 * Hp * Hp);
+    m->vibe[l].bhh = take(cur, D * 3 * Hp);
   }
-  m->vlin_w = take(cur, (size_t)kFeat * Hp);
-  m->vlin_b = take(cur, kFeat);
+  if (m->vibe_linear) {
+    m->vlin_w = take(cur, (size_t)kFeat * D * Hp);
+    m->vlin_b = take(cur, kFeat);
+  }
   layout_tail(m, cur);
 }
 
@@ -199,9 +203,14 @@ struct BlobHeader {
 };
 constexpr uint32_t kBlobMagic = 0x54455031u;        // "TEP1"
 
+// model kind as the header records it: a VIBE handle also carries its constructor flags
+uint32_t header_kind(const tepose_model* m) {
+  return (uint32_t)m->kind | (m->kind == 1 ? (m->vibe_bidir ? 0x100u : 0u) | (m->vibe_linear ? 0x200u : 0u) : 0u);
+}
+
 int write_header(tepose_model* m, hipStream_t s) {
   BlobHeader h{};
-  h.magic = kBlobMagic; h.abi = TEPOSE_ABI_VERSION; h.kind = (uint32_t)m->kind; h.L = (uint32_t)m->L; h.H = (uint32_t)m->H;
+  h.magic = kBlobMagic; h.abi = TEPOSE_ABI_VERSION; h.kind = header_kind(m); h.L = (uint32_t)m->L; h.H = (uint32_t)m->H;
   h.Hp = (uint32_t)m->Hp;
   h.sections = ((m->kind == 0 ? m->enc_packed : m->vibe_packed) ? 1u : 0u) | (m->reg_packed ? 2u : 0u) |
                (m->smpl_packed ? 4u : 0u) | ((m->enc_range_ok && m->reg_range_ok && m->smpl_range_ok) ? 0u : 8u);
@@ -533,16 +542,27 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
   return 0;
 }
 
-int tepose_create_vibe(int n_layers, int hidden, tepose_model** out) {
+int tepose_create_vibe_ex(int n_layers, int hidden, int bidirectional, int add_linear, tepose_model** out) {
   if (!out || n_layers < 1 || hidden < 1) return TEPOSE_E_ARG;
   if (n_layers > 8 || hidden > 8192) return TEPOSE_E_SHAPE;
   tepose_model* m = new (std::nothrow) tepose_model();
   if (!m) return TEPOSE_E_ARG;
   m->kind = 1; m->L = n_layers; m->H = hidden; m->Hp = round_up(hidden, 64);
+  m->vibe_bidir = bidirectional != 0;
+  m->vibe_linear = bidirectional != 0 || add_linear != 0;      // vibe.py:43-47: a bidirectional encoder always has the linear
   read_env_knobs(m);        // TEPOSE_EXACT_FP32 covers the bootstrap model's regressor / blend-shape products too
   layout_vibe(m);
   *out = m;
   return 0;
+}
+
+int tepose_create_vibe(int n_layers, int hidden, tepose_model** out) {
+  return tepose_create_vibe_ex(n_layers, hidden, 0, 1, out);
+}
+
+int tepose_vibe_feature_dim(const tepose_model* m) {
+  if (!m || m->kind != 1) return 0;
+  return m->vibe_linear ? kFeat : m->H;
 }
 
 int tepose_adopt_blob(tepose_model* m) {
@@ -551,7 +571,7 @@ int tepose_adopt_blob(tepose_model* m) {
   BlobHeader h{};
   CK(hipMemcpy(&h, m->blob + m->hdr, sizeof(h), hipMemcpyDeviceToHost));                      // set-up time only
   const uint64_t lf = ((uint64_t)h.layout_floats_hi << 32) | h.layout_floats_lo;
-  if (h.magic != kBlobMagic || h.abi != TEPOSE_ABI_VERSION || (int)h.kind != m->kind || (int)h.L != m->L ||
+  if (h.magic != kBlobMagic || h.abi != TEPOSE_ABI_VERSION || h.kind != header_kind(m) || (int)h.L != m->L ||
       (int)h.H != m->H || (int)h.Hp != m->Hp || lf != (uint64_t)m->blob_floats)
     return TEPOSE_E_STATE;                        // not a blob of this model kind / size / library layout
   m->enc_packed = m->kind == 0 && (h.sections & 1u);
@@ -581,22 +601,31 @@ int tepose_adopt_blob(tepose_model* m) {
 int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, void* stream) {
   if (!m || !w || m->kind != 1) return TEPOSE_E_ARG;
   if (!m->blob) return TEPOSE_E_STATE;
-  const int L = m->L, H = m->H, Hp = m->Hp;
-  if (n_w != 4 * L + 2) return TEPOSE_E_ARG;
+  const int L = m->L, H = m->H, Hp = m->Hp, D = m->vibe_bidir ? 2 : 1;
+  if (n_w != 4 * L * D + (m->vibe_linear ? 2 : 0)) return TEPOSE_E_ARG;
   for (int i = 0; i < n_w; ++i)
     if (!w[i]) return TEPOSE_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* B = m->blob;
-  const int n128 = round_up(3 * Hp, 128);
+  const int n128 = round_up(3 * D * Hp, 128);
+  const int cmap = D == 2 ? COL_SPLIT2 : COL_PLAIN;            // layer >= 1 inputs and the linear read [fwd Hp | bwd Hp]
   for (int l = 0; l < L; ++l) {
-    const int K = l == 0 ? kFeat : H, Kp = l == 0 ? kFeat : Hp;
-    CK((hipError_t)pack(w[4 * l + 0], K, 3 * H, K, B + m->vibe[l].wih, n128, Kp, ROW_GATES, COL_PLAIN, H, Hp, s));
-    CK((hipError_t)pack(w[4 * l + 2], 1, 3 * H, 1, B + m->vibe[l].bih, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
-    CK((hipError_t)pack(w[4 * l + 1], H, 3 * H, H, B + m->vibe[l].whh, 3 * Hp, Hp, ROW_GATES_TILED, COL_PLAIN, H, Hp, s));
-    CK((hipError_t)pack(w[4 * l + 3], 1, 3 * H, 1, B + m->vibe[l].bhh, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+    const int K = l == 0 ? kFeat : D * H, Kp = l == 0 ? kFeat : D * Hp;
+    for (int d = 0; d < D; ++d) {
+      const float* const* q = w + 4 * (l * D + d);              // weight_ih, weight_hh, bias_ih, bias_hh (nn.GRU's order)
+      const int rows = d == D - 1 ? n128 - d * 3 * Hp : 3 * Hp; // the last direction also zeroes the padding rows
+      CK((hipError_t)pack(q[0], K, 3 * H, K, B + m->vibe[l].wih + (size_t)d * 3 * Hp * Kp, rows, Kp, ROW_GATES,
+                          l == 0 ? COL_PLAIN : cmap, H, Hp, s));
+      CK((hipError_t)pack(q[2], 1, 3 * H, 1, B + m->vibe[l].bih + (size_t)d * 3 * Hp, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+      CK((hipError_t)pack(q[1], H, 3 * H, H, B + m->vibe[l].whh + (size_t)d * 3 * Hp * Hp, 3 * Hp, Hp, ROW_GATES_TILED,
+                          COL_PLAIN, H, Hp, s));
+      CK((hipError_t)pack(q[3], 1, 3 * H, 1, B + m->vibe[l].bhh + (size_t)d * 3 * Hp, 3 * Hp, 1, ROW_GATES, COL_PLAIN, H, Hp, s));
+    }
   }
-  CK((hipError_t)pack(w[4 * L], H, kFeat, H, B + m->vlin_w, kFeat, Hp, ROW_PLAIN, COL_PLAIN, H, Hp, s));
-  CK((hipError_t)pack(w[4 * L + 1], 1, kFeat, 1, B + m->vlin_b, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  if (m->vibe_linear) {
+    CK((hipError_t)pack(w[4 * L * D], D * H, kFeat, D * H, B + m->vlin_w, kFeat, D * Hp, ROW_PLAIN, cmap, H, Hp, s));
+    CK((hipError_t)pack(w[4 * L * D + 1], 1, kFeat, 1, B + m->vlin_b, kFeat, 1, ROW_PLAIN, COL_PLAIN, H, Hp, s));
+  }
   m->vibe_packed = true;
   CK((hipError_t)range_check(m, m->vibe[0].wih, m->w1a, &m->enc_range_ok, s));
   return write_header(m, s);
@@ -604,8 +633,8 @@ int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, vo
 
 size_t tepose_vibe_workspace_bytes(const tepose_model* m, int B, int N) {
   if (!m || m->kind != 1 || B < 1 || N < 1) return 0;
-  const size_t BN = (size_t)B * N, Hp = m->Hp;
-  return align_up(BN * 3 * Hp * 4, 256) + 2 * align_up(BN * Hp * 4, 256) + 256;
+  const size_t BN = (size_t)B * N, Hp = m->Hp, D = m->vibe_bidir ? 2 : 1;
+  return align_up(BN * D * 3 * Hp * 4, 256) + 2 * align_up(BN * D * Hp * 4, 256) + 256;
 }
 
 int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N, int use_residual, float* feat,
@@ -614,33 +643,39 @@ int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N,
   if (!m->vibe_packed) return TEPOSE_E_STATE;
   if (ws_bytes < tepose_vibe_workspace_bytes(m, B, N)) return TEPOSE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int L = m->L, Hp = m->Hp, H3 = 3 * Hp;
+  const int L = m->L, Hp = m->Hp, H3 = 3 * Hp, D = m->vibe_bidir ? 2 : 1;
   const long BN = (long)B * N;
   Carver c(workspace, ws_bytes);
-  float* G = c.f((size_t)BN * H3);
-  float* S[2] = {c.f((size_t)BN * Hp), c.f((size_t)BN * Hp)};
+  float* G = c.f((size_t)BN * D * H3);
+  float* S[2] = {c.f((size_t)BN * D * Hp), c.f((size_t)BN * D * Hp)};
   const float* Bl = m->blob;
   // everything is batch-major (row = b*N + t), like the caller's [B,N,2048]: time steps are a
-  // column offset t*ld with row stride N*ld, so no permute (vibe.py:53,62) is ever materialised
+  // column offset t*ld with row stride N*ld, so no permute (vibe.py:53,62) is ever materialised; a layer's
+  // output row is [forward Hp | backward Hp], the backward direction walking t = N-1 .. 0
   const float* in = x;
   int ldin = kFeat;
   for (int l = 0; l < L; ++l) {
-    GemmArgs g = gemm(in, ldin, Bl + m->vibe[l].wih, ldin, G, H3, Bl + m->vibe[l].bih, (int)BN, H3);
+    GemmArgs g = gemm(in, ldin, Bl + m->vibe[l].wih, ldin, G, (long)D * H3, Bl + m->vibe[l].bih, (int)BN, D * H3);
     CK(launch_gemm(g, s));
     float* So = S[l & 1];
     for (int t = 0; t < N; ++t) {
       GruArgs a{};
-      a.M = B; a.Hp = Hp; a.first = t == 0; a.ndir = 1;
-      GruDir& d = a.d[0];
-      d.Whh = Bl + m->vibe[l].whh; d.bhh = Bl + m->vibe[l].bhh;
-      d.gi = G + (long)t * H3; d.ldgi = (long)N * H3;
-      d.hprev = So + (long)(t - 1) * Hp; d.ldh = (long)N * Hp;
-      d.hout = So + (long)t * Hp; d.ldo = (long)N * Hp;
+      a.M = B; a.Hp = Hp; a.first = t == 0; a.ndir = D;
+      for (int d = 0; d < D; ++d) {
+        const int td = d ? N - 1 - t : t, tp = d ? td + 1 : td - 1;
+        GruDir& q = a.d[d];
+        q.Whh = Bl + m->vibe[l].whh + (size_t)d * H3 * Hp; q.bhh = Bl + m->vibe[l].bhh + (size_t)d * H3;
+        q.gi = G + (long)td * D * H3 + (long)d * H3; q.ldgi = (long)N * D * H3;
+        q.hprev = So + (long)tp * D * Hp + (long)d * Hp; q.ldh = (long)N * D * Hp;
+        q.hout = So + (long)td * D * Hp + (long)d * Hp; q.ldo = (long)N * D * Hp;
+      }
       CK(launch_gru_step(a, s));
     }
-    in = So; ldin = Hp;
+    in = So; ldin = D * Hp;
   }
-  GemmArgs g = gemm(in, Hp, Bl + m->vlin_w, Hp, feat, kFeat, Bl + m->vlin_b, (int)BN, kFeat);
+  if (!m->vibe_linear)                                        // y = gru(x) (+ x when it is 2048 wide, vibe.py:55-61)
+    return (int)launch_copy_cols(in, ldin, (use_residual && m->H == kFeat) ? x : nullptr, kFeat, feat, m->H, BN, m->H, s);
+  GemmArgs g = gemm(in, ldin, Bl + m->vlin_w, ldin, feat, kFeat, Bl + m->vlin_b, (int)BN, kFeat);
   g.relu_a = 1;
   if (use_residual) { g.addend = x; g.ldadd = kFeat; }
   CK(launch_gemm(g, s));

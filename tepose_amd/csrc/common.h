@@ -83,6 +83,8 @@ hipError_t launch_pad_input(const float* x, float* xp, long rows, hipStream_t s)
 hipError_t launch_pad_rows(const float* feat, long feat_ld, const float* theta, long theta_ld, float* xp,
                            long rows, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+hipError_t launch_copy_cols(const float* src, long lds, const float* add, long lda, float* dst, long ldd, long rows,
+                            int cols, hipStream_t s);
 hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s);
 hipError_t launch_init_state_rows(const float* init160, const float* pose, const float* shape, const float* cam,
                                   float* xs, int N, hipStream_t s);

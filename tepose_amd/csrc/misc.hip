@@ -148,6 +148,28 @@ hipError_t launch_init_state_rows(const float* init160, const float* pose, const
   return hipGetLastError();
 }
 
+// dst[r][c] = src[r][c] (+ add[r][c]) for c < cols: a padded state buffer out as the caller's unpadded rows
+__global__ void __launch_bounds__(256) copy_cols_kernel(const float* __restrict__ src, long lds, const float* __restrict__ add,
+                                                        long lda, float* __restrict__ dst, long ldd, long rows, int cols) {
+  const long total = rows * cols;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    float v = src[r * lds + c];
+    if (add) v += add[r * lda + c];
+    dst[r * ldd + c] = v;
+  }
+}
+
+hipError_t launch_copy_cols(const float* src, long lds, const float* add, long lda, float* dst, long ldd, long rows,
+                            int cols, hipStream_t s) {
+  const long total = rows * cols;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks), dim3(256), 0, s, src, lds, add, lda, dst, ldd, rows, cols);
+  return hipGetLastError();
+}
+
 hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s) {
   const long total = (long)N * kState;
   if (total <= 0) return hipSuccess;

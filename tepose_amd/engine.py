@@ -43,12 +43,13 @@ def _dev_f32(t, device):
 class Engine:
     """One per TePose / standalone TemporalEncoder / standalone Regressor."""
 
-    def __init__(self, n_layers, hidden, kind='tepose'):
+    def __init__(self, n_layers, hidden, kind='tepose', bidirectional=False, add_linear=True):
         self.lib = _lib.load()
         h = c_void_p()
         self.kind = kind
         if kind == 'vibe':
-            _lib.check(self.lib.tepose_create_vibe(int(n_layers), int(hidden), ctypes.byref(h)), 'tepose_create_vibe')
+            _lib.check(self.lib.tepose_create_vibe_ex(int(n_layers), int(hidden), int(bool(bidirectional)), int(bool(add_linear)),
+                                                      ctypes.byref(h)), 'tepose_create_vibe_ex')
         else:
             _lib.check(self.lib.tepose_create(int(n_layers), int(hidden), ctypes.byref(h)), 'tepose_create')
         self.handle = h
@@ -300,8 +301,10 @@ class Engine:
     def pack_vibe_encoder(self, enc, device):
         ts = []
         for l in range(self.n_layers):
-            ts += [getattr(enc.gru, '%s_l%d' % (k, l)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
-        ts += [enc.linear.weight, enc.linear.bias]
+            for sfx in ('', '_reverse') if enc.gru.bidirectional else ('',):
+                ts += [getattr(enc.gru, '%s_l%d%s' % (k, l, sfx)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        if enc.linear is not None:
+            ts += [enc.linear.weight, enc.linear.bias]
         sig = _sig(ts)
         if sig == self._sig_enc and self.device == device:
             return
@@ -317,7 +320,7 @@ class Engine:
         B, N = x.shape[:2]
         need = int(self.lib.tepose_vibe_workspace_bytes(self.handle, B, N))
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        feat = torch.empty((B * N, 2048), dtype=torch.float32, device=x.device)
+        feat = torch.empty((B * N, int(self.lib.tepose_vibe_feature_dim(self.handle))), dtype=torch.float32, device=x.device)
         _lib.check(self.lib.tepose_vibe_encoder_fwd(self.handle, x.data_ptr(), B, N, 1 if use_residual else 0,
                                                     feat.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                    'tepose_vibe_encoder_fwd')

@@ -200,20 +200,25 @@ def synthetic_windows(B, T, seed=1234):
     return x
 
 
-def synthetic_vibe_state_dict(n_layers=2, hidden=1024, seed=0, dec_gain=0.35):
+def synthetic_vibe_state_dict(n_layers=2, hidden=1024, seed=0, dec_gain=0.35, bidirectional=False, add_linear=True):
     """State dict of the reference VIBE model (lib/models/vibe.py:27-101): encoder.gru.*,
-    encoder.linear.*, regressor.* -- same scales as synthetic_state_dict."""
+    encoder.linear.* (present when bidirectional or add_linear, vibe.py:43-47), regressor.* -- same scales as
+    synthetic_state_dict."""
     sd = OrderedDict()
     H = hidden
+    D = 2 if bidirectional else 1
     b = 1.0 / math.sqrt(H)
     for l in range(n_layers):
-        k_in = FEAT_DIM if l == 0 else H
-        for name, shape in (('weight_ih', (3 * H, k_in)), ('weight_hh', (3 * H, H)), ('bias_ih', (3 * H,)),
-                            ('bias_hh', (3 * H,))):
-            key = 'encoder.gru.%s_l%d' % (name, l)
-            sd[key] = uniform('vibe%d/%s' % (seed, key), shape, -b, b)
-    sd['encoder.linear.weight'] = uniform('vibe%d/lw' % seed, (2048, H), -b, b)
-    sd['encoder.linear.bias'] = uniform('vibe%d/lb' % seed, (2048,), -b, b)
+        k_in = FEAT_DIM if l == 0 else D * H
+        for sfx in ('', '_reverse')[:D]:
+            for name, shape in (('weight_ih', (3 * H, k_in)), ('weight_hh', (3 * H, H)), ('bias_ih', (3 * H,)),
+                                ('bias_hh', (3 * H,))):
+                key = 'encoder.gru.%s_l%d%s' % (name, l, sfx)
+                sd[key] = uniform('vibe%d/%s' % (seed, key), shape, -b, b)
+    if bidirectional or add_linear:
+        bl = 1.0 / math.sqrt(D * H)
+        sd['encoder.linear.weight'] = uniform('vibe%d/lw' % seed, (2048, D * H), -bl, bl)
+        sd['encoder.linear.bias'] = uniform('vibe%d/lb' % seed, (2048,), -bl, bl)
     full = synthetic_state_dict(1, 64, seed, dec_gain)
     for k, v in full.items():
         if k.startswith('regressor.'):

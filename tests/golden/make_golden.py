@@ -213,24 +213,32 @@ def driver_case(T_mod, name, L, H, N, T, seed_w, seed_x):
     print('wrote', name, np.concatenate(th).shape)
 
 
-def vibe_case(name, L, H, B, N, seed_w, seed_x):
-    """Reference lib.models.vibe.VIBE (uni-GRU + Linear + residual, then the per-frame regressor)."""
+def vibe_case(name, L, H, B, N, seed_w, seed_x, bidirectional=False, add_linear=True, use_residual=True):
+    """Reference lib.models.vibe.VIBE (GRU [+ relu + Linear] [+ residual], then the per-frame regressor).  The first two
+    cases are the configuration evaluate.py:93-101 builds; the others cover the remaining constructor flags
+    (vibe.py:27-65).  A model without a linear and hidden != 2048 has no regressor-compatible output: encoder only."""
     import lib.models.vibe as V_mod
-    model = V_mod.VIBE(seqlen=N, n_layers=L, hidden_size=H, add_linear=True, bidirectional=False,
-                       use_residual=True, pretrained='').eval()
-    sd_np = synth.synthetic_vibe_state_dict(L, H, seed_w)
+    model = V_mod.VIBE(seqlen=N, n_layers=L, hidden_size=H, add_linear=add_linear, bidirectional=bidirectional,
+                       use_residual=use_residual, pretrained='').eval()
+    sd_np = synth.synthetic_vibe_state_dict(L, H, seed_w, bidirectional=bidirectional, add_linear=add_linear)
     sd = model.state_dict()
+    assert {k for k in sd if k.startswith('encoder.')} == {k for k in sd_np if k.startswith('encoder.')}
     for k in sd_np:
         assert k in sd and tuple(sd[k].shape) == sd_np[k].shape, k
         sd[k] = torch.from_numpy(sd_np[k])
     model.load_state_dict(sd, strict=True)
     x = torch.from_numpy(synth.synthetic_windows(B, N, seed_x)[:, :, :2048].copy())
     J = torch.from_numpy(SMPL_NP['J_regressor_h36m'])
+    meta = np.array([L, H, B, N, seed_w, seed_x, int(bidirectional), int(add_linear), int(use_residual)], dtype=np.int64)
     with torch.no_grad():
         feat = model.encoder(x)
+        if feat.shape[-1] != 2048:
+            np.savez_compressed(os.path.join(HERE, name + '.npz'), meta=meta, feature=feat.numpy())
+            print('wrote', name, feat.shape, '(encoder only)')
+            return
         out = model(x, J_regressor=J)[-1]
     np.savez_compressed(os.path.join(HERE, name + '.npz'),
-                        meta=np.array([L, H, B, N, seed_w, seed_x], dtype=np.int64), feature=feat.numpy(),
+                        meta=meta[:6] if (not bidirectional and add_linear and use_residual) else meta, feature=feat.numpy(),
                         theta=out['theta'].numpy(), kp_3d=out['kp_3d'].numpy(), rotmat=out['rotmat'].numpy(),
                         verts_sub=out['verts'].numpy()[:, :, ::53])
     print('wrote', name, feat.shape, out['theta'].shape)
@@ -366,6 +374,10 @@ def main():
     regressor_init_case(P_mod, 'regressor_init_N3_it0_j49', 3, 0, False)
     vibe_case('vibe_L2H128_B2N20', 2, 128, 2, 20, 8, 901)
     vibe_case('vibe_L1H64_B1N5', 1, 64, 1, 5, 9, 902)
+    vibe_case('vibe_bi_L2H64_B2N7', 2, 64, 2, 7, 10, 903, bidirectional=True, add_linear=False)
+    vibe_case('vibe_bi_L1H100_B3N4_nores', 1, 100, 3, 4, 11, 904, bidirectional=True, add_linear=True, use_residual=False)
+    vibe_case('vibe_nolin_L1H2048_B1N4', 1, 2048, 1, 4, 12, 905, add_linear=False)
+    vibe_case('vibe_nolin_L2H96_B2N6', 2, 96, 2, 6, 13, 906, add_linear=False)
     metrics_case()
     filter_cases()
     geometry_cases(G)

@@ -140,13 +140,29 @@ def test_oracle_clip_loop_matches_reference_golden(name, smpl_np):
     assert np.abs(out['theta'].numpy()[:, 75:] - g['theta'][:, 75:]).max() < 1e-4
 
 
-@pytest.mark.parametrize('name', ['vibe_L2H128_B2N20', 'vibe_L1H64_B1N5'])
+VIBE_GOLDENS = ['vibe_L2H128_B2N20', 'vibe_L1H64_B1N5', 'vibe_bi_L2H64_B2N7', 'vibe_bi_L1H100_B3N4_nores',
+                'vibe_nolin_L1H2048_B1N4', 'vibe_nolin_L2H96_B2N6']
+
+
+def vibe_golden_config(g):
+    """(L, H, B, N, seed_w, seed_x, bidirectional, add_linear, use_residual) of a VIBE fixture (the first two fixtures
+    predate the flags: evaluate.py:93-101's configuration)."""
+    meta = [int(v) for v in g['meta']]
+    return tuple(meta[:6]) + (tuple(bool(v) for v in meta[6:9]) if len(meta) > 6 else (False, True, True))
+
+
+@pytest.mark.parametrize('name', VIBE_GOLDENS)
 def test_oracle_vibe_matches_reference_golden(name, smpl_np):
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
-    L, H, B, N, seed_w, seed_x = [int(v) for v in g['meta']]
-    state = synth.synthetic_vibe_state_dict(L, H, seed_w)
+    L, H, B, N, seed_w, seed_x, bidir, lin, res = vibe_golden_config(g)
+    state = synth.synthetic_vibe_state_dict(L, H, seed_w, bidirectional=bidir, add_linear=lin)
     x = synth.synthetic_windows(B, N, seed_x)[:, :, :2048].copy()
-    out = O.vibe_fwd(state, smpl_np, x, L, J_regressor=smpl_np['J_regressor_h36m'])
+    if 'theta' not in g.files:                            # no linear and hidden != 2048: encoder only
+        enc, _ = O.split_state_dict(state, torch.float32)
+        feat = O.vibe_encoder_fwd(enc, torch.from_numpy(x), L, res)
+        assert feat.shape == (B, N, H) and np.abs(feat.numpy() - g['feature']).max() < 2e-5
+        return
+    out = O.vibe_fwd(state, smpl_np, x, L, J_regressor=smpl_np['J_regressor_h36m'], use_residual=res)
     assert np.abs(out['feature'].numpy().reshape(B, N, 2048) - g['feature']).max() < 2e-5
     assert np.abs(out['kp_3d'].numpy().reshape(B, N, 14, 3) - g['kp_3d']).max() < 2e-5
     assert np.abs(out['rotmat'].numpy().reshape(B, N, 24, 3, 3) - g['rotmat']).max() < 2e-5
