@@ -171,11 +171,94 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
   }
 }
 
+// The same conversion for a handful of rows (one window, a few clips): one workgroup per row, a thread per 8 consecutive k
+// (= one 16-byte run of either layout), the row's maximum through one LDS round.  The 8-rows-per-block kernel above is
+// built for bandwidth; on 16 rows it is two workgroups walking 67 K-tiles each (11.6 us of a 0.2 ms forward).
+template <bool F16>
+__global__ void __launch_bounds__(256) split_rows_few_kernel(const float* __restrict__ src, long ld, long rows, int K, int Kp,
+                                                             long R, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                             float* __restrict__ row_scale, uint4* __restrict__ zero,
+                                                             long zero_n) {
+  typedef _Float16 h16x8v __attribute__((ext_vector_type(8)));
+  __shared__ float wmax[4];
+  __shared__ int wbad[4];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero[i] = uint4{0u, 0u, 0u, 0u};
+  const long row = blockIdx.x;
+  const float* x = src + row * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NO = 2;                                        // octets per thread: Kp <= 4096
+  float v[NO][8];
+  float m = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    const int k0 = 8 * ((int)threadIdx.x + 256 * o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[o][i] = (k0 + i < K) ? x[k0 + i] : 0.f;
+      m = fmaxf(m, fabsf(v[o][i]));
+      bad |= !(fabsf(v[o][i]) <= 3.0e38f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  bad = __any(bad);
+  if (lane == 0) { wmax[wave] = m; wbad[wave] = bad ? 1 : 0; }
+  __syncthreads();
+  m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  bad = (wbad[0] | wbad[1] | wbad[2] | wbad[3]) != 0;
+  float sc = 1.f, inv = 1.f;
+  if (m > 0.f && !bad) {
+    int ex;
+    (void)frexpf(m, &ex);
+    int e = 14 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    sc = ldexpf(1.f, e);
+    inv = ldexpf(1.f, -e);
+  }
+  if (threadIdx.x == 0) row_scale[row] = inv;
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    const int k0 = 8 * ((int)threadIdx.x + 256 * o);
+    if (k0 >= Kp) continue;
+    h16x8v h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float a = v[o][i] * sc;
+      if (F16) {
+        const _Float16 hh = (_Float16)a;
+        h[i] = hh; l[i] = (_Float16)(a - (float)hh);
+      } else {
+        half_t hh, ll;
+        split_hi_lo(a, hh, ll);
+        h[i] = hh; l[i] = ll;
+      }
+    }
+    const long off = F16 ? plane16_index(row, k0, R) : plane_index(row, k0, R);
+    *(h16x8v*)(hi + off) = h;
+    *(h16x8v*)(lo + off) = l;
+  }
+}
+
+static int split_few_max_rows() {
+  static const int v = [] { const char* e = getenv("TEPOSE_SPLIT_FEW_MAX_ROWS"); return e ? atoi(e) : 64; }();
+  return v;
+}
+
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
                              float* row_scale, hipStream_t s, void* zero, size_t zero_bytes) {
   if (rows <= 0) return hipSuccess;
   if (zero_bytes % 16 != 0) return hipErrorInvalidValue;
   if (Kp > 64 * 2 * 17 || Kp > kRowsLd || (Kp & 31)) return hipErrorInvalidValue;        // the [., 2144] input rows
+  if (rows <= split_few_max_rows() && Kp <= 4096) {
+    if (fmt16)
+      hipLaunchKernelGGL((split_rows_few_kernel<true>), dim3((unsigned)rows), dim3(256), 0, s, src, ld, rows, K, Kp, R,
+                         (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
+    else
+      hipLaunchKernelGGL((split_rows_few_kernel<false>), dim3((unsigned)rows), dim3(256), 0, s, src, ld, rows, K, Kp, R,
+                         (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
+    return hipGetLastError();
+  }
   const dim3 grid((unsigned)((rows + 7) / 8));
   if (fmt16)
     hipLaunchKernelGGL((split_rows_kernel<17, true>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
