@@ -1485,10 +1485,15 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
   sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
   sc.xr_val = Bl + m->smpl.xr_val;
-  CK(launch_smpl_prep(sc, w.xs, N, w.pf, w.amat, w.posed, rotmat, theta, s, w.split ? w.pfP.hi : nullptr,
-                      w.split ? w.pfP.lo : nullptr, w.pfP.kst));
-  CK((hipError_t)blend_shapes(m, w, N, s));
-  CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
+  if (smpl_small_ok(sc, N)) {     // a window or a few: prep + blend shapes + skinning as one launch (smpl.hip)
+    CK(launch_smpl_small(sc, 0, w.xs, kState, w.xs + kNPose, kState, w.xs + 154, kState, N, w.amat, w.posed, rotmat, theta,
+                         verts, s));
+  } else {
+    CK(launch_smpl_prep(sc, w.xs, N, w.pf, w.amat, w.posed, rotmat, theta, s, w.split ? w.pfP.hi : nullptr,
+                        w.split ? w.pfP.lo : nullptr, w.pfP.kst));
+    CK((hipError_t)blend_shapes(m, w, N, s));
+    CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
+  }
   JregPacked jr{};
   if (jreg_packed) {
     const int* p = (const int*)jreg_packed;
@@ -1562,10 +1567,15 @@ int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, cons
   carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
-  CK(launch_smpl_prep_pose(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, N, w.pf, w.amat, w.posed, s,
-                           w.split ? w.pfP.hi : nullptr, w.split ? w.pfP.lo : nullptr, w.pfP.kst));
-  CK((hipError_t)blend_shapes(m, w, N, s));
-  CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
+  if (smpl_small_ok(sc, N)) {
+    CK(launch_smpl_small(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, nullptr, 0, N, w.amat, w.posed, nullptr,
+                         nullptr, verts, s));
+  } else {
+    CK(launch_smpl_prep_pose(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, N, w.pf, w.amat, w.posed, s,
+                             w.split ? w.pfP.hi : nullptr, w.split ? w.pfP.lo : nullptr, w.pfP.kst));
+    CK((hipError_t)blend_shapes(m, w, N, s));
+    CK(launch_smpl_skin(sc, w.vposed, w.amat, N, verts, s));
+  }
   if (joints49) CK(launch_smpl_joints(sc, nullptr, verts, w.posed, nullptr, N, joints49, nullptr, s));
   return 0;
 }
@@ -1595,6 +1605,10 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
   carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
+  if (smpl_small_ok(sc, N)) {
+    CK(launch_smpl_small(sc, 1, theta + 3, kTheta, theta + 75, kTheta, nullptr, 0, N, w.amat, nullptr, nullptr, nullptr, verts, s));
+    return 0;
+  }
   CK(launch_smpl_prep_pose(sc, 1, theta + 3, kTheta, theta + 75, kTheta, N, w.pf, w.amat, nullptr, s,
                            w.split ? w.pfP.hi : nullptr, w.split ? w.pfP.lo : nullptr, w.pfP.kst));
   CK((hipError_t)blend_shapes(m, w, N, s));

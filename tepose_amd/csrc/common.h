@@ -118,6 +118,10 @@ hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pos
                                  const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
                                  hipStream_t s, void* pf_hi = nullptr, void* pf_lo = nullptr, long pf_kst = 0);
 // measurement only: blend shapes + skinning as one wave per person
+bool smpl_small_ok(const SmplConsts& c, int N);
+hipError_t launch_smpl_small(const SmplConsts& c, int mode, const float* pose, int pose_ld, const float* betas, int betas_ld,
+                             const float* cam, int cam_ld, int N, float* Amat, float* posed, float* rotmat, float* theta,
+                             float* verts, hipStream_t s);
 hipError_t launch_smpl_person(const SmplConsts& c, const float* pf, const float* Amat, int N, float* verts, hipStream_t s);
 hipError_t launch_lbs_compact(const float* lbsW, int* cidx, float* cval, int* max_nnz, hipStream_t s);
 hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,

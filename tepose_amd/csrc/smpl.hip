@@ -178,14 +178,10 @@ __device__ __forceinline__ void pf_put(const PrepIn& in, float* f, long p, int c
     split_hi_lo(v, in.pf_hi[o], in.pf_lo[o]);
   }
 }
-__global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth, PrepIn in, int N,
-                                                        float* __restrict__ pf, float* __restrict__ Amat,
-                                                        float* __restrict__ posed,
-                                                        float* __restrict__ rotmat,
-                                                        float* __restrict__ theta) {
-  const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= N) return;                       // wave-uniform
+// one person's preparation by one wave (lane = joint): A_p[24][12] skinning transforms, f[224] pose-feature row (also as
+// planes when in.pf_hi is set), and -- where asked -- posed joints [24][3], rotation matrices [24][9], theta[85]
+__device__ __forceinline__ void smpl_prep_person(const SmplConsts& c, int maxdepth, const PrepIn& in, int p, int lane,
+                                                 float* A_p, float* f, float* posed_p, float* rotmat_p, float* th) {
   const float* x = in.pose + (long)p * in.pose_ld;
   const float* bx = in.betas + (long)p * in.betas_ld;
   const int mode = in.mode;
@@ -219,7 +215,7 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
     rot6d_to_rotmat(x + 6 * j, R);
   }
   float aa[3] = {0.f, 0.f, 0.f};
-  if (theta) rotmat_to_aa(R, aa);
+  if (th) rotmat_to_aa(R, aa);
 
   // rest joint of this lane and of its parent
   float Jr[3];
@@ -260,20 +256,18 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
     }
   }
   if (act) {
-    float* Ao = Amat + ((long)p * kNJ + j) * 12;
+    float* Ao = A_p + j * 12;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       Ao[r * 4 + 0] = G[r][0]; Ao[r * 4 + 1] = G[r][1]; Ao[r * 4 + 2] = G[r][2];
       Ao[r * 4 + 3] = G[r][3] - (G[r][0] * Jr[0] + G[r][1] * Jr[1] + G[r][2] * Jr[2]);
-      if (posed) posed[((long)p * kNJ + j) * 3 + r] = G[r][3];
-      if (rotmat) {
-        float* Ro = rotmat + ((long)p * kNJ + j) * 9;
+      if (posed_p) posed_p[j * 3 + r] = G[r][3];
+      if (rotmat_p) {
+        float* Ro = rotmat_p + j * 9;
         Ro[r * 3 + 0] = R[r][0]; Ro[r * 3 + 1] = R[r][1]; Ro[r * 3 + 2] = R[r][2];
       }
     }
-    float* th = theta ? theta + (long)p * kTheta : nullptr;
     if (th) { th[3 + 3 * j + 0] = aa[0]; th[3 + 3 * j + 1] = aa[1]; th[3 + 3 * j + 2] = aa[2]; }
-    float* f = pf + (long)p * kBlendK;
     if (j >= 1) {
 #pragma unroll
       for (int r = 0; r < 3; ++r)
@@ -288,6 +282,19 @@ __global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdep
       if (th && in.cam) { const float* cm = in.cam + (long)p * in.cam_ld; th[0] = cm[0]; th[1] = cm[1]; th[2] = cm[2]; }
     }
   }
+}
+
+__global__ void __launch_bounds__(256) smpl_prep_kernel(SmplConsts c, int maxdepth, PrepIn in, int N,
+                                                        float* __restrict__ pf, float* __restrict__ Amat,
+                                                        float* __restrict__ posed,
+                                                        float* __restrict__ rotmat,
+                                                        float* __restrict__ theta) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= N) return;                       // wave-uniform
+  smpl_prep_person(c, maxdepth, in, p, lane, Amat + (long)p * kNJ * 12, pf + (long)p * kBlendK,
+                   posed ? posed + (long)p * kNJ * 3 : nullptr, rotmat ? rotmat + (long)p * kNJ * 9 : nullptr,
+                   theta ? theta + (long)p * kTheta : nullptr);
 }
 
 // ------------------------------------------------------------------ skinning
@@ -413,10 +420,114 @@ hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const floa
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ few persons (N <= kSmallN): prep + blend shapes + skinning in one launch
+// One window is one person: the four-launch chain above then costs four launch latencies for 19 MB of table reads.
+// Here a workgroup owns 32 vertices: it first issues the loads of its 96 blend-shape rows (224 floats each; a wave owns
+// 24 rows, 8 lanes share a row -- these do not depend on the pose), its waves < N then prepare one person
+// each into LDS (every workgroup repeats the 24-joint chain: ~3 us of latency against a grid-wide hand-off), the rows
+// are reduced against the pose features in LDS (fp32 FMA, exact-fp32 tables; 8 lanes per row, so 3 shuffle steps) and the 32 x N vertices skinned from LDS.
+// Workgroup 0 also writes the per-person outputs (theta, rotation matrices, posed joints, transforms).
+constexpr int kSmallN = 4;
+constexpr int kSmallVB = 32;                       // vertices per workgroup
+__global__ void __launch_bounds__(256) smpl_small_kernel(SmplConsts c, int maxdepth, PrepIn in, int N,
+                                                         float* __restrict__ Amat, float* __restrict__ posed,
+                                                         float* __restrict__ rotmat, float* __restrict__ theta,
+                                                         float* __restrict__ verts) {
+  __shared__ __attribute__((aligned(16))) float sA[kSmallN][kNJ * 12];
+  __shared__ __attribute__((aligned(16))) float spf[kSmallN][kBlendK];
+  __shared__ float svp[kSmallN][3 * kSmallVB];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // blend rows: 8 lanes per row (28 consecutive k each = 7 x 16 bytes), 8 rows per wave and pass, 3 passes per wave
+  constexpr int NPASS = 3 * kSmallVB / 32, KQ = kBlendK / 8 / 4;
+  static_assert(kBlendK == 8 * 4 * KQ && NPASS * 32 == 3 * kSmallVB, "row cut");
+  const int row0 = blockIdx.x * 3 * kSmallVB;
+  const int sub = lane & 7;
+  f4 wv[NPASS][KQ];
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int gr = row0 + wave * (8 * NPASS) + i * 8 + (lane >> 3);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+      wv[i][q] = gr < 3 * kNV ? *(const f4*)(c.blendW + (long)gr * kBlendK + sub * (4 * KQ) + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+  }
+  // skinning operands of this thread's (person, vertex)
+  const int sp = threadIdx.x / kSmallVB, sv = blockIdx.x * kSmallVB + (threadIdx.x % kSmallVB);
+  const bool sok = sp < N && sv < kNV;
+  int jx[4];
+  float wj[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { jx[k] = sok ? c.lbs_cidx[sv * 4 + k] * 12 : 0; wj[k] = sok ? c.lbs_cval[sv * 4 + k] : 0.f; }
+  if (wave < N) {
+    const bool out = blockIdx.x == 0;
+    PrepIn q = in;
+    q.pf_hi = nullptr; q.pf_lo = nullptr;
+    smpl_prep_person(c, maxdepth, q, wave, lane, sA[wave], spf[wave], out && posed ? posed + (long)wave * kNJ * 3 : nullptr,
+                     out && rotmat ? rotmat + (long)wave * kNJ * 9 : nullptr, out && theta ? theta + (long)wave * kTheta : nullptr);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && Amat)
+    for (int i = threadIdx.x; i < N * kNJ * 12; i += 256) Amat[i] = sA[i / (kNJ * 12)][i % (kNJ * 12)];
+  for (int p = 0; p < N; ++p) {
+    f4 f[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) f[q] = *(const f4*)(&spf[p][sub * (4 * KQ) + 4 * q]);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) a += wv[i][q][0] * f[q][0] + wv[i][q][1] * f[q][1] + wv[i][q][2] * f[q][2] + wv[i][q][3] * f[q][3];
+      a += __shfl_xor(a, 1);
+      a += __shfl_xor(a, 2);
+      a += __shfl_xor(a, 4);
+      if (sub == 0) svp[p][wave * (8 * NPASS) + i * 8 + (lane >> 3)] = a;
+    }
+  }
+  __syncthreads();
+  if (sok) {
+    float t[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) t[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f4 r0 = *(const f4*)(&sA[sp][jx[k]]), r1 = *(const f4*)(&sA[sp][jx[k] + 4]), r2 = *(const f4*)(&sA[sp][jx[k] + 8]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t[e] += wj[k] * r0[e]; t[4 + e] += wj[k] * r1[e]; t[8 + e] += wj[k] * r2[e]; }
+    }
+    const int lv = threadIdx.x % kSmallVB;
+    const float x = svp[sp][3 * lv], y = svp[sp][3 * lv + 1], z = svp[sp][3 * lv + 2];
+    float* o = verts + ((long)sp * kNV + sv) * 3;
+    o[0] = t[0] * x + t[1] * y + t[2] * z + t[3];
+    o[1] = t[4] * x + t[5] * y + t[6] * z + t[7];
+    o[2] = t[8] * x + t[9] * y + t[10] * z + t[11];
+  }
+}
+
+static int smpl_small_max_n() {
+  static const int v = [] {
+    const char* e = getenv("TEPOSE_SMPL_SMALL_MAX_N");
+    const int n = e ? atoi(e) : kSmallN;
+    return n < 0 ? 0 : (n > kSmallN ? kSmallN : n);
+  }();
+  return v;
+}
+bool smpl_small_ok(const SmplConsts& c, int N) { return c.lbs_sparse && N >= 1 && N <= smpl_small_max_n() && 256 / kSmallVB >= N; }
+
+// in: PrepIn-style source (mode 0: regressor state rows xs; 1: axis-angle; 2: rotation matrices)
+hipError_t launch_smpl_small(const SmplConsts& c, int mode, const float* pose, int pose_ld, const float* betas, int betas_ld,
+                             const float* cam, int cam_ld, int N, float* Amat, float* posed, float* rotmat, float* theta,
+                             float* verts, hipStream_t s) {
+  PrepIn in{pose, pose_ld, betas, betas_ld, cam, cam_ld, mode, nullptr, nullptr, 0};
+  hipLaunchKernelGGL(smpl_small_kernel, dim3((kNV + kSmallVB - 1) / kSmallVB), dim3(256), 0, s, c, c.maxdepth, in, N, Amat,
+                     posed, rotmat, theta, verts);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ joints + projection
 // block per person.  Regressed joints = CSR rows (9 extra rows always; 17 h36m rows when the
 // evaluation regressor is given).  kp_3d = 14 (h36m path) or 49 joints; kp_2d = projection.
-__global__ void __launch_bounds__(256) smpl_joints_kernel(SmplConsts c, JregPacked jr, int use_jr,
+template <int NT>
+__global__ void __launch_bounds__(NT) smpl_joints_kernel(SmplConsts c, JregPacked jr, int use_jr,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ posed,
                                                           const float* __restrict__ xs, int N,
@@ -429,7 +540,7 @@ __global__ void __launch_bounds__(256) smpl_joints_kernel(SmplConsts c, JregPack
   const int* ptr = use_jr ? jr.ptr : c.xr_ptr;
   const int* idx = use_jr ? jr.idx : c.xr_idx;
   const float* val = use_jr ? jr.val : c.xr_val;
-  for (int row = wave; row < nrows; row += 4) {
+  for (int row = wave; row < nrows; row += NT / 64) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const int e1 = ptr[row + 1];
     for (int e = ptr[row] + lane; e < e1; e += 64) {
@@ -481,8 +592,10 @@ hipError_t launch_smpl_joints(const SmplConsts& c, const JregPacked* jr, const f
                               hipStream_t s) {
   if (N <= 0) return hipSuccess;
   JregPacked j = jr ? *jr : JregPacked{nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(smpl_joints_kernel, dim3(N), dim3(256), 0, s, c, j, jr ? 1 : 0, verts, posed, xs,
-                     N, kp3d, kp2d);
+  if (N <= 16)          // a handful of persons: 16 waves per person share the 9 / 17 regressor rows (8.0 -> us at N = 1)
+    hipLaunchKernelGGL(smpl_joints_kernel<1024>, dim3(N), dim3(1024), 0, s, c, j, jr ? 1 : 0, verts, posed, xs, N, kp3d, kp2d);
+  else
+    hipLaunchKernelGGL(smpl_joints_kernel<256>, dim3(N), dim3(256), 0, s, c, j, jr ? 1 : 0, verts, posed, xs, N, kp3d, kp2d);
   return hipGetLastError();
 }
 
