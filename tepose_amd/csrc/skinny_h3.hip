@@ -149,9 +149,8 @@ __global__ void __launch_bounds__(256) skinny_gru_h3_kernel(H3Batch batch, int M
 // a block owns 16*MT rows x 48 columns, K split over the 4 waves exactly as above.
 // NT: 16-column tiles per block (3 = 48 columns; 1 = 16 columns for narrow products of few rows, where 48-column blocks
 // would leave most CUs without a weight stream: N = 2048 -> 43 blocks vs 128)
-template <int MT, int NT = 3>
-__global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) {
-  constexpr int NW = 4;
+template <int MT, int NT = 3, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) skinny_gemm_h3_kernel(H3ArgsBatch batch) {
   const H3Args& a = batch.p[blockIdx.z];          // up to 3 independent products per launch (their own M, N, K)
   if ((int)blockIdx.x * (16 * NT) >= a.N || (int)blockIdx.y * 16 * MT >= a.M) return;   // the grid covers the largest one
   __shared__ __attribute__((aligned(16))) float red[NW * MT * NT * 256];
@@ -233,6 +232,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_h3_kernel(H3ArgsBatch batch) 
       for (int ee = 0; ee < 4; ++ee)
         red[((wave * MT * NT + i * NT + t) * 4 + ee) * 64 + lane] = acc[i][t][ee] + accx[i][t][ee] * (1.f / kLoScale);
   __syncthreads();
+  if (NW > 4 && threadIdx.x >= 256) return;      // 4 accumulator registers: the first 256 threads finish one element each
   const int e = threadIdx.x >> 6;                // accumulator register of the element this thread finishes
   const float sc = a.scale != 0.f ? a.scale : 1.f;
 #pragma unroll
@@ -269,8 +269,14 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
   for (int i = 0; i < b.n; ++i) { maxM = b.p[i].M > maxM ? b.p[i].M : maxM; maxN = b.p[i].N > maxN ? b.p[i].N : maxN; }
   if (b.n <= 0 || maxM <= 0 || maxN <= 0) return hipSuccess;
   const int nt = (maxN + 47) / 48;
-  if (maxM <= 32 && nt * b.n < 96) {          // few rows, narrow product: 16-column blocks put a weight stream on 3x the CUs
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
+  static const int nt1_max = [] { const char* e = getenv("TEPOSE_SKINNY_NT1_BELOW"); return e ? atoi(e) : 96; }();
+  if (maxM <= 32 && nt * b.n < nt1_max) {          // few rows, narrow product: 16-column blocks put a weight stream on 3x the CUs
+    // (<= 128 such blocks -- the 2048-column tail linears: 8 waves split K, twice the weight bytes in flight per CU)
+    static const bool w8 = [] { const char* e = getenv("TEPOSE_SKINNY_W8"); return e ? atoi(e) != 0 : true; }();
+    if (w8 && (maxN + 15) / 16 * b.n <= 128)
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 8>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
+    else
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
   } else if (maxM <= 32) {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else if (maxM <= 64 && nt * b.n < 96 && narrow64()) {
