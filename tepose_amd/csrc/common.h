@@ -298,6 +298,6 @@ hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, in
 hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);
 size_t gemm_h3s_ws_bytes(int M, int N, int K);
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
-                               int K, float pA, float pW, void* ws, hipStream_t s);
+                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias = nullptr);
 
 }  // namespace tepose

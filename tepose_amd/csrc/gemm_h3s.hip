@@ -340,12 +340,242 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
   }
 }
 
+// The plain product as a PERSISTENT kernel: 256 workgroups (one per CU) walk the 256 x 256 tiles b, b + 256, ...
+// What it buys over one workgroup per tile: the C stores of a tile (256 KB) used to drain at the end of its workgroup,
+// with the CU's matrix pipes idle until the next workgroup had refilled the ring (ablation: ~10 % of the projection).
+// Here the next tile's first three stages are requested BEFORE the stores of the finished tile are issued, and the
+// first three K-tiles of the next tile only wait for their own stage (vmcnt allows the 32 younger stores to stay in
+// flight), so the stores drain under the next tile's MFMAs.  To get a countable, small number of stores the product is
+// formed transposed (W fragments as the MFMA's row operand): a lane then owns 4 consecutive columns of one row of C,
+// i.e. 32 16-byte stores per wave instead of 128 4-byte ones.  Same fragments, same K order, same accumulators.
+__global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int tilesM, int tilesN) {
+  constexpr int WMF = 2, WNT = 4, NWN = 2, NST = 4;
+  constexpr int HM = 256, HN = 256, HK = 16, RB = HK * 2, RPI = 1024 / RB;
+  constexpr int STAGE = (2 * HM + 2 * HN) * RB, TOT = STAGE / 1024, Q = TOT / 8;
+  constexpr int NSTORE = WMF * WNT * 4;                   // 16-byte stores per wave and tile
+  static_assert(TOT % 8 == 0 && NST * STAGE + HN * 4 <= 160 * 1024 && 2 * Q + NSTORE <= 63, "ring / vmcnt budget");
+  typedef float f32x4p __attribute__((ext_vector_type(4)));
+  // ONE __shared__ object (ring + the tile's bias row): with two, hipcc tags LDS accesses with alias scopes, starts tracking
+  // the LDS-DMA requests per object and answers every fragment read with s_waitcnt vmcnt(0) -- no DMA stays in flight
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE + HN * 4];
+  float* sbias = (float*)(lds + NST * STAGE);
+  const int ntiles = tilesM * tilesN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int r = lane & 31, h = lane >> 5;
+  const int i0 = wave * Q;
+
+  // this lane's rows of the stage image [A_hi | A_lo | W_hi | W_lo] (the same for every tile)
+  bool isA[Q], isLo[Q];
+  int lrow[Q];
+  long kst[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    int ri = (i0 + q) * RPI + lane / 2;
+    isA[q] = ri < 2 * HM;
+    if (!isA[q]) ri -= 2 * HM;
+    isLo[q] = ri >= (isA[q] ? HM : HN);
+    lrow[q] = isLo[q] ? ri - (isA[q] ? HM : HN) : ri;
+    const long ks = (isA[q] ? a.a_kst : a.w_kst) * 2;
+    kst[q] = ((long)__builtin_amdgcn_readfirstlane((int)(ks >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ks);
+  }
+  const char* gbase[Q];                                   // plane base of each row role (+ this lane's 16-byte half), once
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    gbase[q] = (const char*)(isA[q] ? (isLo[q] ? a.Al : a.Ah) : (isLo[q] ? a.Wl : a.Wh)) + 16 * (lane & 1);
+  const char* gsrc[Q];
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int tile) {
+    int tm, tn;
+    h3s_tile_of_block(tile, ntiles, tilesM, tilesN, tm, tn);
+    m0 = tm * HM; n0 = tn * HN;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const long grow = isA[q] ? min((long)m0 + lrow[q], (long)a.M - 1) : (long)n0 + lrow[q];
+      gsrc[q] = gbase[q] + grow * RB;
+    }
+  };
+  auto dma_part = [&](int stage, int q) {
+    glds16s(gsrc[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
+    gsrc[q] += kst[q];
+  };
+  const int sx = 16 * (h ^ ((r >> 3) & 1));
+  int aoff[WMF], boff[WNT];
+#pragma unroll
+  for (int i = 0; i < WMF; ++i) aoff[i] = (wm * 32 * WMF + i * 32 + r) * RB + sx;
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) boff[j] = 2 * HM * RB + (wn * 32 * WNT + j * 32 + r) * RB + sx;
+  constexpr int A_LO = HM * RB, W_LO = HN * RB;
+  const int KT = a.Kp / HK;
+  const bool overlap = KT >= 2 * NST;                     // the store-drain accounting below needs a few K-tiles
+  const bool vec = (((size_t)a.C | (size_t)a.bias) & 15) == 0 && (a.ldc & 3) == 0;
+
+  f32x16 acc[WMF][WNT];
+  auto ktile = [&](int kt, auto dma, auto extra) __attribute__((always_inline)) {
+    constexpr bool DMA = decltype(dma)::value;
+    constexpr int EXTRA = decltype(extra)::value;         // younger stores of the previous tile that may stay in flight
+    if constexpr (DMA) {
+      wait_vms<2 * Q + EXTRA>();
+    } else {
+      const int newer = min(NST - 2, KT - 1 - kt);
+      if (newer >= 2) wait_vms<2 * Q>();
+      else if (newer == 1) wait_vms<Q>();
+      else wait_vms<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* st = lds + (kt % NST) * STAGE;
+    h16x8 ah[WMF], al[WMF], bh[WNT], bl[WNT];
+#pragma unroll
+    for (int i = 0; i < WMF; ++i) {
+      ah[i] = *(const h16x8*)(st + aoff[i]);
+      al[i] = *(const h16x8*)(st + A_LO + aoff[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      bh[j] = *(const h16x8*)(st + boff[j]);
+      bl[j] = *(const h16x8*)(st + W_LO + boff[j]);
+    }
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        const int t = i * WNT + j;
+#pragma unroll
+        for (; q < (t + 1) * Q / (WMF * WNT); ++q)
+          if constexpr (DMA) dma_part(kt + NST - 1, q);
+      }
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  setup(tile);
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < KT) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) dma_part(p, q);
+    }
+  bool pending = false;                                   // NSTORE stores of the previous tile are younger than this tile's first stages
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int kt = 0;
+    if (pending) {
+      for (; kt < NST - 1; ++kt) ktile(kt, std::true_type{}, std::integral_constant<int, NSTORE>{});
+    }
+    for (; kt + NST - 1 < KT; ++kt) ktile(kt, std::true_type{}, std::integral_constant<int, 0>{});
+    for (; kt < KT; ++kt) ktile(kt, std::false_type{}, std::integral_constant<int, 0>{});
+    wait_vms<0>();
+
+    const int tm0 = m0, tn0 = n0;                          // the finished tile
+    const int next = tile + (int)gridDim.x;
+    const bool full = tm0 + HM <= a.M && tn0 + HN <= a.N && vec;
+    // epilogue operands first: nothing may be loaded from global memory between the next tile's requests and the stores
+    // (the tile's 256 bias values wait in LDS, outside the ring)
+    float rs[WMF];
+    if (full) {
+      if (tid < 64)
+        *(f32x4p*)(sbias + 4 * tid) = a.bias ? *(const f32x4p*)(a.bias + tn0 + 4 * tid) : f32x4p{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < WMF; ++i) {
+        const int row = tm0 + wm * 32 * WMF + i * 32 + r;
+        rs[i] = a.row_scale ? a.row_scale[row] * a.inv_scale : a.inv_scale;
+      }
+      wait_vms<0>();
+    }
+    const bool ov = full && overlap && next < ntiles;
+    __syncthreads();                                       // every wave has read the last stages: the ring is free; sbias is written
+    if (next < ntiles) {
+      setup(next);
+      if (ov) {
+#pragma unroll
+        for (int p = 0; p < NST - 1; ++p)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) dma_part(p, q);
+      }
+    }
+    if (full) {
+      // the bias reads are asm: hipcc's wait-count pass answers a C++ LDS read behind LDS-DMA requests with
+      // s_waitcnt vmcnt(0) in the next K-tiles, i.e. exactly the store drain this loop is built to avoid
+      const unsigned sb = (unsigned)(size_t)sbias + (unsigned)(wn * 32 * WNT + 4 * h) * 4u;
+      float* c0 = a.C + (long)(tm0 + wm * 32 * WMF + r) * a.ldc + tn0 + wn * 32 * WNT + 4 * h;
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        f32x4p bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[g]) : "v"(sb), "n"((j * 32 + 8 * g) * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4p v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = acc[i][j][4 * g + c] * rs[i] + bq[g][c];
+            *(f32x4p*)(c0 + (long)i * 32 * a.ldc + j * 32 + 8 * g) = v;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WMF; ++i) {
+        const int row = tm0 + wm * 32 * WMF + i * 32 + r;
+        if (row >= a.M) continue;
+        const float rsv = a.row_scale ? a.row_scale[row] * a.inv_scale : a.inv_scale;
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int col = tn0 + wn * 32 * WNT + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (col < a.N) a.C[(long)row * a.ldc + col] = acc[i][j][e] * rsv + (a.bias ? a.bias[col] : 0.f);
+          }
+      }
+    }
+    if (next >= ntiles) break;
+    tile = next;
+    if (!ov) {                                            // partial tile / short K: drain, then fill the ring as a first tile does
+      wait_vms<0>();
+#pragma unroll
+      for (int p = 0; p < NST - 1; ++p)
+        if (p < KT) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) dma_part(p, q);
+        }
+    }
+    pending = ov;
+  }
+}
+
+static bool h3s_persist() {
+  static const bool v = [] { const char* e = getenv("TEPOSE_H3S_PERSIST"); return e ? atoi(e) != 0 : true; }();
+  return v;
+}
+
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   H3SBatch b{};
   b.p[0] = a; b.n = 1;
-  hipLaunchKernelGGL((gemm_h3s_kernel<2, 4, 4, 2, false>), dim3(tilesM * tilesN, 1), dim3(512), 0, s, b, tilesM, tilesN);
+  if (h3s_persist()) {
+    const int nt = tilesM * tilesN;
+    hipLaunchKernelGGL(gemm_h3s_persist_kernel, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
+  } else {
+    hipLaunchKernelGGL((gemm_h3s_kernel<2, 4, 4, 2, false>), dim3(tilesM * tilesN, 1), dim3(512), 0, s, b, tilesM, tilesN);
+  }
   return hipGetLastError();
 }
 
@@ -368,7 +598,7 @@ size_t gemm_h3s_ws_bytes(int M, int N, int K) {
 
 // test / bench entry: fp32 A[M,K], W[N,K] (no bias) -> scaled planes in ws -> C; pA / pW: power-of-two operand scales
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
-                               int K, float pA, float pW, void* ws, hipStream_t s) {
+                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias) {
   const int Kp = round_up(K, 16), Np = round_up(N, 256);
   char* p = (char*)ws;
   _Float16* Ah = (_Float16*)p; p += align_up((size_t)M * Kp * 2, 256);
@@ -379,7 +609,7 @@ hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ld
   if (e != hipSuccess) return e;
   if ((e = launch_split_planes16(A, lda, M, K, Kp, M, pA, Ah, Al, s)) != hipSuccess) return e;
   if ((e = launch_split_planes16(W, ldw, N, K, Kp, Np, pW, Wh, Wl, s)) != hipSuccess) return e;
-  H3SArgs a{Ah, Al, (long)M * 16, Wh, Wl, (long)Np * 16, Kp, C, ldc, nullptr, 1.f / (pA * pW), M, N};
+  H3SArgs a{Ah, Al, (long)M * 16, Wh, Wl, (long)Np * 16, Kp, C, ldc, bias, 1.f / (pA * pW), M, N};
   return launch_gemm_h3s(a, s);
 }
 

@@ -144,3 +144,39 @@ def test_both_numerics_modes_vs_fp64_oracle_at_the_published_size(monkeypatch, c
             assert e < 2e-5, (mode, k, e)
         assert (got['theta'][:, :3] - ref['theta'][:, :3]).abs().max() < 2e-5
         assert (got['theta'][:, 75:] - ref['theta'][:, 75:]).abs().max() < 2e-5
+
+
+def test_single_accumulator_gemm_persistent_tiles_against_fp64(monkeypatch):
+    """csrc/gemm_h3s.hip, the plain product as a persistent kernel (256 workgroups walking the 256 x 256 tiles, the next
+    tile's stages requested before the finished tile's stores): more tiles than workgroups, partial edge tiles (their own
+    drained path), unaligned C rows (scalar stores), short K (no overlap), with and without bias; and the one-workgroup-
+    per-tile kernel (TEPOSE_H3S_PERSIST is latched per process, so that one is compared in tools/h3_bench.py)."""
+    from tepose_amd import _lib
+    lib = _lib.load()
+    monkeypatch.setenv('TEPOSE_H3S', '1')
+    g = torch.Generator(device='cuda').manual_seed(9)
+    cases = [(8192, 2304, 2144 // 32 * 32, 2304, True),      # 32 x 9 = 288 full tiles: 32 workgroups take a second tile
+             (5000, 5000, 256, 5000, True),                   # 400 tiles, partial last row / column of tiles
+             (4096, 4608, 64, 4608, False),                   # KT = 4: the no-overlap path, 288 tiles
+             (2100, 2050, 512, 2051, True),                   # C rows not 16-byte aligned: scalar stores
+             (300, 200, 128, 200, False), (256, 256, 1024, 256, True), (65536, 512, 96, 512, True)]
+    for M, N, K, ldc, use_bias in cases:
+        A = torch.randn(M, K, device='cuda', generator=g) * 3.0             # |a| * 256 < 65504
+        W = torch.randn(N, K, device='cuda', generator=g) * 0.05            # |w| * 16384 < 65504
+        b = torch.randn(N, device='cuda', generator=g) if use_bias else None
+        C = torch.full((M, ldc), float('nan'), device='cuda')
+        ws = torch.empty(lib.tepose_gemm_h3_workspace_bytes(M, N, K), dtype=torch.uint8, device='cuda')
+        rc = lib.tepose_gemm_h3_f32(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr() if use_bias else None, C.data_ptr(), ldc,
+                                    M, N, K, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = A.double() @ W.double().t()
+        if use_bias:
+            ref += b.double()
+        mag = (A.double().abs() @ W.double().abs().t()).max().item() + 1.0
+        err = (C[:, :N].double() - ref).abs().max().item()
+        assert err < 3e-6 * mag, (M, N, K, err, mag)
+        assert torch.isnan(C[:, N:]).all()                                  # nothing written past column N
+        C2 = torch.full((M, ldc), float('nan'), device='cuda')
+        lib.tepose_gemm_h3_f32(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr() if use_bias else None, C2.data_ptr(), ldc,
+                               M, N, K, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(C[:, :N], C2[:, :N])                             # deterministic
