@@ -91,3 +91,35 @@ def test_smpl_module_is_callable_like_the_reference_class():
     assert out2.vertices.is_cuda
     assert (out2.vertices.cpu() - v_ref).abs().max() < 1e-4
     assert (out2.joints.cpu() - j_ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5])
+def test_smpl_few_persons_every_input_mode(n):
+    """1-4 persons run prep + blend shapes + skinning as one launch (csrc/smpl.hip smpl_small_kernel), 5 the four-launch
+    chain: axis-angle input (pose2rot=True), rotation-matrix input (evaluate.py:279-286) and theta rows (MPVPE ground truth,
+    eval_utils.py:155-169) against the oracle, and the two paths against each other on the same persons."""
+    from oracle import tepose_ref as O
+    from tepose_amd.metrics import gt_vertices
+    from tepose_amd.smpl import SMPL
+    from tepose_amd.testing import build_model
+    smpl_np = synth.synthetic_smpl(0)
+    smpl = SMPL.from_tables(smpl_np).cuda()
+    theta = synth.synthetic_windows(1, 12, 91)[0, :11, 2048:]
+    theta[1, 3:75] *= 9.0                                   # a far-from-rest pose among them
+    pose = torch.from_numpy(theta[:, 3:75].copy()).view(11, 24, 3)
+    betas = torch.from_numpy(theta[:, 75:].copy())
+    s = O.smpl_tensors(smpl_np)
+    R = O.batch_rodrigues(pose.reshape(-1, 3)).view(11, 24, 3, 3)
+    v_ref, posed = O.lbs(s, betas, R)
+    j_ref = O.smpl_joints49(s, v_ref, posed)
+    a = smpl(betas=betas[:n].cuda(), body_pose=pose[:n, 1:].cuda(), global_orient=pose[:n, 0:1].cuda())
+    b = smpl(betas=betas[:n].cuda(), body_pose=R[:n, 1:].cuda(), global_orient=R[:n, 0:1].cuda(), pose2rot=False)
+    for out in (a, b):
+        assert out.vertices.shape == (n, 6890, 3) and out.joints.shape == (n, 49, 3)
+        assert (out.vertices.cpu() - v_ref[:n]).abs().max() < 1e-4
+        assert (out.joints.cpu() - j_ref[:n]).abs().max() < 1e-4
+    big = smpl(betas=betas.cuda(), body_pose=pose[:, 1:].cuda(), global_orient=pose[:, 0:1].cuda())       # 11 persons: the chain
+    assert (big.vertices[:n] - a.vertices).abs().max() < 1e-5
+    model, _, _ = build_model(1, 64, seed=1, device='cuda', smpl_np=smpl_np)
+    gt = gt_vertices(model, torch.from_numpy(theta[:n].copy()).cuda())
+    assert (gt.cpu() - O.verts_from_theta(smpl_np, theta[:n])).abs().max() < 1e-4
