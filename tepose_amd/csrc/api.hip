@@ -1267,7 +1267,17 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
   const half_t* w0l = w0h + rows0 * kInputP;
   // large batches of an L >= 2 model: the single-accumulator kernel (its input planes carry scale 1: same fp16 range
   // as the other layout; elements below 2^-3 keep an absolute error <= 2^-25 instead of a relative one)
-  const bool g0s = h3 && m->g0_single_acc && L >= 2 && BT >= 8192;
+  const bool g0big = h3 && m->g0_single_acc && L >= 2 && BT >= 8192;
+  // mid-size batches (cfg-B: 64 windows x 16 frames = 1024 rows): the same kernel with 128 x 288 tiles, which cut the 9 Hp
+  // columns into whole rounds of the chip; below ~512 rows the two-accumulator kernel's 128 x 128 tiles fill it better
+  static const int g0mid_min = [] { const char* e = getenv("TEPOSE_G0_MID_MIN_ROWS"); return e ? atoi(e) : 512; }();
+  bool g0mid = h3 && m->g0_single_acc && L >= 2 && !g0big && BT >= g0mid_min && BT > 128 && (9 * Hp) % 288 == 0;
+  if (g0mid) {   // whichever tile shape needs less time in whole rounds of the 256 CUs (a 128 x 288 tile takes ~2.1x a 128 x 128 one)
+    const long rt = (BT + 127) / 128;
+    const long r_mid = (rt * (9 * Hp / 288) + 255) / 256, r_old = (rt * ((9 * Hp + 127) / 128) + 255) / 256;
+    g0mid = 2.1 * (double)r_mid <= (double)r_old + 0.15;
+  }
+  const bool g0s = g0big || g0mid;
   // the caller's windows -> planes with one power-of-two scale per row (any finite fp32 magnitude; DESIGN 4b "range")
   // (with zero_sync the kernel also clears the forward's arrival counters / granules: it is the forward's first kernel)
   if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, zero_sync ? (void*)w.sync : nullptr,
@@ -1291,7 +1301,8 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       const half_t* sh = (const half_t*)(Bl + m->wih0_s);
       H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
                 Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0, w.rs};
-      CK(launch_gemm_h3s(a, s));
+      if (g0mid) CK(launch_gemm_h3s_mid(a, s));
+      else CK(launch_gemm_h3s(a, s));
     } else if (h3) {
       H3Batch b{};
       b.p[0] = H3Args{xh, xl, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT,

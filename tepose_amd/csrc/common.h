@@ -293,6 +293,8 @@ struct H3SArgs {
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s);                                // state planes a GRU step writes
 hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
+bool gemm_h3s_mid_ok(const H3SArgs& a);
+hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s);   // 128 x 288 tiles, N % 288 == 0
 hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
                                  void* lo, hipStream_t s);
 hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);

@@ -114,16 +114,17 @@ __device__ __forceinline__ float gs_tanh(float x) {
 // r, z, n tiles of 32 hidden units) = 128 rows x 64 hidden units x 3 gates, W_hh rows in the gate-interleaved tile
 // order, cell update in the epilogue, new state out as fp32 and as scaled planes.
 template <int WMF, int WNT, int NWM, int NWN, bool GRU>
-__global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tilesM, int tilesN) {
+__global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch, int tilesM, int tilesN) {
+  constexpr int NW = NWM * NWN;                           // waves per block: 8, or 12 for the 128 x 288 tile of mid-size batches
   constexpr int NST = 4;
   constexpr int HM = 32 * WMF * NWM, HN = 32 * WNT * NWN, HK = 16;
-  static_assert(NWM * NWN == 8, "8 waves");
+  static_assert(NW == 8 || NW == 12, "8 or 12 waves");
   const H3SArgs& a = batch.p[blockIdx.y];
   constexpr int RB = HK * 2;                             // 32 bytes per plane row of a stage
   constexpr int RPI = 1024 / RB;                         // 32 rows per DMA instruction
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;          // 32 KB
   constexpr int TOT = STAGE / 1024;                      // DMA instructions per stage, dealt to the 8 waves:
-  constexpr int Q = TOT / 8, REM = TOT % 8;              // waves < REM issue Q + 1 of them, the others Q
+  constexpr int Q = TOT / NW, REM = TOT % NW;            // waves < REM issue Q + 1 of them, the others Q
   constexpr int NDMA = Q + (REM ? 1 : 0);
   static_assert(STAGE % 1024 == 0 && NST * STAGE <= 160 * 1024, "ring fits the LDS");
   __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_kernel(H3SBatch batch, int tiles
     // store and two 8-byte plane stores (a quarter of the memory instructions of the one-column-per-lane layout).
     __syncthreads();
     float* tile = (float*)lds + wave * 32 * 32;            // one gate's [row][32] block at a time (4 KB per wave)
-    static_assert(8 * 32 * 32 * 4 <= NST * STAGE, "epilogue staging fits the ring");
+    static_assert(NW * 32 * 32 * 4 <= NST * STAGE, "epilogue staging fits the ring");
     const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev) & 15) == 0 && (d.ldo & 3) == 0 &&
                      (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
 #pragma unroll
@@ -576,6 +577,19 @@ hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s) {
   } else {
     hipLaunchKernelGGL((gemm_h3s_kernel<2, 4, 4, 2, false>), dim3(tilesM * tilesN, 1), dim3(512), 0, s, b, tilesM, tilesN);
   }
+  return hipGetLastError();
+}
+
+// Mid-size products (a few hundred to a few thousand rows) whose N is a multiple of 288 -- the stacked layer-0 block, 9 Hp
+// columns: 128 x 288 tiles, 12 waves of 32 x 96 (three per SIMD).  B * T = 1024 rows x 9216 columns are exactly 256 tiles
+// = one round of the chip, where 128 x 128 tiles of the two-accumulator kernel make 576 = 2.25 rounds.
+bool gemm_h3s_mid_ok(const H3SArgs& a) { return a.N % 288 == 0 && a.Kp % 16 == 0 && a.M > 0; }
+hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s) {
+  if (!gemm_h3s_mid_ok(a)) return hipErrorInvalidValue;
+  const int tilesM = (a.M + 127) / 128, tilesN = a.N / 288;
+  H3SBatch b{};
+  b.p[0] = a; b.n = 1;
+  hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 3, false>), dim3(tilesM * tilesN, 1), dim3(768), 0, s, b, tilesM, tilesN);
   return hipGetLastError();
 }
 

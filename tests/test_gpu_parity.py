@@ -66,6 +66,7 @@ def test_gemm_rejects_bad_arguments():
                                       (2, 128, 3, 1), (1, 64, 2, 2), (2, 64, 900, 2),
                                       (1, 2048, 2, 6), (1, 2048, 800, 3), (3, 64, 777, 2),
                                       (2, 64, 100, 1), (2, 100, 120, 3), (1, 64, 97, 2),
+                                      (2, 128, 70, 9), (2, 1024, 40, 16), (3, 100, 250, 3), (2, 64, 333, 4), (2, 192, 129, 4),   # 512 <= B*T < 8192, L >= 2: 128 x 288 tiles (ragged last row tile)
                                       (2, 64, 1100, 8), (3, 100, 1030, 8), (2, 64, 4100, 3), (3, 100, 4097, 2), (2, 128, 2048, 2)])   # B*T >= 8192: single-accumulator
                                       # layer-0 projection; B >= 2048: scaled-format recurrent path; class defaults: n_layers=1, hidden=2048
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
