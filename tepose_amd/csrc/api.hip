@@ -55,6 +55,12 @@ struct tepose_model {
   // regressor offsets
   size_t w1a = 0, b1 = 0, w1b = 0, w2 = 0, b2 = 0, wdec = 0, bdec = 0, init = 0;
   size_t w1a_p = 0, w1b_p = 0, w2_p = 0, wdec_p = 0, blendW_p = 0;   // blocked hi|lo planes (split path)
+  // collapsed regressor: the eval-mode FC loop is affine in (feature, initial state), so with the model's own
+  // initial state and n_iter = 3 the final state is  xs = feat Mf^T + k0  and, through the (affine) tail linears,
+  // xs = [relu(h_fwd) | relu(y_rec0)] Mt^T + kt.  fp64 algebra at pack time; [256][K] fp32 + planes, bias rows of 160.
+  size_t mf = 0, mf_p = 0, k0 = 0, mt = 0, mt_p = 0, kt = 0;
+  bool reg_collapsed = false, tail_collapsed = false;
+  bool collapse_env = true;                     // TEPOSE_COLLAPSE_REGRESSOR=0: always run the FC loop
   SmplOff smpl{};
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
@@ -186,6 +192,14 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
   m->w2_p = take(cur, 1024 * 1024);
   m->wdec_p = take(cur, 256 * 1024);
   m->blendW_p = take(cur, (size_t)kBlendN * kBlendK);
+  m->mf = take(cur, 256 * (size_t)kFeat);
+  m->mf_p = take(cur, 256 * (size_t)kFeat);
+  m->k0 = take(cur, kState);
+  if (m->kind == 0) {
+    m->mt = take(cur, 256 * (size_t)3 * m->Hp);
+    m->mt_p = take(cur, 256 * (size_t)3 * m->Hp);
+    m->kt = take(cur, kState);
+  }
   m->blob_floats = cur;
 }
 
@@ -198,7 +212,7 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
 // First 256 bytes of the blob: identifies the model the packed sections belong to, so that a blob that travelled
 // (RCCL broadcast, copy) is only adopted by a handle of the same kind / size / library layout.
 struct BlobHeader {
-  uint32_t magic, abi, kind, L, H, Hp, sections;   // sections: bit 0 encoder, 1 regressor, 2 SMPL tables
+  uint32_t magic, abi, kind, L, H, Hp, sections;   // sections: bit 0 encoder, 1 regressor, 2 SMPL tables, 3 range flag, 4 / 5 collapsed regressor / tail
   uint32_t layout_floats_lo, layout_floats_hi;      // blob_floats of the layout that wrote it
 };
 constexpr uint32_t kBlobMagic = 0x54455031u;        // "TEP1"
@@ -213,7 +227,8 @@ int write_header(tepose_model* m, hipStream_t s) {
   h.magic = kBlobMagic; h.abi = TEPOSE_ABI_VERSION; h.kind = header_kind(m); h.L = (uint32_t)m->L; h.H = (uint32_t)m->H;
   h.Hp = (uint32_t)m->Hp;
   h.sections = ((m->kind == 0 ? m->enc_packed : m->vibe_packed) ? 1u : 0u) | (m->reg_packed ? 2u : 0u) |
-               (m->smpl_packed ? 4u : 0u) | ((m->enc_range_ok && m->reg_range_ok && m->smpl_range_ok) ? 0u : 8u);
+               (m->smpl_packed ? 4u : 0u) | ((m->enc_range_ok && m->reg_range_ok && m->smpl_range_ok) ? 0u : 8u) |
+               (m->reg_collapsed ? 16u : 0u) | (m->tail_collapsed ? 32u : 0u);
   h.layout_floats_lo = (uint32_t)(m->blob_floats & 0xffffffffu); h.layout_floats_hi = (uint32_t)((uint64_t)m->blob_floats >> 32);
   CK(hipMemcpyAsync(m->blob + m->hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
   CK(hipStreamSynchronize(s));                      // h is a stack object (pack time only)
@@ -495,9 +510,87 @@ static void read_env_knobs(tepose_model* m) {
   m->g0_single_acc = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
   m->gru_single_acc = !(e && atoi(e) == 0);
+  e = getenv("TEPOSE_COLLAPSE_REGRESSOR");          // 0: the regressor's FC loop is always run as a loop
+  m->collapse_env = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
   m->s_min_b = e ? atoi(e) : 2048;                  // measured crossover against the two-accumulator recurrent path
 }
+
+namespace {
+// The regressor's loop (spin.py:252-261) in eval mode, with s = [pose6d | shape | cam] (157 values):
+//   h1 = W1a f + W1b s + b1,  h2 = W2 h1 + b2,  s' = s + Wd h2 + bd        (no activation; Dropout is the identity)
+// is affine:  s' = G s + F f + c  with  P = Wd W2,  G = I + P W1b,  F = P W1a,  c = P b1 + Wd b2 + bd,  so after three
+// iterations from the model's own initial state s0:  s3 = (I + G + G^2)(F f + c) + G^3 s0 = Mf f + k0.
+// All products in fp64 on the device (a few hundred MFLOP, pack time only), rounded to fp32 once.
+int collapse_regressor(tepose_model* m, hipStream_t s) {
+  m->reg_collapsed = false;
+  m->tail_collapsed = false;
+  if (!m->collapse_env || !m->reg_packed) return 0;
+  constexpr int S = 157;
+  float* B = m->blob;
+  const size_t nP = (size_t)S * 1024, nF = (size_t)S * kFeat, nG = (size_t)S * S;
+  double* d = nullptr;
+  CK(hipMalloc((void**)&d, (nP + 2 * nF + 4 * nG + 5 * S) * sizeof(double)));
+  double *P = d, *F = P + nP, *Mf = F + nF, *G = Mf + nF, *G2 = G + nG, *G3 = G2 + nG, *Ss = G3 + nG;
+  double *t1 = Ss + nG, *c = t1 + S, *t2 = c + S, *k0 = t2 + S;
+  auto run = [&]() -> int {
+    CK(launch_dmm(B + m->wdec, 0, 1024, B + m->w2, 0, 1024, nullptr, 0, nullptr, 0, P, 1024, S, 1024, 1024, 1.0, 0, s));
+    CK(launch_dmm(P, 1, 1024, B + m->w1a, 0, kFeat, nullptr, 0, nullptr, 0, F, kFeat, S, kFeat, 1024, 1.0, 0, s));
+    CK(launch_dmm(P, 1, 1024, B + m->w1b, 0, kState, nullptr, 0, nullptr, 0, G, S, S, S, 1024, 1.0, 1, s));
+    CK(launch_dmm(B + m->wdec, 0, 1024, B + m->b2, 0, 1, nullptr, 0, nullptr, 0, t1, 1, S, 1, 1024, 1.0, 0, s));
+    CK(launch_dmm(P, 1, 1024, B + m->b1, 0, 1, t1, 1, B + m->bdec, 1, c, 1, S, 1, 1024, 1.0, 0, s));
+    CK(launch_dmm(G, 1, S, G, 1, S, nullptr, 0, nullptr, 0, G2, S, S, S, S, 1.0, 0, s));
+    CK(launch_dmm(G2, 1, S, G, 1, S, nullptr, 0, nullptr, 0, G3, S, S, S, S, 1.0, 0, s));
+    CK(launch_dmm(G, 1, S, G, 1, S, G, S, nullptr, 0, Ss, S, S, S, S, 1.0, 1, s));                    // I + G + G^2
+    CK(launch_dmm(Ss, 1, S, F, 1, kFeat, nullptr, 0, nullptr, 0, Mf, kFeat, S, kFeat, S, 1.0, 0, s));
+    CK(launch_dmm(G3, 1, S, B + m->init, 0, 1, nullptr, 0, nullptr, 0, t2, 1, S, 1, S, 1.0, 0, s));
+    CK(launch_dmm(Ss, 1, S, c, 1, 1, t2, 1, nullptr, 0, k0, 1, S, 1, S, 1.0, 0, s));
+    CK(launch_d2f_pad(Mf, kFeat, S, kFeat, B + m->mf, 256, kFeat, s));
+    CK(launch_d2f_pad(k0, S, 1, S, B + m->k0, 1, kState, s));
+    CK((hipError_t)planes_of(B + m->mf, 256, kFeat, B + m->mf_p, s));
+    CK(hipStreamSynchronize(s));
+    return 0;
+  };
+  const int rc = run();
+  (void)hipFree(d);
+  if (rc) return rc;
+  bool ok = false;                                        // the collapsed matrix must fit the fp16 planes like any weight
+  CK((hipError_t)range_check(m, m->mf, m->mf_p, &ok, s));
+  m->reg_collapsed = ok;
+  return 0;
+}
+
+// ... and through the tail linears (tepose.py:81-86, eval mode: feat = (relu(h_fwd) W_lf^T + b_lf + relu(y_rec0) W_lr^T + b_lr) / 2):
+//   xs = [relu(h_fwd) | relu(y_rec0)] Mt^T + kt,   Mt = Mf [W_lf | W_lr] / 2,   kt = Mf (b_lf + b_lr) / 2 + k0
+int collapse_tail(tepose_model* m, hipStream_t s) {
+  m->tail_collapsed = false;
+  if (m->kind != 0 || !m->collapse_env || !m->reg_collapsed || !m->enc_packed) return 0;
+  constexpr int S = 157;
+  const int Hp = m->Hp, K3 = 3 * Hp;
+  float* B = m->blob;
+  double* d = nullptr;
+  CK(hipMalloc((void**)&d, ((size_t)S * K3 + 2 * S) * sizeof(double)));
+  double *Mt = d, *t = Mt + (size_t)S * K3, *kt = t + S;
+  auto run = [&]() -> int {
+    CK(launch_dmm(B + m->mf, 0, kFeat, B + m->wlf, 0, Hp, nullptr, 0, nullptr, 0, Mt, K3, S, Hp, kFeat, 0.5, 0, s));
+    CK(launch_dmm(B + m->mf, 0, kFeat, B + m->wlr, 0, 2 * Hp, nullptr, 0, nullptr, 0, Mt + Hp, K3, S, 2 * Hp, kFeat, 0.5, 0, s));
+    CK(launch_dmm(B + m->mf, 0, kFeat, B + m->blf, 0, 1, nullptr, 0, nullptr, 0, t, 1, S, 1, kFeat, 0.5, 0, s));
+    CK(launch_dmm(B + m->mf, 0, kFeat, B + m->blr, 0, 1, t, 1, B + m->k0, 1, kt, 1, S, 1, kFeat, 0.5, 0, s));
+    CK(launch_d2f_pad(Mt, K3, S, K3, B + m->mt, 256, K3, s));
+    CK(launch_d2f_pad(kt, S, 1, S, B + m->kt, 1, kState, s));
+    CK((hipError_t)planes_of(B + m->mt, 256, K3, B + m->mt_p, s));
+    CK(hipStreamSynchronize(s));
+    return 0;
+  };
+  const int rc = run();
+  (void)hipFree(d);
+  if (rc) return rc;
+  bool ok = false;
+  CK((hipError_t)range_check(m, m->mt, m->mt_p, &ok, s));
+  m->tail_collapsed = ok;
+  return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -579,6 +672,8 @@ int tepose_adopt_blob(tepose_model* m) {
   m->reg_packed = (h.sections & 2u) != 0;
   m->smpl_packed = (h.sections & 4u) != 0;
   m->enc_range_ok = m->reg_range_ok = m->smpl_range_ok = !(h.sections & 8u);   // bit 3: a weight outside the fp16 range
+  m->reg_collapsed = (h.sections & 16u) != 0;
+  m->tail_collapsed = m->kind == 0 && (h.sections & 32u) != 0;
   m->split = m->split_env && m->enc_range_ok;
   m->maxdepth = kNJ - 1;   // upper bound; chain levels past the real depth are no-ops
   int max_nnz = kNJ;
@@ -765,6 +860,7 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
   }
   m->enc_packed = true;
   CK((hipError_t)range_check(m, m->wih0, m->wih0_p, &m->enc_range_ok, s));
+  CK((hipError_t)collapse_tail(m, s));
   return write_header(m, s);
 }
 
@@ -798,6 +894,8 @@ int tepose_pack_regressor(tepose_model* m, const float* const* w, int n_w, void*
   CK((hipError_t)planes_of(B + m->wdec, 256, 1024, B + m->wdec_p, s));
   m->reg_packed = true;
   CK((hipError_t)range_check(m, m->w1a, m->smpl.J0, &m->reg_range_ok, s));
+  CK((hipError_t)collapse_regressor(m, s));
+  CK((hipError_t)collapse_tail(m, s));
   return write_header(m, s);
 }
 
@@ -907,8 +1005,10 @@ int prof_mark(tepose_model* mm, hipStream_t s) {     // next event of the GRU-in
   return 0;
 }
 
+// xs_out (eval mode, tail_collapsed handles only): instead of the feature, write the regressor's final state rows
+// [B][160] = [relu(h_fwd) | relu(y_rec0)] Mt^T + kt -- the tail linears and the three FC iterations as one product
 int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_train, float* feat, EncWs& w,
-                 hipStream_t s, const Planes* feat_planes = nullptr, bool sync_zeroed = false) {
+                 hipStream_t s, const Planes* feat_planes = nullptr, bool sync_zeroed = false, float* xs_out = nullptr) {
   tepose_model* mm = const_cast<tepose_model*>(m);
   const int L = m->L, Hp = m->Hp;
   const float* Bl = m->blob;
@@ -1172,7 +1272,10 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       CK(launch_split_planes(hlast, Hp, B, Hp, Hp, B, w.tailF.hi, w.tailF.lo, s, 1));
       CK(launch_split_planes(w.ytop, 2 * Hp, B, 2 * Hp, 2 * Hp, B, w.tailR.hi, w.tailR.lo, s, 1));
     }
-    if (!is_train) {
+    if (!is_train && xs_out && m->tail_collapsed) {
+      CK((hipError_t)h3_mm(w.tailA, Bl + m->mt_p, 256, 3 * Hp, xs_out, kState, Bl + m->kt, B, kState, nullptr, 0, 0.f,
+                           nullptr, s));
+    } else if (!is_train) {
       // (y_fwd + y_rec) / 2 = ([relu(h_fwd) | relu(y_rec0)] [W_lf | W_lr]^T + b_lf + b_lr) / 2: one product, K = 3Hp
       // (b_lr rides in as an addend row with stride 0)
       CK((hipError_t)h3_mm(w.tailA, Bl + m->wlfr_p, kFeat, 3 * Hp, feat, kFeat, Bl + m->blf, B, kFeat, Bl + m->blr, 0,
@@ -1207,11 +1310,11 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
 namespace {
 int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                      void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes,
-                     bool zero_sync);
+                     bool zero_sync, float* xs_out);
 int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
                    const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta, float* verts,
                    float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream,
-                   bool feat_planes_ready, bool sync_zeroed);
+                   bool feat_planes_ready, bool sync_zeroed, const float* xs_ready = nullptr);
 }  // namespace
 
 int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward) {
@@ -1234,7 +1337,7 @@ int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, 
 
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {
-  return encoder_fwd_impl(m, x, B, T, is_train, feat, workspace, ws_bytes, stream, nullptr, nullptr, false);
+  return encoder_fwd_impl(m, x, B, T, is_train, feat, workspace, ws_bytes, stream, nullptr, nullptr, false, nullptr);
 }
 
 namespace {
@@ -1242,7 +1345,7 @@ namespace {
 // not overlap a buffer the tail product still reads
 int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                      void* workspace, size_t ws_bytes, void* stream, const Planes* feat_planes, bool* wrote_planes,
-                     bool zero_sync) {
+                     bool zero_sync, float* xs_out) {
   if (wrote_planes) *wrote_planes = false;
   if (!m || m->kind != 0 || !x || !feat || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
@@ -1352,7 +1455,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
     if (!h3 || is_train || end > first_live) feat_planes = nullptr;
   }
   if (wrote_planes) *wrote_planes = feat_planes != nullptr;
-  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes, zero_sync);     // cleared above when asked
+  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes, zero_sync, xs_out);     // cleared above when asked
 }
 }  // namespace
 
@@ -1407,9 +1510,11 @@ int tepose_forward_cached(const tepose_model* m, const float* ring_base, int rin
   if (c.cur > rest_bytes) return TEPOSE_E_WORKSPACE;
   const int ld0 = 9 * m->Hp;
   G0Src src{ring_base, ld0, clip_stride, first_slot, ring, newest, newest_ld, newest + 6 * m->Hp, newest_ld};
-  int rc = encoder_core(m, src, B, T, 0, feat, w, s);
+  const bool col = m->tail_collapsed && m->split && B > split_min_m();
+  int rc = encoder_core(m, src, B, T, 0, feat, w, s, nullptr, false, col ? feat : nullptr);
   if (rc) return rc;
-  return tepose_regressor_fwd(m, feat, B, 3, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest, rest_bytes, stream);
+  return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
+                        rest_bytes, stream, false, false, col ? feat : nullptr);
 }
 
 int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter, const void* jreg_packed,
@@ -1431,7 +1536,7 @@ namespace {
 int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, const float* init_pose,
                    const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta, float* verts,
                    float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes, void* stream,
-                   bool feat_planes_ready, bool sync_zeroed) {
+                   bool feat_planes_ready, bool sync_zeroed, const float* xs_ready) {
   if (!m || !feat || !theta || !verts || !kp_3d || !kp_2d || !rotmat || !workspace || N < 1 || n_iter < 0)
     return TEPOSE_E_ARG;
   if (!m->reg_packed || !m->smpl_packed) return TEPOSE_E_STATE;
@@ -1442,7 +1547,14 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   const float* Bl = m->blob;
   // xc = cat[x, pose, shape, cam]; fc1(xc) = x W1a^T + b1 (iteration-invariant) + state W1b^T
-  if (w.split_fc && N <= reg_seq_max_n()) {
+  if (xs_ready) {
+    // the encoder's last product already produced the final state rows (collapsed regressor + tail)
+    w.xs = const_cast<float*>(xs_ready);
+  } else if (m->reg_collapsed && w.split_fc && n_iter == 3 && !init_pose && !init_shape && !init_cam) {
+    // the three iterations from the model's own initial state as ONE product: xs = feat Mf^T + k0
+    if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
+    CK((hipError_t)h3_mm(w.featP, Bl + m->mf_p, 256, kFeat, w.xs, kState, Bl + m->k0, N, kState, nullptr, 0, 0.f, nullptr, s));
+  } else if (w.split_fc && N <= reg_seq_max_n()) {
     // small batches: the whole FC loop in one persistent launch (reg_seq.hip)
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     if (!sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
@@ -1534,7 +1646,15 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
   // every arrival counter (and, for B <= 4, every granule) of this forward is cleared by its first kernel (the input
   // split), or by one memset node where that kernel does not run
   bool wrote = false;
-  int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, rw.split_fc ? &rw.featP : nullptr, &wrote, true);
+  if (m->tail_collapsed && rw.split_fc) {
+    // the tail linears and the regressor's three iterations are one product on the relu(final states): the
+    // state rows land in the (otherwise unused) feature buffer
+    int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, nullptr, &wrote, true, feat);
+    if (rc) return rc;
+    return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
+                          rest_bytes, stream, false, true, feat);
+  }
+  int rc = encoder_fwd_impl(m, x, B, T, 0, feat, rest, rest_bytes, stream, rw.split_fc ? &rw.featP : nullptr, &wrote, true, nullptr);
   if (rc) return rc;
   return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
                         rest_bytes, stream, wrote, true);

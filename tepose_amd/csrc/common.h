@@ -83,6 +83,10 @@ hipError_t launch_pad_input(const float* x, float* xp, long rows, hipStream_t s)
 hipError_t launch_pad_rows(const float* feat, long feat_ld, const float* theta, long theta_ld, float* xp,
                            long rows, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+hipError_t launch_dmm(const void* A, int a64, long lda, const void* B, int b64, long ldb, const double* Cadd, long ldadd,
+                      const float* Cadd32, long ldadd32, double* C, long ldc, int M, int N, int K, double alpha,
+                      int add_identity, hipStream_t s);
+hipError_t launch_d2f_pad(const double* src, long ld, int rows, int cols, float* dst, int Rp, int Cp, hipStream_t s);
 hipError_t launch_copy_cols(const float* src, long lds, const float* add, long lda, float* dst, long ldd, long rows,
                             int cols, hipStream_t s);
 hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s);

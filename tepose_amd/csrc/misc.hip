@@ -170,6 +170,58 @@ hipError_t launch_copy_cols(const float* src, long lds, const float* add, long l
   return hipGetLastError();
 }
 
+// ---- pack-time fp64 algebra (the collapsed regressor, api.hip): small dense products, one thread per output element.
+// C[i][j] = alpha * sum_k A[i][k] * B[k][j] (+ 1 on the diagonal) (+ Cadd[i][j]) (+ Cadd32[i][j]); A / B are fp32 or fp64, row-major
+// with their own leading dimensions.  A few hundred MFLOP per pack: speed is irrelevant, fp64 accumulation is the point.
+__global__ void __launch_bounds__(256) dmm_kernel(const void* __restrict__ A, int a64, long lda, const void* __restrict__ B,
+                                                  int b64, long ldb, const double* __restrict__ Cadd, long ldadd,
+                                                  const float* __restrict__ Cadd32, long ldadd32,
+                                                  double* __restrict__ C, long ldc, int M, int N, int K, double alpha,
+                                                  int add_identity) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * N) return;
+  const int i = (int)(idx / N), j = (int)(idx - (long)i * N);
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double a = a64 ? ((const double*)A)[i * lda + k] : (double)((const float*)A)[i * lda + k];
+    const double b = b64 ? ((const double*)B)[k * ldb + j] : (double)((const float*)B)[k * ldb + j];
+    acc += a * b;
+  }
+  acc *= alpha;
+  if (add_identity && i == j) acc += 1.0;
+  if (Cadd) acc += Cadd[i * ldadd + j];
+  if (Cadd32) acc += (double)Cadd32[i * ldadd32 + j];
+  C[i * ldc + j] = acc;
+}
+
+hipError_t launch_dmm(const void* A, int a64, long lda, const void* B, int b64, long ldb, const double* Cadd, long ldadd,
+                      const float* Cadd32, long ldadd32, double* C, long ldc, int M, int N, int K, double alpha,
+                      int add_identity, hipStream_t s) {
+  const long total = (long)M * N;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dmm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, a64, lda, B, b64, ldb, Cadd, ldadd,
+                     Cadd32, ldadd32, C, ldc, M, N, K, alpha, add_identity);
+  return hipGetLastError();
+}
+
+// fp64 [rows][cols] (leading dimension ld) -> zero-padded fp32 [Rp][Cp]
+__global__ void __launch_bounds__(256) d2f_pad_kernel(const double* __restrict__ src, long ld, int rows, int cols,
+                                                      float* __restrict__ dst, int Rp, int Cp) {
+  const long total = (long)Rp * Cp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int r = (int)(idx / Cp), c = (int)(idx - (long)r * Cp);
+    dst[idx] = (r < rows && c < cols) ? (float)src[r * ld + c] : 0.f;
+  }
+}
+
+hipError_t launch_d2f_pad(const double* src, long ld, int rows, int cols, float* dst, int Rp, int Cp, hipStream_t s) {
+  const long total = (long)Rp * Cp;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(d2f_pad_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, cols, dst, Rp, Cp);
+  return hipGetLastError();
+}
+
 hipError_t launch_init_state(const float* init160, float* xs, int N, hipStream_t s) {
   const long total = (long)N * kState;
   if (total <= 0) return hipSuccess;
