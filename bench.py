@@ -30,6 +30,18 @@ if ROOT not in sys.path:
 
 # algorithmic work per window, L=2 H=1024
 GFLOP_PER_WINDOW = {6: 0.600, 16: 1.497, 32: 2.931}
+# the default (split-precision) path runs the tail linears + the regressor's three FC iterations as ONE collapsed product
+# (DESIGN.md 4d): 2*(2048*3072 + 1024*2048 + 3*(2*157*1024 + 1024*1024)) FLOP become 2*157*3072 per window
+COLLAPSED_GFLOP_SAVING = (2.0 * (2048 * 3072 + 1024 * 2048 + 3 * (2 * 157 * 1024 + 1024 * 1024)) - 2.0 * 157 * 3072) / 1e9
+
+
+def gflop_per_window(t, split=True):
+    """Algorithmic FLOPs the measured path executes per window (None when BASELINE.md has no figure for this T)."""
+    if t not in GFLOP_PER_WINDOW:
+        return None
+    return GFLOP_PER_WINDOW[t] - (COLLAPSED_GFLOP_SAVING if split else 0.0)
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, fp32-input MFMA
 PEAK_F16_MFMA_TFLOPS = 2516.6         # dense fp16/bf16 MFMA (16x the fp32-input rate, ~2.5 PF spec)
 SPLIT_PRODUCTS = 3                    # fp16 MFMAs per fp32-equivalent product in csrc/gemm_h3.hip
@@ -70,8 +82,9 @@ def pmc_traffic(B, T, split):
 # every weight of the published architecture (n_layers=2, hidden=1024) touched once, fp32-equivalent bytes (the fp16 hi + lo
 # planes are the same 4 bytes per element): W_ih / W_hh of the consumed directions and layers, tail linears, regressor FCs,
 # blend-shape table, skin weights
+# (default path: the tail linears and the regressor FCs are read as the collapsed 157 x 3072 map)
 WEIGHT_BYTES = 4.0 * (3 * 3072 * 2133 + 3 * 3072 * 1024 + 3072 * 1024 + 2 * 3072 * 2048 + 2 * 3072 * 1024 +
-                      2048 * 1024 + 2048 * 2048 + 1024 * 2205 + 1024 * 1024 + 157 * 1024 + 20670 * 218) + 6890 * 4 * 8.0
+                      157 * 3072 + 20670 * 218) + 6890 * 4 * 8.0
 
 
 def small_batch_roofline(b, t, ms):
@@ -83,11 +96,11 @@ def small_batch_roofline(b, t, ms):
            'algorithmic_bytes': bytes_min, 'achieved_GBps': gbps, 'frac_of_hbm_8TBps': gbps / 8000.0,
            'dependent_recurrent_steps': 2 * t, 'us_per_dependent_step_if_all_time_were_steps': ms * 1e3 / (2 * t)}
     if t in GFLOP_PER_WINDOW:
-        tf = b * GFLOP_PER_WINDOW[t] / (ms * 1e-3) / 1e3
+        tf = b * gflop_per_window(t) / (ms * 1e-3) / 1e3
         out['algorithmic_tflops'] = tf
         out['frac_of_split_mfma_peak'] = tf / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS)
     out['bound'] = 'latency (2T-step recurrence; weights read once: byte floor %.0f us, MFMA floor %.0f us)' % (
-        bytes_min / 8e12 * 1e6, b * GFLOP_PER_WINDOW.get(t, 0) * 1e9 / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS * 1e12) * 1e6)
+        bytes_min / 8e12 * 1e6, b * (gflop_per_window(t) or 0) * 1e9 / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS * 1e12) * 1e6)
     return out
 
 
@@ -295,7 +308,7 @@ def main():
             'outputs_finite': finite,
         }
         if T in GFLOP_PER_WINDOW:
-            res['whole_path_tflops'] = windows * GFLOP_PER_WINDOW[T] / t_max / 1e3
+            res['whole_path_tflops'] = windows * gflop_per_window(T, os.environ.get('TEPOSE_EXACT_FP32', '0') in ('', '0')) / t_max / 1e3
             res['whole_path_frac_of_f32_mfma_peak'] = res['whole_path_tflops'] / (PEAK_F32_MFMA_TFLOPS * world)   # > 1 is possible in split mode
         split = os.environ.get('TEPOSE_EXACT_FP32', '0') in ('', '0')
         if k_n > 0:

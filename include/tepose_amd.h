@@ -105,7 +105,10 @@ int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int 
  * smplx.lbs), projection (spin.py:307-351), rotation_matrix_to_angle_axis
  * (geometry.py:68-233).  feat[N,2048] -> theta[N,85], verts[N,6890,3], kp_3d[N,J,3],
  * kp_2d[N,J,2], rotmat[N,24,3,3]; J = 14 when jreg_packed != NULL (H36M_TO_J14 path),
- * else 49.  n_iter = 3 in the reference.                                             */
+ * else 49.  n_iter = 3 in the reference.  With n_iter = 3 and the model's own initial state a split-mode handle runs the
+ * loop as ONE product: the loop has no activation and Dropout is the identity in eval mode, so it is an affine map of the
+ * feature, formed in fp64 by tepose_pack_regressor (TEPOSE_COLLAPSE_REGRESSOR=0 or TEPOSE_EXACT_FP32=1 at
+ * tepose_create keep the loop).  Same results to ~2e-6.                                                              */
 int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter,
                          const void* jreg_packed, float* theta, float* verts, float* kp_3d,
                          float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,

@@ -15,7 +15,7 @@ log = open('gpurun_out/%s_%s_trace.log' % (tag, shape)).read()
 m = re.findall(r'B=\s*\d+ T=\s*\d+\s+[\d.]+ ms/forward\s+[\d.]+ windows/s', log)
 tr = glob.glob('gpurun_out/%s_%s_trace/*/*kernel_trace.csv' % (tag, shape))[0]
 rows = list(csv.DictReader(open(tr)))
-nf = max(sum(1 for r in rows if 'reg_seq_kernel' in r['Kernel_Name']), 1)
+nf = max(sum(1 for r in rows if 'smpl_joints_kernel' in r['Kernel_Name']), 1)          # one per forward
 print('# rocprofv3 --kernel-trace of `python3 tools/sweep.py %s` (%d forwards, shipped binary, round 2 final): %s'
       % (shape, nf, m[-1] if m else ''))
 trace(tr)
@@ -30,11 +30,11 @@ for name, unit in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         a = agg[short(r['Kernel_Name'])]
         a[0] += 1
         a[1] += float(r['Counter_Value'])
-    nfw = max(agg.get('reg_seq_kernel<1>', agg.get('reg_seq_kernel<2>', [1]))[0], 1)
+    nfw = max([v[0] for k, v in agg.items() if k.startswith('smpl_joints_kernel')] + [1])
     print('\n# %s per forward (KB, sum over the forward\'s launches; kernels with >= 1 launch per forward)' % unit)
     tot = 0.0
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        if n < nfw or k.startswith(('at::', 'pack', 'csr', 'absmax', '__amd')):
+        if n < nfw or k.startswith(('at::', 'pack', 'csr', 'absmax', '__amd', 'dmm', 'd2f')):
             continue
         print('%-60s x%-3d %12.1f KB' % (k[:60], round(n / nfw), v / nfw))
         tot += v / nfw
