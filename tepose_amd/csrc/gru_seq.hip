@@ -30,6 +30,8 @@
 // equals the step's, re-packs the halves into A fragments through wave-private LDS and goes (one round trip per step
 // instead of drain + atomic + poll + load).  Two granule buffers alternate; the forward's memset node zeroes them, and
 // tags are layer * 64 + step + 1, so no granule of another step, layer or forward can match.
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef TEPOSE_SEQ_ABL
@@ -136,6 +138,18 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
   const int rq = err >> 2, re = err & 3;
   const float* rbase_e = red + ((ei * 3) * 4 + re) * 64 + rq * 16 + 2 * ep;
 
+  // ---- one row (the live stream, B = 1; granule mode): 8 threads used to finish the workgroup's 16 units -- 24 LDS reads
+  // of partial sums and two units' gate math each, 0.6 us of a 2.2 us step (tools/seq_stamps.py).  Here every thread
+  // takes ONE partial sum: thread = (unit u1 = tid / 32, gate g1 = (tid / 8) % 4 [3: idle], K-partial pw1 = tid % 8);
+  // three DPP steps add the 8 partials, two more bring z and n to the r lane, and the 16 lanes tid % 32 == 0 finish one
+  // unit each.  (The partials are then added as a tree, not in wave order: last-bit differences against B > 1.)
+  const bool one = GR && M == 1;
+  const int u1 = tid >> 5, g1 = (tid >> 3) & 3, pw1 = tid & 7;
+  const bool ul = one && (tid & 31) == 0;
+  const int j1 = j0 + u1;
+  float b1r = 0.f, b1z = 0.f, b1n = 0.f, hp1 = 0.f;
+  if (ul) { b1r = a.bhh[dir][j1]; b1z = a.bhh[dir][Hp + j1]; b1n = a.bhh[dir][2 * Hp + j1]; }
+
   // ---- the extra direction's single step from h = 0 (element-wise; consumed by later kernels only: plain stores)
   if (dir == 0 && a.x_gi && live) {
     const float* gi = a.x_gi + (long)erow * a.x_ldgi + ej;
@@ -164,11 +178,14 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
     const GruSeqStep s = tab[st];
     // gate pre-activations of this step (written by an earlier kernel: plain loads), issued before the wait
     float2 gr = {0.f, 0.f}, gz = gr, gn = gr;
-    if (live) {
+    if (live && !one) {
       const float* gi = s.gi + (long)erow * s.ldgi + ej;
       gr = *(const float2*)gi; gz = *(const float2*)(gi + Hp); gn = *(const float2*)(gi + 2 * Hp);
     }
+    float g1r = 0.f, g1z = 0.f, g1n = 0.f;
+    if (ul) { const float* gi = s.gi + j1; g1r = gi[0]; g1z = gi[Hp]; g1n = gi[2 * Hp]; }     // row 0
     float2 hr = {0.f, 0.f}, hz = hr, hn = hr;
+    float h1r = 0.f, h1z = 0.f, h1n = 0.f;
     SEQ_STAMP(0);
     if (st > 0) {
       if constexpr (GR) {
@@ -305,7 +322,20 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
       SEQ_STAMP(3);
       __syncthreads();
       SEQ_STAMP(4);
-      if (live) {
+      if (one) {
+        static_assert(NW == 8, "8 K-partials per sum");
+        // row 0 of the MFMA D layout: lanes 0..15 = units, register 0
+        float v = g1 < 3 ? red[((pw1 * MT * 3 + g1) * 4) * 64 + u1] : 0.f;
+        auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+        };
+        v += dpp(v, std::integral_constant<int, 0xB1>{});        // quad_perm [1,0,3,2]
+        v += dpp(v, std::integral_constant<int, 0x4E>{});        // quad_perm [2,3,0,1]
+        v += dpp(v, std::integral_constant<int, 0x141>{});       // row_half_mirror: the other quad of the 8 lanes
+        h1r = v;
+        h1z = dpp(v, std::integral_constant<int, 0x108>{});      // row_shl:8  -> the z sum of this unit (lane + 8)
+        h1n = __shfl(v, lane + 16);                              // the n sum (lane + 16: next DPP row)
+      } else if (live) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           const float* rp = rbase_e + (long)w * MT * 3 * 256;
@@ -314,7 +344,36 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
         }
       }
     }
-    if (live) {
+    if (one) {
+      if (ul) {
+        const float rg = sq_sigmoid(g1r + (h1r + b1r));
+        const float zg = sq_sigmoid(g1z + (h1z + b1z));
+        const float ng = sq_tanh(g1n + rg * (h1n + b1n));
+        float hv = (1.f - zg) * ng + zg * hp1;
+        if (gave_up) hv = __builtin_nanf("");
+        hp1 = hv;
+        half_t h0, l0;
+        split_hi_lo(hv, h0, l0);
+        union { half_t h; unsigned short u; } c0, c1;
+        c0.h = h0; c1.h = l0;
+        if (st + 1 < T) {
+          unsigned long long* gd = a.gran + ((size_t)(dir * 2 + (st & 1)) * kSeqGranRows) * Hp + j1;
+          const unsigned long long tg = (unsigned long long)(a.tag_base + (unsigned)st + 1u) << 32;
+          __hip_atomic_store(gd, tg | c0.u | ((unsigned)c1.u << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s.hout[j1] = hv;                                                       // row 0; later kernels: plain stores
+        const long o = (long)s.poff + (long)(j1 >> 5) * s.pkst + plane_index(0, j1 & 31, 0);
+        a.phi[o] = h0;
+        a.plo[o] = l0;
+        if (st == T - 1 && a.r_off[dir] != kNoPlane) {
+          const long ro = (long)a.r_off[dir] + (long)(j1 >> 5) * a.r_kst + plane_index(0, j1 & 31, 0);
+          half_t rh, rl;
+          split_hi_lo(fmaxf(hv, 0.f), rh, rl);
+          a.rhi[ro] = rh;
+          a.rlo[ro] = rl;
+        }
+      }
+    } else if (live) {
       float hv[2];
       {
         const float rg = sq_sigmoid(gr.x + (hr.x + br.x));
