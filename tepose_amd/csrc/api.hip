@@ -672,8 +672,8 @@ int tepose_adopt_blob(tepose_model* m) {
   m->reg_packed = (h.sections & 2u) != 0;
   m->smpl_packed = (h.sections & 4u) != 0;
   m->enc_range_ok = m->reg_range_ok = m->smpl_range_ok = !(h.sections & 8u);   // bit 3: a weight outside the fp16 range
-  m->reg_collapsed = (h.sections & 16u) != 0;
-  m->tail_collapsed = m->kind == 0 && (h.sections & 32u) != 0;
+  m->reg_collapsed = m->collapse_env && (h.sections & 16u) != 0;      // (a handle created with TEPOSE_COLLAPSE_REGRESSOR=0 keeps the loop)
+  m->tail_collapsed = m->collapse_env && m->kind == 0 && (h.sections & 32u) != 0;
   m->split = m->split_env && m->enc_range_ok;
   m->maxdepth = kNJ - 1;   // upper bound; chain levels past the real depth are no-ops
   int max_nnz = kNJ;
