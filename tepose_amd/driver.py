@@ -90,3 +90,37 @@ def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('thet
     for s, i in enumerate(order):
         results[i] = {k: bufs[k][s, :steps[s]].clone() for k in keep}
     return results
+
+
+@torch.no_grad()
+def validate_padded(model, target, seqlen, J_regressor=None, keep=('theta', 'kp_3d', 'verts')):
+    """The batched whole-clip validation loop of the reference's trainer (lib/core/trainer.py:307-357) on one batch of its
+    validation Datasets (lib/dataset/threedpw_test.py:62-134, h36m_val.py): target['features'] [C, vidlen, 2048] (clips
+    zero-padded to the longest), target['theta_pseu'] [C, vidlen, 85] (cam = [1, 0, 0]), target['vidlen_each'] [C, 1].
+
+    The reference advances every clip through all vidlen - seqlen + 1 windows, padding included, and keeps the rows with
+    j < vidlen_each - seqlen + 1; here a clip stops at its own last window (run_clips: the active clips are a prefix of the
+    longest-first order), which yields the same kept rows.  Returns the trainer's accumulators in its order -- for j in
+    windows, the clips still running, in batch order: 'pred_<key>' [sum_c (vidlen_c - seqlen + 1), ...] for key in `keep`
+    -- and 'pred_j3d_tsr' [C, vidlen, J, 3] with the prediction for frame j + seqlen - 1 of clip c (zeros in front of the
+    first window and on the padding, where the reference holds predictions from zero features)."""
+    T = int(seqlen)
+    feats, th = target['features'], target['theta_pseu']
+    C, vidlen = int(feats.shape[0]), int(feats.shape[1])
+    lens = [int(v) for v in target['vidlen_each'].reshape(-1).tolist()]
+    res = run_clips(model, [feats[c, :lens[c]] for c in range(C)], [th[c, :T - 1] for c in range(C)], T,
+                    J_regressor=J_regressor, keep=tuple(keep))
+    nwin = [max(lens[c] - T + 1, 0) if res[c] is not None else 0 for c in range(C)]
+    out = {}
+    order = [(j, c) for j in range(max(nwin + [0])) for c in range(C) if j < nwin[c]]
+    for k in keep:
+        rows = [res[c][k][j] for j, c in order]
+        out['pred_' + k] = torch.stack(rows) if rows else None
+    if 'kp_3d' in keep and order:
+        nj = int(res[order[0][1]]['kp_3d'].shape[1])
+        tsr = torch.zeros((C, vidlen, nj, 3), device=out['pred_kp_3d'].device)
+        for c in range(C):
+            if nwin[c]:
+                tsr[c, T - 1:T - 1 + nwin[c]] = res[c]['kp_3d']
+        out['pred_j3d_tsr'] = tsr
+    return out

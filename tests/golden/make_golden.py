@@ -213,6 +213,55 @@ def driver_case(T_mod, name, L, H, N, T, seed_w, seed_x):
     print('wrote', name, np.concatenate(th).shape)
 
 
+def padded_case(T_mod, name, L, H, lens, T, seed_w, seed_x):
+    """The batched whole-clip validation loop of lib/core/trainer.py:307-357 on one padded batch as the validation
+    Datasets emit it (lib/dataset/threedpw_test.py:62-134: clips zero-padded to the longest one, arrays staged in
+    float16, theta_pseu with cam = [1, 0, 0], `vidlen_each`, `index`): every clip advances through ALL vidlen - T + 1
+    windows, padding included, the accumulators keep rows with j < vidlen_each - T + 1.  Loop written out as the caller
+    has it, model = the reference TePose."""
+    model = T_mod.TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='').eval()
+    sd_np = synth.synthetic_state_dict(L, H, seed_w)
+    sd = model.state_dict()
+    for k in sd:
+        if k in sd_np:
+            sd[k] = torch.from_numpy(sd_np[k])
+    model.load_state_dict(sd, strict=True)
+    C, vidlen = len(lens), max(lens)
+    feats = np.zeros((C, vidlen, 2048), dtype=np.float16)
+    theta_pseu = np.zeros((C, vidlen, 85), dtype=np.float16)
+    for c, n in enumerate(lens):
+        w = synth.synthetic_windows(1, n, seed_x + c)[0]
+        feats[c, :n] = w[:, :2048]
+        theta_pseu[c, :n] = np.concatenate([np.tile(np.array([1., 0., 0.], dtype=np.float32), (n, 1)), w[:, 2051:]], axis=1)
+    target = {'features': torch.from_numpy(feats).float(), 'theta_pseu': torch.from_numpy(theta_pseu).float(),
+              'vidlen_each': torch.tensor(lens).float().view(C, 1), 'index': torch.arange(C).float().view(C, 1)}
+    J = torch.from_numpy(SMPL_NP['J_regressor_h36m'])
+    acc_j3d, acc_theta, acc_verts = [], [], []
+    with torch.no_grad():
+        for j in range(vidlen - T + 1):
+            if j == 0:
+                theta_input = torch.zeros((C, vidlen, 85))
+                theta_input[target['index'].view(-1).long(), :T - 1, :] = target['theta_pseu'][:, :T - 1, :]
+                pred_j3d_tsr = torch.zeros((C, vidlen, 14, 3))
+            inp = torch.zeros((C, T, 2048 + 85))
+            inp[:, :, :2048] = target['features'][:, j:j + T, :]
+            inp[:, :T - 1, 2048:] = theta_input[target['index'].view(-1).long(), j:j + T - 1, :]
+            preds = model(inp, J_regressor=J)
+            pred_j3d = preds[-1]['kp_3d'].view(-1, 14, 3)
+            theta_input[target['index'].view(-1).long(), j + T - 1, :] = preds[-1]['theta']
+            keep = j < (target['vidlen_each'].view(-1) - T + 1)
+            acc_j3d.append(pred_j3d[keep].numpy().copy())
+            acc_theta.append(preds[-1]['theta'].view(-1, 85)[keep].numpy().copy())
+            acc_verts.append(preds[-1]['verts'].view(-1, 6890, 3)[keep][:, ::53].numpy().copy())
+            pred_j3d_tsr[:, j + T - 1] = pred_j3d
+    np.savez_compressed(os.path.join(HERE, name + '.npz'),
+                        meta=np.array([L, H, T, seed_w, seed_x] + list(lens), dtype=np.int64),
+                        features=feats, theta_pseu=theta_pseu, pred_j3d=np.concatenate(acc_j3d),
+                        pred_theta=np.concatenate(acc_theta), pred_verts_sub=np.concatenate(acc_verts),
+                        pred_j3d_tsr=pred_j3d_tsr.numpy())
+    print('wrote', name, np.concatenate(acc_j3d).shape, pred_j3d_tsr.shape)
+
+
 def vibe_case(name, L, H, B, N, seed_w, seed_x, bidirectional=False, add_linear=True, use_residual=True):
     """Reference lib.models.vibe.VIBE (GRU [+ relu + Linear] [+ residual], then the per-frame regressor).  The first two
     cases are the configuration evaluate.py:93-101 builds; the others cover the remaining constructor flags
@@ -370,6 +419,7 @@ def main():
     run_case(T_mod, 'tepose_L3H64_B2T4_j14', 3, 64, 2, 4, True, seed_w=4, seed_x=78)
     driver_case(T_mod, 'driver_L2H128_N40T6', 2, 128, 40, 6, 6, 555)
     driver_case(T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
+    padded_case(T_mod, 'padded_L2H128_T5', 2, 128, [23, 9, 17, 5], 5, 14, 700)
     regressor_init_case(P_mod, 'regressor_init_N5_it2_j14', 5, 2, True)
     regressor_init_case(P_mod, 'regressor_init_N3_it0_j49', 3, 0, False)
     vibe_case('vibe_L2H128_B2N20', 2, 128, 2, 20, 8, 901)

@@ -135,3 +135,34 @@ def test_live_stream_window_32_single_clip_vs_oracle_loop(smpl_np):
             assert (out[k].cpu() - ref[k]).abs().max() < 1e-4, (cache, k)
         assert (out['theta'][:, :3].cpu() - ref['theta'][:, :3]).abs().max() < 1e-4
         assert (out['theta'][:, 75:].cpu() - ref['theta'][:, 75:]).abs().max() < 1e-4
+
+
+def test_padded_validation_batch_matches_reference_trainer_loop():
+    """tepose_amd.driver.validate_padded = lib/core/trainer.py:307-357 on one batch of the validation Datasets
+    (zero-padded clips, float16-staged arrays, vidlen_each): accumulators in the trainer's order against vectors from the
+    reference model run through that very loop (padding windows included)."""
+    import os
+    from tepose_amd.driver import validate_padded
+    from tepose_amd.testing import build_model
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'padded_L2H128_T5.npz'))
+    L, H, T, seed_w, seed_x = [int(v) for v in g['meta'][:5]]
+    lens = [int(v) for v in g['meta'][5:]]
+    smpl_np = synth.synthetic_smpl(0)
+    model, _, _ = build_model(L, H, seed=seed_w, device='cuda', smpl_np=smpl_np)
+    target = {'features': torch.from_numpy(g['features'].astype(np.float32)).cuda(),
+              'theta_pseu': torch.from_numpy(g['theta_pseu'].astype(np.float32)).cuda(),
+              'vidlen_each': torch.tensor(lens).float().view(-1, 1), 'index': torch.arange(len(lens)).float().view(-1, 1)}
+    out = validate_padded(model, target, T, J_regressor=torch.from_numpy(smpl_np['J_regressor_h36m']))
+    assert out['pred_kp_3d'].shape == g['pred_j3d'].shape and out['pred_j3d_tsr'].shape == g['pred_j3d_tsr'].shape
+    assert np.abs(out['pred_kp_3d'].cpu().numpy() - g['pred_j3d']).max() < 1e-4
+    assert np.abs(out['pred_theta'].cpu().numpy()[:, 75:] - g['pred_theta'][:, 75:]).max() < 1e-4
+    assert np.abs(out['pred_verts'].cpu().numpy()[:, ::53] - g['pred_verts_sub']).max() < 1e-4
+    tsr = out['pred_j3d_tsr'].cpu().numpy()
+    for c, n in enumerate(lens):
+        assert np.abs(tsr[c, T - 1:n] - g['pred_j3d_tsr'][c, T - 1:n]).max() < 1e-4
+        assert not tsr[c, :T - 1].any() and not tsr[c, n:].any()
+    # a clip shorter than the window contributes nothing (split_into_videos_val drops it, _img_utils.py:369-370)
+    target['vidlen_each'] = torch.tensor([lens[0], 3, lens[2], lens[3]]).float().view(-1, 1)
+    out2 = validate_padded(model, target, T)
+    assert out2['pred_kp_3d'].shape[0] == sum(max(n - T + 1, 0) for n in (lens[0], 0, lens[2], lens[3]))
+    assert out2['pred_kp_3d'].shape[1] == 49

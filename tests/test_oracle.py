@@ -259,3 +259,25 @@ def test_regressor_per_call_init_golden(name, smpl_np):
     assert np.abs(out['theta'].numpy()[:, :3] - g['theta'][:, :3]).max() < 1e-5
     assert np.abs(out['theta'].numpy()[:, 75:] - g['theta'][:, 75:]).max() < 1e-5
     assert np.abs(only['kp_3d'].numpy() - g['kp_3d_only_pose']).max() < 1e-5
+
+
+def test_oracle_padded_validation_batch_matches_reference_golden(smpl_np):
+    """lib/core/trainer.py:307-357 on a padded batch (tests/golden/make_golden.py::padded_case runs the reference model
+    through that loop, padding windows included): a clip's kept rows do not depend on the padded windows the reference also
+    computes, so clip-by-clip (the oracle's run_clip) reproduces the accumulators in the trainer's order."""
+    g = np.load(os.path.join(GOLDEN, 'padded_L2H128_T5.npz'))
+    L, H, T, seed_w, seed_x = [int(v) for v in g['meta'][:5]]
+    lens = [int(v) for v in g['meta'][5:]]
+    state = synth.synthetic_state_dict(L, H, seed_w)
+    feats = torch.from_numpy(g['features'].astype(np.float32))           # the Datasets stage their arrays in float16
+    th = torch.from_numpy(g['theta_pseu'].astype(np.float32))
+    per = [O.run_clip(state, smpl_np, feats[c, :n], th[c, :T - 1], T, L, J_regressor=smpl_np['J_regressor_h36m'])
+           for c, n in enumerate(lens)]
+    order = [(j, c) for j in range(max(lens) - T + 1) for c in range(len(lens)) if j < lens[c] - T + 1]
+    j3d = np.stack([per[c]['kp_3d'][j].numpy() for j, c in order])
+    theta = np.stack([per[c]['theta'][j].numpy() for j, c in order])
+    assert j3d.shape == g['pred_j3d'].shape
+    assert np.abs(j3d - g['pred_j3d']).max() < 5e-5            # 19 feedback steps on the longest clip
+    assert np.abs(theta[:, 75:] - g['pred_theta'][:, 75:]).max() < 5e-5
+    for c, n in enumerate(lens):
+        assert np.abs(per[c]['kp_3d'].numpy() - g['pred_j3d_tsr'][c, T - 1:n]).max() < 5e-5
