@@ -80,3 +80,38 @@ def synthetic_eval_db(lengths, seed=0, joints=49):
           'valid': np.ones(n, dtype=np.float32)}
     pse = synth.synthetic_windows(1, n + 1, 9200 + seed)[0, :n, 2048:].copy()
     return db, pse
+
+
+def padded_validation_batch(db, pseudotheta, seqlen, joints=14):
+    """The batch the reference's validation Datasets hand to trainer.validate (lib/dataset/threedpw_test.py:54-134,
+    h36m_val.py; lib/data_utils/_img_utils.py:356-376), hot-path fields only: videos in order of first appearance of their
+    `vid_name`, those shorter than `seqlen` dropped, every clip zero-padded to the longest; the arrays are staged in
+    float16 exactly as the Datasets do (`np.zeros(..., dtype=np.float16)` filled, then `.float()`), so features and
+    thetas carry fp16 rounding; theta / theta_pseu = [1, 0, 0 | pose 72 | shape 10].
+    Returns dict of torch tensors: features [C, vidlen, 2048], theta, theta_pseu [C, vidlen, 85], kp_3d [C, vidlen,
+    joints, 3], vidlen_each [C, 1], index [C, 1] -- what tepose_amd.driver.validate_padded consumes."""
+    import torch
+    names = np.asarray(db['vid_name'])
+    _, first = np.unique(names, return_index=True)
+    starts = np.sort(first)
+    bounds = list(starts) + [names.shape[0]]
+    spans = [(int(bounds[i]), int(bounds[i + 1])) for i in range(len(starts)) if bounds[i + 1] - bounds[i] >= seqlen]
+    if not spans:
+        return None
+    C, vidlen = len(spans), max(e - s for s, e in spans)
+    pse = np.asarray(pseudotheta, dtype=np.float32)
+    feats = np.zeros((C, vidlen, 2048), dtype=np.float16)
+    theta = np.zeros((C, vidlen, 85), dtype=np.float16)
+    theta_pseu = np.zeros((C, vidlen, 85), dtype=np.float16)
+    kp_3d = np.zeros((C, vidlen, joints, 3), dtype=np.float16)
+    cam = np.tile(np.array([1., 0., 0.], dtype=np.float32), (vidlen, 1))
+    for c, (s, e) in enumerate(spans):
+        n = e - s
+        feats[c, :n] = db['features'][s:e]
+        theta[c, :n] = np.concatenate([cam[:n], db['pose'][s:e], db['shape'][s:e]], axis=1)
+        theta_pseu[c, :n] = np.concatenate([cam[:n], pse[s:e, 3:75], pse[s:e, 75:]], axis=1)
+        kp_3d[c, :n] = np.asarray(db['joints3D'][s:e])[:, :joints]
+    return {'features': torch.from_numpy(feats).float(), 'theta': torch.from_numpy(theta).float(),
+            'theta_pseu': torch.from_numpy(theta_pseu).float(), 'kp_3d': torch.from_numpy(kp_3d).float(),
+            'vidlen_each': torch.tensor([float(e - s) for s, e in spans]).view(C, 1),
+            'index': torch.arange(C).float().view(C, 1)}

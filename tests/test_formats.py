@@ -98,3 +98,23 @@ def test_db_split_and_checkpoint_roundtrip(tmp_path):
     torch.save({'gen_state_dict': sd, 'x': fractions.Fraction(1, 2)}, tmp_path / 'bad.pt')
     with pytest.raises(Exception):
         load_generator_state_dict(tmp_path / 'bad.pt')
+
+
+def test_padded_validation_batch_follows_the_dataset_layout():
+    """lib/dataset/threedpw_test.py:54-134 + _img_utils.py:356-376: first-appearance video order, short videos dropped,
+    zero padding to the longest, float16 staging, cam = [1, 0, 0]."""
+    import numpy as np
+    from tepose_amd.data import padded_validation_batch, synthetic_eval_db
+    lens = [9, 3, 14, 6]
+    db, pse = synthetic_eval_db(lens, seed=5, joints=14)
+    db['vid_name'] = np.concatenate([np.array([n] * l) for n, l in zip(['zz', 'short', 'aa', 'mm'], lens)])   # not sorted by name
+    b = padded_validation_batch(db, pse, seqlen=6)
+    assert b['features'].shape == (3, 14, 2048) and b['theta_pseu'].shape == (3, 14, 85) and b['kp_3d'].shape == (3, 14, 14, 3)
+    assert b['vidlen_each'].view(-1).tolist() == [9.0, 14.0, 6.0]            # 'short' (3 < 6 frames) dropped, order kept
+    f16 = db['features'][:9].astype(np.float16).astype(np.float32)
+    assert np.array_equal(b['features'][0, :9].numpy(), f16) and not b['features'][0, 9:].any()
+    assert b['theta_pseu'][1, :14, :3].eq(b['theta_pseu'].new_tensor([1., 0., 0.])).all()
+    assert np.array_equal(b['theta_pseu'][1, :14, 3:].numpy(), pse[12:26, 3:].astype(np.float16).astype(np.float32))
+    assert np.array_equal(b['theta'][2, :6, 3:75].numpy(), db['pose'][26:32].astype(np.float16).astype(np.float32))
+    assert not b['theta'][2, 6:].any() and b['index'].view(-1).tolist() == [0.0, 1.0, 2.0]
+    assert padded_validation_batch(db, pse, seqlen=20) is None
