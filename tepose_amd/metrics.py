@@ -94,3 +94,42 @@ def reduce_records(records):
     if r[:, 6].sum() > 0:
         out['mpvpe'] = float(r[:, 7].sum() / r[:, 6].sum())
     return out
+
+
+@torch.no_grad()
+def trainer_evaluate(model, acc, target, seqlen):
+    """Trainer.evaluate (lib/core/trainer.py:437-488) on the accumulators of one validation pass: acc = the dict
+    tepose_amd.driver.validate_padded returns ('pred_kp_3d', 'pred_verts', 'pred_j3d_tsr'), target = the padded batch
+    ('kp_3d' [C, vidlen, J, 3], 'theta' [C, vidlen, 85], 'vidlen_each' [C, 1]).  Returns the trainer's eval_dict in mm:
+    'mpjpe', 'pa-mpjpe' (pelvis = mean of joints 2, 3; similarity Procrustes: the device kernels of joint_metrics),
+    'accel', 'accel_err' (eval_utils.py:53-107: per video the second differences of frames seqlen-1 .. vidlen-3 resp.
+    .. vidlen-5 of the pelvis-aligned [C, vidlen] tensors, normalised by sum(vidlen) - C (seqlen + 1) resp. (seqlen + 3)),
+    'pve' (vertices against SMPL(target theta), eval_utils.py:141-175)."""
+    T = int(seqlen)
+    dev = acc['pred_kp_3d'].device
+    lens = [int(v) for v in target['vidlen_each'].reshape(-1).tolist()]
+    C = len(lens)
+    nwin = [max(n - T + 1, 0) for n in lens]
+    order = [(j, c) for j in range(max(nwin + [0])) for c in range(C) if j < nwin[c]]
+    kp_t = target['kp_3d'].to(dev)
+    tgt = torch.stack([kp_t[c, j + T - 1] for j, c in order])
+    m = joint_metrics(acc['pred_kp_3d'].float().contiguous(), tgt.float().contiguous())
+    out = {'mpjpe': float(m['mpjpe'].mean()), 'pa-mpjpe': float(m['pa_mpjpe'].mean())}
+    p = acc['pred_j3d_tsr'].to(dev).clone()
+    g = kp_t.clone().float()
+    p -= (p[:, :, [2]] + p[:, :, [3]]) / 2.0
+    g -= (g[:, :, [2]] + g[:, :, [3]]) / 2.0
+    vl = torch.tensor(lens, dtype=torch.float32)
+    a_p = p[:, 2:] - 2 * p[:, 1:-1] + p[:, :-2]
+    a_g = g[:, 2:] - 2 * g[:, 1:-1] + g[:, :-2]
+    an = a_p.norm(dim=3).mean(dim=2)                     # [C, vidlen - 2]
+    en = (a_p - a_g).norm(dim=3).mean(dim=2)
+    acc_sum = sum(float(an[c, T - 1:max(lens[c] - 2, T - 1)].sum()) for c in range(C))
+    err_sum = sum(float(en[c, T - 1:max(lens[c] - 4, T - 1)].sum()) for c in range(C))
+    out['accel'] = acc_sum / (float(vl.sum()) - C * (T + 1) + 1e-8) * 1000.0
+    out['accel_err'] = err_sum / (float(vl.sum()) - C * (T + 3) + 1e-8) * 1000.0
+    if 'pred_verts' in acc and acc['pred_verts'] is not None and 'theta' in target:
+        th_t = target['theta'].to(dev)
+        tt = torch.stack([th_t[c, j + T - 1] for j, c in order]).float().contiguous()
+        out['pve'] = float(vertex_metric(acc['pred_verts'].float().contiguous(), gt_vertices(model, tt)).mean())
+    return out

@@ -235,8 +235,12 @@ def padded_case(T_mod, name, L, H, lens, T, seed_w, seed_x):
         theta_pseu[c, :n] = np.concatenate([np.tile(np.array([1., 0., 0.], dtype=np.float32), (n, 1)), w[:, 2051:]], axis=1)
     target = {'features': torch.from_numpy(feats).float(), 'theta_pseu': torch.from_numpy(theta_pseu).float(),
               'vidlen_each': torch.tensor(lens).float().view(C, 1), 'index': torch.arange(C).float().view(C, 1)}
+    kp3d = np.zeros((C, vidlen, 14, 3), dtype=np.float16)
+    for c, n in enumerate(lens):
+        kp3d[c, :n] = synth.normal('pad/kp%d_%d' % (seed_x, c), (n, 14, 3), std=0.3)
+    target['kp_3d'] = torch.from_numpy(kp3d).float()
     J = torch.from_numpy(SMPL_NP['J_regressor_h36m'])
-    acc_j3d, acc_theta, acc_verts = [], [], []
+    acc_j3d, acc_theta, acc_verts, acc_tj3d = [], [], [], []
     with torch.no_grad():
         for j in range(vidlen - T + 1):
             if j == 0:
@@ -251,10 +255,25 @@ def padded_case(T_mod, name, L, H, lens, T, seed_w, seed_x):
             theta_input[target['index'].view(-1).long(), j + T - 1, :] = preds[-1]['theta']
             keep = j < (target['vidlen_each'].view(-1) - T + 1)
             acc_j3d.append(pred_j3d[keep].numpy().copy())
+            acc_tj3d.append(target['kp_3d'][:, j + T - 1][keep].numpy().copy())
             acc_theta.append(preds[-1]['theta'].view(-1, 85)[keep].numpy().copy())
             acc_verts.append(preds[-1]['verts'].view(-1, 6890, 3)[keep][:, ::53].numpy().copy())
             pred_j3d_tsr[:, j + T - 1] = pred_j3d
-    np.savez_compressed(os.path.join(HERE, name + '.npz'),
+    # Trainer.evaluate (trainer.py:437-488) on these accumulators, with the reference's own metric functions
+    from lib.utils.eval_utils import batch_compute_similarity_transform_torch, compute_accel, compute_error_accel
+    pj, tj = torch.from_numpy(np.concatenate(acc_j3d)).clone(), torch.from_numpy(np.concatenate(acc_tj3d)).clone()
+    pj -= (pj[:, [2], :] + pj[:, [3], :]) / 2.0
+    tj -= (tj[:, [2], :] + tj[:, [3], :]) / 2.0
+    errors = torch.sqrt(((pj - tj) ** 2).sum(dim=-1)).mean(dim=-1).numpy()
+    S1_hat = batch_compute_similarity_transform_torch(pj, tj)
+    errors_pa = torch.sqrt(((S1_hat - tj) ** 2).sum(dim=-1)).mean(dim=-1).numpy()
+    ptsr, ttsr = pred_j3d_tsr.clone(), target['kp_3d'].clone()
+    ptsr -= (ptsr[:, :, [2], :] + ptsr[:, :, [3], :]) / 2.0
+    ttsr -= (ttsr[:, :, [2], :] + ttsr[:, :, [3], :]) / 2.0
+    accel = compute_accel(ptsr, target['vidlen_each'], T) * 1000
+    accel_err = compute_error_accel(joints_pred=ptsr, joints_gt=ttsr, vidlen_each=target['vidlen_each'], seqlen=T) * 1000
+    evald = np.array([np.mean(errors) * 1000, np.mean(errors_pa) * 1000, float(accel), float(accel_err)], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), kp_3d=kp3d, eval_mpjpe_pa_accel_accelerr=evald,
                         meta=np.array([L, H, T, seed_w, seed_x] + list(lens), dtype=np.int64),
                         features=feats, theta_pseu=theta_pseu, pred_j3d=np.concatenate(acc_j3d),
                         pred_theta=np.concatenate(acc_theta), pred_verts_sub=np.concatenate(acc_verts),
