@@ -1127,9 +1127,11 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           a.C = out; a.ldc = H3; a.bias = Bl + bias; a.M = M; a.N = H3;
           return a;
         };
-        H3Args pa[3] = {mk(vf, Hp, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, MT),
-                        mk(vr, 2 * Hp, m->rec_r[l].wih_p, m->rec_r[l].bih, w.grr, MT),
-                        mk(vr, 2 * Hp, m->rec_f[l].wih_p, m->rec_f[l].bih, w.grf, Mf)};
+        // longest K first: the blocks of a batched launch are dealt product by product, and the chip finishes a mix of
+        // K = 2Hp and K = Hp tiles sooner when the long ones start first (1.5 -> 1.0 long-tile times at 1024 rows)
+        H3Args pa[3] = {mk(vr, 2 * Hp, m->rec_r[l].wih_p, m->rec_r[l].bih, w.grr, MT),
+                        mk(vr, 2 * Hp, m->rec_f[l].wih_p, m->rec_f[l].bih, w.grf, Mf),
+                        mk(vf, Hp, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, MT)};
         H3ArgsBatch sk{};
         H3Batch big{};
         for (H3Args& a : pa) {
