@@ -319,7 +319,7 @@ def main():
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                    'traffic': tr, 'traffic_source': tr_src,
                                    'algorithmic_bytes': float(B * T) * 2133 * 4 + 9216.0 * 2133 * 4 + float(B * T) * 9216 * 4,
-                                   'kernel': 'gemm_h3s_persist_kernel (single-accumulator split GEMM, 256x256 tiles walked by 256 persistent workgroups; layer-0 input projection, M=%d N=9216 K=2133)'
+                                   'kernel': 'gemm_h3s_persist_kernel<0> (single-accumulator split GEMM, 256x256 tiles walked by 256 persistent workgroups; layer-0 input projection, M=%d N=9216 K=2133)'
                                              % (B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n,
                                    'note': 'achieved = algorithmic fp32-equivalent FLOP/s; the kernel issues %d fp16 MFMAs '

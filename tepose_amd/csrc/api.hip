@@ -1407,7 +1407,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
                 Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0, w.rs};
       if (g0mid) CK(launch_gemm_h3s_mid(a, s));
-      else CK(launch_gemm_h3s(a, s));
+      else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {
       H3Batch b{};
       b.p[0] = H3Args{xh, xl, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT,

@@ -349,6 +349,9 @@ __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch
 // flight), so the stores drain under the next tile's MFMAs.  To get a countable, small number of stores the product is
 // formed transposed (W fragments as the MFMA's row operand): a lane then owns 4 consecutive columns of one row of C,
 // i.e. 32 16-byte stores per wave instead of 128 4-byte ones.  Same fragments, same K order, same accumulators.
+// TAG only names the instantiation: 0 = the layer-0 input projection (the kernel bench.py's roofline is about), 1 = every other
+// plain product, so that a rocprofv3 --stats table lists the dominant launches under a symbol of their own
+template <int TAG>
 __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int tilesM, int tilesN) {
   constexpr int WMF = 2, WNT = 4, NWN = 2, NST = 4;
   constexpr int HM = 256, HN = 256, HK = 16, RB = HK * 2, RPI = 1024 / RB;
@@ -566,14 +569,15 @@ static bool h3s_persist() {
   return v;
 }
 
-hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s) {
+hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   H3SBatch b{};
   b.p[0] = a; b.n = 1;
   if (h3s_persist()) {
     const int nt = tilesM * tilesN;
-    hipLaunchKernelGGL(gemm_h3s_persist_kernel, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
+    if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
+    else hipLaunchKernelGGL(gemm_h3s_persist_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
   } else {
     hipLaunchKernelGGL((gemm_h3s_kernel<2, 4, 4, 2, false>), dim3(tilesM * tilesN, 1), dim3(512), 0, s, b, tilesM, tilesN);
   }

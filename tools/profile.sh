@@ -8,7 +8,7 @@ tag=${1:-rNN}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 common="--steps 2 --warmup 1 --no-cpu-baseline --no-extra"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/${tag}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/${tag}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_fetch -- python3 bench.py $common > gpurun_out/${tag}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_write -- python3 bench.py $common > gpurun_out/${tag}_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/${tag}_sq -- python3 bench.py $common > gpurun_out/${tag}_sq.log 2>&1
