@@ -104,6 +104,18 @@ def small_batch_roofline(b, t, ms):
     return out
 
 
+def cpu_model_string():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=None):
     """Reference op sequence on the host cores (oracle, torch CPU), windows/s -- and, on the same 256-window
     sample, the largest absolute difference between that CPU result and each GPU numerics mode (the north-star
@@ -139,8 +151,25 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
     O.tepose_fwd(state, smpl_np, x[:32], L, J_regressor=J, nn_gru=True)
     single = 32 / (time.perf_counter() - t1)
     torch.set_num_threads(cores)
+    # the reference path at the small shapes of BASELINE.json too (config 1: one window; config 2: 64 windows),
+    # each at the better of {8 threads, the thread count chosen above} -- a single window does not feed many cores
+    small = {}
+    for name, b, reps in (('b1_T%d' % T, 1, 12), ('b64_T%d' % T, 64, 3)):
+        best_s = None
+        for nt in sorted({min(8, all_cores), cores}):
+            torch.set_num_threads(nt)
+            O.tepose_fwd(state, smpl_np, x[:b], L, J_regressor=J, nn_gru=True)
+            ts = time.perf_counter()
+            for _ in range(reps):
+                O.tepose_fwd(state, smpl_np, x[:b], L, J_regressor=J, nn_gru=True)
+            ms = (time.perf_counter() - ts) / reps * 1e3
+            if best_s is None or ms < best_s[0]:
+                best_s = (ms, nt)
+        small[name] = {'ms_per_forward': best_s[0], 'windows_per_s': b / best_s[0] * 1e3, 'threads': best_s[1]}
+    torch.set_num_threads(cores)
     res = {'value': n / el, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
-           'single_thread_value': single, 'host_cpus': all_cores,
+           'single_thread_value': single, 'host_cpus': all_cores, 'cpu_model': cpu_model_string(),
+           'small_shapes': small,
            'sample': '%d windows of [%d,2133] in batches of %d, torch %s CPU, nn.GRU op sequence, %.1f s'
                      % (n, T, Bc, torch.__version__, el)}
     if gpu_models:
@@ -192,6 +221,9 @@ def main():
     ap.add_argument('--no-extra', action='store_true', help='skip the informational small-batch shapes (use under rocprofv3 --pmc)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to test the multi-process logic on a 1-GPU box)')
     ap.add_argument('--share-device0', action='store_true', help='testing only: every rank uses cuda:0')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='run the process-group path at world size 1 too: init_process_group (nccl = RCCL), blob broadcast, '
+                         'all_reduce, gather -- so that the collectives of the N-GPU run execute on a 1-GPU box')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -210,8 +242,17 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:           # --force-dist from a plain `python bench.py`: a one-rank rendezvous
+            import socket
+            sk = socket.socket()
+            sk.bind(('127.0.0.1', 0))
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]), RANK='0', WORLD_SIZE='1',
+                              LOCAL_RANK='0')
+            sk.close()
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:
@@ -238,7 +279,7 @@ def main():
         blob = torch.empty(eng.packed_bytes, dtype=torch.uint8, device=device)
         state = None
     bcast_ms = None
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -247,11 +288,24 @@ def main():
         bcast_ms = (time.perf_counter() - t0) * 1e3
         if rank != 0:
             eng.adopt_blob(blob, model)
+        elif args.force_dist and world == 1:
+            # one rank: exercise the receiving side too -- a second handle adopts a copy of the broadcast blob and must
+            # reproduce rank 0's probe forward bit for bit (checked below as `adopted_blob_matches`)
+            from tepose_amd.smpl import SMPL
+            from tepose_amd.tepose import TePose
+            twin = TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='', smpl=SMPL.from_tables(smpl_np),
+                          smpl_mean_params=synth.synthetic_mean_params(0)).to(device).eval()
+            twin._engine.adopt_blob(blob.clone(), twin)
 
     # every rank runs the same 4-window probe: identical results prove the broadcast blob is the model
     with torch.no_grad():
         probe = model(synthetic_windows_device(4, T, 7, device), J_regressor=J)[0]
     probe_sum = float(probe['verts'].double().abs().sum().item())
+    adopted_ok = None
+    if use_dist and world == 1 and rank == 0:
+        with torch.no_grad():
+            adopted_ok = bool(torch.equal(twin(synthetic_windows_device(4, T, 7, device), J_regressor=J)[0]['verts'], probe['verts']))
+        del twin
     x = synthetic_windows_device(B, T, 1234 + rank, device)
     torch.cuda.synchronize()
     _t('model packed, inputs resident')
@@ -264,14 +318,14 @@ def main():
         out = step()
     torch.cuda.synchronize()
     eng.profile_enable(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     _t('timed region done')
@@ -281,7 +335,7 @@ def main():
     finite = bool(torch.isfinite(out['verts']).all().item() and torch.isfinite(out['theta']).all().item())
 
     t_all = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         rec = torch.tensor([float(rank), elapsed, float(B * args.steps), float(finite), probe_sum], device=device,
                            dtype=torch.float64)
@@ -354,6 +408,12 @@ def main():
             res['per_rank'] = [[float(v) for v in g.tolist()] for g in gathered]
             sums = [r[4] for r in res['per_rank']]
             res['ranks_agree'] = bool(max(sums) - min(sums) <= 1e-6 * max(sums))
+            res['dist_backend'] = dist.get_backend()
+            # lower bound of the broadcast on this node: the blob crosses at least one xGMI link (~153 GB/s per link,
+            # MI355X_MICROARCH.md); at world 1 there is no link and the figure is the collective's fixed cost
+            res['weight_broadcast_xgmi_floor_ms'] = eng.packed_bytes / 153e9 * 1e3 if world > 1 else 0.0
+            if adopted_ok is not None:
+                res['adopted_blob_matches'] = adopted_ok
         gpu_models = {'default': model}
         if world == 1 and split and not args.no_extra:
             # the same workload with every product on the exact-fp32 MFMA (TEPOSE_EXACT_FP32=1), for comparison
@@ -363,12 +423,22 @@ def main():
             with torch.no_grad():
                 ox = model_x(x, J_regressor=J)[0]
                 torch.cuda.synchronize()
+                model_x._engine.profile_enable(True)
                 tx = time.perf_counter()
                 for _ in range(args.steps):
                     ox = model_x(x, J_regressor=J)[0]
                 torch.cuda.synchronize()
             tx = (time.perf_counter() - tx) / args.steps
+            xk_ms, xk_n, xk_flops = model_x._engine.profile_read()
+            model_x._engine.profile_enable(False)
+            xach = xk_flops / (xk_ms / max(xk_n, 1) * 1e-3) / 1e12 if xk_n else None
             res['exact_fp32_mode'] = {'value': B / tx, 'ms_per_step': tx * 1e3,
+                                      'roofline': None if xach is None else {
+                                          'bound': 'mfma', 'achieved': xach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                          'frac': xach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(B, T, False)[0],
+                                          'kernel': 'gemm_f32_kernel (exact-fp32 MFMA v_mfma_f32_32x32x2_f32; layer-0 input '
+                                                    'projection, M=%d N=9216 K=2133), hipEvents on the launch stream' % (B * T),
+                                          'launches': xk_n, 'avg_ms': xk_ms / max(xk_n, 1)},
                                       'whole_path_frac_of_f32_mfma_peak': B * GFLOP_PER_WINDOW.get(T, 0) / tx / 1e3 / PEAK_F32_MFMA_TFLOPS,
                                       'max_abs_diff_verts_vs_default': float((ox['verts'] - out['verts']).abs().max().item()),
                                       'max_abs_diff_kp3d_vs_default': float((ox['kp_3d'] - out['kp_3d']).abs().max().item())}
@@ -382,15 +452,39 @@ def main():
                                        'b1_T6': (1, 6, 300), 'b37_T6_3dpw_lockstep': (37, 6, 100)}.items():
                 xe = synthetic_windows_device(b, t, 77, device)
                 with torch.no_grad():
-                    for _ in range(5):
-                        model(xe, J_regressor=J)
-                    torch.cuda.synchronize()
+                    # queued back to back (status mode 'lazy': the fault word of the persistent kernels is read once, at
+                    # the end of the loop -- how tepose_amd.driver runs them) ...
+                    with eng.lazy_status():
+                        for _ in range(5):
+                            model(xe, J_regressor=J)
+                        torch.cuda.synchronize()
+                        te = time.perf_counter()
+                        for _ in range(reps):
+                            model(xe, J_regressor=J)
+                        eng.check_status()              # syncs; raises if any of them gave up
+                    ms = (time.perf_counter() - te) / reps * 1e3
+                    # ... and as a drop-in caller sees one call: forward + the default per-call status check, which
+                    # synchronises (the reference's callers .cpu() the outputs right after, evaluate.py:258-261)
                     te = time.perf_counter()
                     for _ in range(reps):
                         model(xe, J_regressor=J)
                     torch.cuda.synchronize()
-                ms = (time.perf_counter() - te) / reps * 1e3
+                    ms_sync = (time.perf_counter() - te) / reps * 1e3
                 extra[name] = small_batch_roofline(b, t, ms)
+                extra[name]['ms_per_forward_with_per_call_status_sync'] = ms_sync
+            # config 5 as the caller runs it (demo.py:238-252): ONE clip, window of 32 frames advancing a frame at a time
+            # with theta feedback, through tepose_amd.driver.run_clips -- per-frame latency end to end
+            from tepose_amd.driver import run_clips
+            for t in (32, 16):
+                nfr = 300 + t
+                wv = synthetic_windows_device(1, nfr, 5, device)[0]
+                feats, init = [wv[:, :2048].contiguous()], [wv[:t - 1, 2048:].contiguous()]
+                run_clips(model, feats, init, t, keep=('theta', 'verts', 'kp_3d'))
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                run_clips(model, feats, init, t, keep=('theta', 'verts', 'kp_3d'))
+                torch.cuda.synchronize()
+                extra['cfgE_stream_per_frame_ms' if t == 32 else 'stream_T16_per_frame_ms'] = (time.perf_counter() - te) / (nfr - t + 1) * 1e3
             extra['note'] = ('BASELINE.json configs 1 / 2 / 5 (synthetic stand-ins: random-init weights, synthetic features; the '
                              'licence-gated 3DPW data and repr_wpw_3dpw checkpoint are absent, so MPJPE vs that checkpoint is '
                              'UNMEASURED); the recurrent layers and the regressor loop run as persistent kernels '
@@ -401,7 +495,7 @@ def main():
             res['cpu_baseline'] = cpu_baseline(state, smpl_np, L, T, gpu_models=gpu_models, device=device)
             _t('cpu baseline done')
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -14,8 +14,12 @@
  *     (fp32, contiguous unless a stride is given); the library never frees them and keeps
  *     none beyond the call, except the packed-weight blob registered in a model handle;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
- *   - a handle is host memory only; calls on one handle are re-entrant across streams as
- *     long as each call gets its own workspace.
+ *   - a handle is host memory only (plus one word of pinned host memory, the fault word
+ *     below); calls on one handle are re-entrant across streams as long as each call gets
+ *     its own workspace;
+ *   - tepose_workspace_bytes() must be queried again after every tepose_pack_* / tepose_adopt_blob
+ *     call: what was packed (e.g. a weight outside the fp16 range) can change the kernels a
+ *     forward uses and with them the workspace it needs.
  */
 #ifndef TEPOSE_AMD_H
 #define TEPOSE_AMD_H
@@ -33,6 +37,7 @@ extern "C" {
 #define TEPOSE_E_SHAPE (-2)     /* dimension not supported (see each function)           */
 #define TEPOSE_E_WORKSPACE (-3) /* workspace smaller than tepose_*_workspace_bytes()     */
 #define TEPOSE_E_STATE (-4)     /* handle not packed yet / blob of another model         */
+#define TEPOSE_E_TIMEOUT (-5)   /* a persistent small-batch kernel gave up waiting: that forward's outputs are NaN */
 
 #define TEPOSE_FEAT 2048        /* ResNet feature width (lib/models/tepose.py:68)         */
 #define TEPOSE_THETA 85         /* cam3 + pose72 + shape10 (lib/models/spin.py:285)       */
@@ -127,6 +132,26 @@ int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, i
 int tepose_forward(const tepose_model* m, const float* x, int B, int T, const void* jreg_packed,
                    float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
                    void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- failure channel of the persistent small-batch kernels ------------------------------------
+ * Batches of <= 64 windows run each GRU layer (and an iterating regressor) as ONE persistent launch whose
+ * workgroups hand the recurrent state to each other through L2; that needs all of them resident at once (<= 192
+ * of the 256 CUs).  On a GPU that is shared with another process or CU-masked they may not be; every wait is
+ * therefore bounded (~2 s), and a launch that gives up poisons that forward's outputs with NaN AND raises the
+ * handle's fault word (pinned host memory, written by the kernel).  The reference has no silent-garbage mode
+ * (an exception ends evaluate.py:255); neither has this boundary:
+ *   - tepose_status(m, stream): synchronises `stream`, returns TEPOSE_E_TIMEOUT if a forward on `m` gave up
+ *     since the last call (and clears the word), else 0.  Call it wherever the outputs are about to be trusted.
+ *   - tepose_status_peek(m): the same test without synchronising or clearing.
+ *   - every forward entry point (tepose_forward, tepose_forward_cached, tepose_encoder_fwd,
+ *     tepose_regressor_fwd[_init]) returns TEPOSE_E_TIMEOUT up front while the word is raised.
+ *   - tepose_set_persistent(m, 0) (or TEPOSE_PERSISTENT=0 at tepose_create): the step-per-launch HIP kernels at
+ *     every batch size -- same results, no residency requirement; the remedy after a TEPOSE_E_TIMEOUT.
+ *   - tepose_uses_persistent(m, B, T): 1 if a forward of B windows may launch a persistent kernel.          */
+int tepose_status(tepose_model* m, void* stream);
+int tepose_status_peek(const tepose_model* m);
+int tepose_set_persistent(tepose_model* m, int on);
+int tepose_uses_persistent(const tepose_model* m, int B, int T);
 
 /* ---- sliding-window driver with cached layer-0 projections ---------------
  * Consecutive windows of a clip share T-1 frames, and a frame's layer-0 gate pre-activations

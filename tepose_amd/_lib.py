@@ -21,6 +21,7 @@ SYMBOLS = [
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
+    'tepose_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent',
 ]
 
 _lib = None
@@ -28,6 +29,14 @@ _lib = None
 
 class TeposeError(RuntimeError):
     pass
+
+
+E_TIMEOUT = -5
+
+
+class TeposeTimeout(TeposeError):
+    """TEPOSE_E_TIMEOUT: a persistent small-batch kernel gave up waiting for its peers (GPU shared or CU-masked);
+    the outputs of that forward are NaN.  Engine re-runs on the step-per-launch kernels where it owns the sync point."""
 
 
 def load():
@@ -93,6 +102,10 @@ def load():
     lib.tepose_gemm_h3_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.tepose_gemm_h3_workspace_bytes.restype = c_size_t
     lib.tepose_gemm_h3_f32.argtypes = [fp, c_long, fp, c_long, fp, fp, c_long, c_int, c_int, c_int, fp, c_size_t, c_void_p]
+    lib.tepose_status.argtypes = [c_void_p, c_void_p]
+    lib.tepose_status_peek.argtypes = [c_void_p]
+    lib.tepose_set_persistent.argtypes = [c_void_p, c_int]
+    lib.tepose_uses_persistent.argtypes = [c_void_p, c_int, c_int]
     lib.tepose_profile_enable.argtypes = [c_void_p, c_int]
     lib.tepose_profile_read.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     lib.tepose_profile_read_gru.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
@@ -107,7 +120,7 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().tepose_error_string(rc)
-        raise TeposeError('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', rc))
+        raise (TeposeTimeout if rc == E_TIMEOUT else TeposeError)('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', rc))
 
 
 def ptr_array(ptrs):

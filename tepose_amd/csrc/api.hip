@@ -68,6 +68,12 @@ struct tepose_model {
   bool split_env = true;                        // what the environment asked for; `split` also needs every packed weight inside
   bool enc_range_ok = true, reg_range_ok = true, smpl_range_ok = true;   // the fp16 range (|w| < 2^15), checked at pack time
   int s_min_b = 2048;                           // scaled-format recurrent path from this batch size
+  // fault channel of the persistent kernels (gru_seq.hip, reg_seq.hip): one word of pinned host memory that a kernel
+  // whose bounded wait expired writes with system scope; sticky until tepose_status() reads it
+  unsigned* fault = nullptr;
+  bool persist = true;                          // false: step-per-launch kernels at every batch size (tepose_set_persistent)
+  unsigned spin_limit = 1u << 21;               // polls (~1 us each) before a wait gives up
+  unsigned test_fault = 0;                      // TEPOSE_TEST_FAULT: bit 0 recurrent kernel, bit 1 regressor kernel wait for arrivals that never come
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
   std::vector<hipEvent_t> ev;
@@ -514,6 +520,12 @@ static void read_env_knobs(tepose_model* m) {
   m->collapse_env = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
   m->s_min_b = e ? atoi(e) : 2048;                  // measured crossover against the two-accumulator recurrent path
+  e = getenv("TEPOSE_PERSISTENT");                  // 0: never launch the persistent small-batch kernels (the remedy for GPUs
+  m->persist = !(e && atoi(e) == 0);                // that are shared or CU-masked: they need all their workgroups resident)
+  e = getenv("TEPOSE_SEQ_SPIN_LIMIT");              // polls before a persistent kernel's wait gives up
+  if (e && atol(e) > 0) m->spin_limit = (unsigned)atol(e);
+  e = getenv("TEPOSE_TEST_FAULT");                  // tests only: make the persistent kernels' waits unmeetable
+  m->test_fault = e ? (unsigned)atoi(e) : 0u;
 }
 
 namespace {
@@ -603,6 +615,9 @@ const char* tepose_error_string(int code) {
     case TEPOSE_E_SHAPE: return "tepose: unsupported shape";
     case TEPOSE_E_WORKSPACE: return "tepose: workspace too small";
     case TEPOSE_E_STATE: return "tepose: model not packed";
+    case TEPOSE_E_TIMEOUT: return "tepose: a persistent kernel's bounded wait expired (GPU shared or CU-masked?); "
+                                  "outputs of that forward are NaN -- tepose_status() clears, TEPOSE_PERSISTENT=0 / "
+                                  "tepose_set_persistent(m, 0) selects the step-per-launch kernels";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "tepose: unknown error";
   }
 }
@@ -623,6 +638,7 @@ void tepose_destroy(tepose_model* m) {
   if (!m) return;
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : m->ev_gru) (void)hipEventDestroy(e);
+  if (m->fault) (void)hipHostFree(m->fault);
   delete m;
 }
 
@@ -632,7 +648,44 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
   if (!m || !blob) return TEPOSE_E_ARG;
   if (bytes < m->blob_floats * sizeof(float)) return TEPOSE_E_WORKSPACE;
   m->blob = (float*)blob;
+  if (!m->fault) {                               // first blob = first moment a device is certain to exist
+    unsigned* f = nullptr;
+    if (hipHostMalloc((void**)&f, 64, hipHostMallocDefault) == hipSuccess && f) { *f = 0u; m->fault = f; }
+    else (void)hipGetLastError();                // no fault word: the persistent kernels are not used (uses_persistent)
+  }
   return 0;
+}
+
+// ---- fault channel of the persistent kernels ------------------------------------------------------------------
+static inline bool fault_pending(const tepose_model* m) {
+  return m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) != 0u;
+}
+static inline bool persist_on(const tepose_model* m) { return m->persist && m->fault != nullptr; }
+
+int tepose_status_peek(const tepose_model* m) {
+  if (!m) return TEPOSE_E_ARG;
+  return fault_pending(m) ? TEPOSE_E_TIMEOUT : 0;
+}
+
+int tepose_status(tepose_model* m, void* stream) {
+  if (!m) return TEPOSE_E_ARG;
+  CK(hipStreamSynchronize((hipStream_t)stream));
+  if (!m->fault) return 0;
+  return __atomic_exchange_n(m->fault, 0u, __ATOMIC_RELAXED) != 0u ? TEPOSE_E_TIMEOUT : 0;
+}
+
+int tepose_set_persistent(tepose_model* m, int on) {
+  if (!m) return TEPOSE_E_ARG;
+  m->persist = on != 0;
+  return 0;
+}
+
+int tepose_uses_persistent(const tepose_model* m, int B, int T) {
+  if (!m || B < 1) return 0;
+  if (!persist_on(m) || !m->split || B <= split_min_m()) return 0;
+  const int cap = gru_seq_max_m() > reg_seq_max_n() ? gru_seq_max_m() : reg_seq_max_n();
+  (void)T;
+  return B <= cap ? 1 : 0;
 }
 
 int tepose_create_vibe_ex(int n_layers, int hidden, int bidirectional, int add_linear, tepose_model** out) {
@@ -1099,7 +1152,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   // by a memset node in front of the first launch of every forward
   const bool scaled_fmt = sf;         // (the layer loop below reuses the name `sf` for a state buffer)
   bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
-  const bool seq = h3 && !sf && w.sync && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
+  const bool seq = h3 && !sf && w.sync && persist_on(m) && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
   const size_t gran_bytes = seq_gran_words(m, B) * sizeof(float);
   if (seq && !sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
   for (int l = 0; l < L; ++l) {
@@ -1224,6 +1277,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         if (st == T - 1) {
           sq.w_kst = (long)n128 * 32; sq.phi = w.state_hi; sq.plo = w.state_lo;
           sq.counters = sync_gru(w.sync, l); sq.status = sync_gru_status(m, w.sync);
+          sq.fault = m->fault; sq.spin_limit = m->spin_limit; sq.inject = (m->test_fault & 1u) ? 1u : 0u;
           sq.ndir = nd; sq.T = T; sq.M = B; sq.Hp = Hp;
           sq.gran = gran_bytes ? w.gran : nullptr; sq.tag_base = (unsigned)l * 64u;
           sq.rhi = w.tailA.hi; sq.rlo = w.tailA.lo; sq.r_kst = (unsigned)w.tailA.kst;
@@ -1339,6 +1393,7 @@ int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, 
 
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {
+  if (m && fault_pending(m)) return TEPOSE_E_TIMEOUT;       // an earlier forward on this handle gave up: say so before more work is queued
   return encoder_fwd_impl(m, x, B, T, is_train, feat, workspace, ws_bytes, stream, nullptr, nullptr, false, nullptr);
 }
 
@@ -1501,6 +1556,7 @@ int tepose_forward_cached(const tepose_model* m, const float* ring_base, int rin
       first_slot < 0 || first_slot >= ring)
     return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
+  if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
   if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* feat = (float*)workspace;
@@ -1530,6 +1586,7 @@ int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, i
                               const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta,
                               float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                               void* stream) {
+  if (m && fault_pending(m)) return TEPOSE_E_TIMEOUT;
   return regressor_impl(m, feat, N, n_iter, init_pose, init_shape, init_cam, jreg_packed, theta, verts, kp_3d, kp_2d,
                         rotmat, workspace, ws_bytes, stream, false, false);
 }
@@ -1556,7 +1613,7 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
     // the three iterations from the model's own initial state as ONE product: xs = feat Mf^T + k0
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     CK((hipError_t)h3_mm(w.featP, Bl + m->mf_p, 256, kFeat, w.xs, kState, Bl + m->k0, N, kState, nullptr, 0, 0.f, nullptr, s));
-  } else if (w.split_fc && N <= reg_seq_max_n()) {
+  } else if (w.split_fc && N <= reg_seq_max_n() && persist_on(m)) {
     // small batches: the whole FC loop in one persistent launch (reg_seq.hip)
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     if (!sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
@@ -1572,6 +1629,7 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
     ra.h1h = w.h1P.hi; ra.h1l = w.h1P.lo; ra.h2h = w.h2P.hi; ra.h2l = w.h2P.lo; ra.h_kst = w.h1P.kst;
     ra.xh = w.xsP.hi; ra.xl = w.xsP.lo; ra.x_kst = w.xsP.kst;
     ra.xs = w.xs; ra.counters = sync_reg(m, w.sync); ra.status = sync_reg_status(m, w.sync);
+    ra.fault = m->fault; ra.spin_limit = m->spin_limit; ra.inject = (m->test_fault & 2u) ? 1u : 0u;
     ra.N = N; ra.n_iter = n_iter;
     CK(launch_reg_seq(ra, s));
   } else if (w.split_fc) {
@@ -1633,6 +1691,7 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
                    float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                    void* stream) {
   if (!m || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
+  if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
   if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
   // [feature | shared scratch]: the encoder's scratch is dead once `feat` exists
   float* feat = (float*)workspace;

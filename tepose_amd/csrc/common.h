@@ -219,7 +219,11 @@ struct GruSeqArgs {
   const float* bhh[3];
   half_t *phi, *plo;                     // state planes (hi / lo) that every poff refers to
   unsigned* counters;                    // 3 x 32 uints, zeroed before the launch: arrivals per direction
-  unsigned* status;                      // set to 1 when a bounded wait gave up
+  unsigned* status;                      // set to non-zero when a bounded wait gave up (device word, cleared per forward)
+  unsigned* fault;                       // the handle's host-visible fault word (pinned host memory, sticky until
+                                         // tepose_status reads it) or nullptr: written with system scope on give-up
+  unsigned spin_limit;                   // polls before a wait gives up (~1 us each)
+  unsigned inject;                       // test knob (TEPOSE_TEST_FAULT): added to what a wait expects, so that it cannot be met
   int ndir, T, M, Hp;
   // optional single cell step from h = 0 of one more direction (the top bi-GRU layer's forward direction consumes only
   // its first step, tepose.py:80), done by direction 0's workgroups before their loop; x_gi == nullptr: none
@@ -250,6 +254,7 @@ struct RegSeqArgs {
   float* xs;                                      // final state [N][160]
   unsigned* counters;                             // 3 x 32 uints, zeroed before the launch
   unsigned* status;
+  unsigned* fault; unsigned spin_limit; unsigned inject;      // as GruSeqArgs
   int N, n_iter;
 };
 int reg_seq_max_n();

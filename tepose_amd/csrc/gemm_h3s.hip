@@ -79,7 +79,11 @@ hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, in
 // max |v| of a buffer into *out (one float, zeroed by the caller): bit pattern of |v| as an unsigned atomic max
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ src, size_t n, unsigned* out) {
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+  // a NaN counts as infinite (fmaxf alone would drop it and a NaN weight would pass the fp16 range guard)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = fabsf(src[i]);
+    m = fmaxf(m, v <= 3.402823466e38f ? v : __builtin_inff());
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));

@@ -21,8 +21,10 @@
 // storing wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane adds to the direction's counter
 // (agent-scope atomic); the consumer's lane 0 polls that counter with sc1 loads, the workgroup barriers, and every
 // load of handed-off bytes is a buffer_load ... sc1 (bypasses this CU's L1, which other CUs' stores never refresh).
-// Counters are zeroed by a memset node before every launch; spins are bounded (a launch that gives up reports through a
-// status word and publishes NaN from then on).
+// Counters are zeroed by a memset node before every launch; spins are bounded: a launch that gives up sets the forward's
+// status word (the other workgroups' waits test it and end at once), publishes NaN from then on, and writes the HANDLE's
+// host-visible fault word (pinned host memory, system-scope store) -- tepose_status() / the next call on the handle
+// return TEPOSE_E_TIMEOUT (api.hip), so a give-up is an error at the boundary, never silent NaN.
 //
 // 33..64 rows of a 2-direction layer: two workgroups share a unit slice and take 32 rows each (row slices are independent
 // chains with their own counters).  <= 4 rows (template flag GR): no counters at all -- the state travels as 8-byte
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
     if (st > 0) {
       if constexpr (GR) {
         // sweep this wave's K-slice of the previous state until every granule carries this step's tag
-        const unsigned want = a.tag_base + (unsigned)st;
+        const unsigned want = a.tag_base + (unsigned)st + a.inject;
         const unsigned long long* gsrc = a.gran + ((size_t)(dir * 2 + ((st - 1) & 1)) * kSeqGranRows) * Hp + wave * 32 * KS + 2 * lane;
         const bool mine = 2 * lane < 32 * KS;
         half_t* gh = gst + (wave * 2) * 16 * GLD;
@@ -214,8 +216,20 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
               *(unsigned*)(gl + r * GLD + 2 * lane) = (((unsigned)g0[r] >> 16) & 0xffffu) | ((unsigned)g1[r] & 0xffff0000u);
             }
           if (__all(ok)) break;
-          if (++spins > (1u << 20)) {                       // ~1 s: a workgroup of the direction is not resident
-            if (lane == 0) { __hip_atomic_store(a.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); gave_up = 1; }
+          ++spins;
+          // somebody else gave up already (status word, or a wave of this workgroup): do not sit out the rest of this wait,
+          // nor any later one (tested every 1024 sweeps only: the sweep is the B <= 4 step's critical path)
+          if ((spins & 1023u) == 0u && (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                        *(volatile unsigned*)&gave_up != 0u)) {
+            if (lane == 0) gave_up = 1;
+            break;
+          }
+          if (spins > (a.spin_limit >> 1)) {                // ~1 s by default: a workgroup of the direction is not resident
+            if (lane == 0) {
+              __hip_atomic_store(a.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (a.fault) __hip_atomic_store(a.fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              gave_up = 1;
+            }
             break;
           }
         }
@@ -248,13 +262,20 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
             red[((wave * MT * 3 + g) * 4 + ee) * 64 + lane] = acc[g][ee] + accx[g][ee] * (1.f / kLoScale);
       } else {
       // every workgroup of this direction has published step st - 1
-      if (tid == 0 && !(TEPOSE_SEQ_ABL & 4)) {
-        const unsigned want = cpd * (unsigned)st;
+      if (tid == 0 && !(TEPOSE_SEQ_ABL & 4) && !gave_up) {
+        const unsigned want = cpd * (unsigned)st + a.inject;
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 21)) {             // ~2 s: give up (a workgroup of the direction is not resident / died)
+          ++spins;
+          // another workgroup gave up already: this wait (and every later one, `gave_up`) ends at once
+          if ((spins & 1023u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            gave_up = 1;
+            break;
+          }
+          if (spins > a.spin_limit) {             // ~2 s by default: give up (a workgroup of the direction is not resident / died)
             __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             gave_up = 1;
             break;
           }

@@ -31,14 +31,20 @@ __device__ __forceinline__ h16x8 rs_h8(u32x4 v) {
   return c.h;
 }
 
-// wait until *counter >= want (lane 0 of the workgroup polls, everybody leaves through the barrier)
-__device__ __forceinline__ void rs_wait(unsigned* counter, unsigned want, unsigned* status, int tid) {
+// wait until *counter >= want (lane 0 of the workgroup polls, everybody leaves through the barrier).  A wait that gives up
+// sets the forward's status word (the final store turns the state NaN; other waits see it and end at once) and the
+// handle's host-visible fault word (tepose_status / the next call return TEPOSE_E_TIMEOUT).
+__device__ __forceinline__ void rs_wait(unsigned* counter, unsigned want, const RegSeqArgs& a, int tid) {
   if (tid == 0) {
     unsigned spins = 0;
+    want += a.inject;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 21)) {                         // ~2 s: give up; the state turns NaN (see the final store)
-        __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++spins;
+      if ((spins & 1023u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      if (spins > a.spin_limit) {                         // ~2 s by default: give up
+        __hip_atomic_store(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.fault) __hip_atomic_store(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
     }
@@ -191,7 +197,7 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
 
   for (int it = 0; it < a.n_iter; ++it) {
     // ---- h1 = base + xs W1b^T (K = 160: waves 0..4 one K-tile each)
-    rs_wait(c_xs, 10u * (unsigned)(it + 1), a.status, tid);
+    rs_wait(c_xs, 10u * (unsigned)(it + 1), a, tid);
     {
       f32x4 acc[MT], accx[MT];
       zero(acc, accx);
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
     }
     rs_arrive(c_h1, tid);
     // ---- h2 = h1 W2^T + b2 (K = 1024: 4 K-tiles per wave)
-    rs_wait(c_h1, 64u * (unsigned)(it + 1), a.status, tid);
+    rs_wait(c_h1, 64u * (unsigned)(it + 1), a, tid);
     {
       f32x4 acc[MT], accx[MT];
       zero(acc, accx);
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
     rs_arrive(c_h2, tid);
     // ---- xs += h2 Wdec^T + bdec (workgroups 0..9)
     if (dec) {
-      rs_wait(c_h2, 64u * (unsigned)(it + 1), a.status, tid);
+      rs_wait(c_h2, 64u * (unsigned)(it + 1), a, tid);
       f32x4 acc[MT], accx[MT];
       zero(acc, accx);
 #pragma unroll

@@ -44,8 +44,8 @@ def gather_records(records, dst=0):
     sum_mpjpe, ...).  Ranks may hold different n_local: rows are padded to the maximum and
     the true counts travel in a first all_gather.  Returns the concatenated [sum n, k]
     tensor on `dst`, None elsewhere."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return records
+    if not (dist.is_available() and dist.is_initialized()):
+        return records               # (an initialised group of ONE rank runs the collectives: `--force-dist`)
     world, rank = dist.get_world_size(), dist.get_rank()
     k = records.shape[1]
     n = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)

@@ -13,12 +13,30 @@ import os
 
 import torch
 
+from . import _lib
 from .engine import on_device
 
 
 @torch.no_grad()
 def run_clips(model, features, theta_init, seqlen, J_regressor=None, keep=('theta', 'kp_3d', 'verts', 'rotmat'),
               cache_projections='auto'):
+    """`_run_clips` under the failure contract of the persistent small-batch kernels (include/tepose_amd.h, "failure
+    channel"): the window steps are queued without a host sync (`lazy` status mode), the handle's fault word is read at
+    the end -- the driver's one sync point -- and a run during which a kernel gave up is repeated on the step-per-launch
+    HIP kernels (the engine has switched the handle over and warned by then).  Never NaN results, never a CPU path."""
+    eng = model._engine
+    for attempt in (0, 1):
+        try:
+            with eng.lazy_status():
+                res = _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_projections)
+                eng.check_status()
+            return res
+        except _lib.TeposeTimeout:
+            if attempt:
+                raise
+
+
+def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_projections):
     """features: list of [N_i, 2048] tensors (one per clip); theta_init: list of [seqlen-1, 85]
     (theta of the first seqlen-1 frames: pseudo-theta with cam=[1,0,0] in evaluate.py:177,219,
     VIBE output in demo.py:237).  Clips shorter than seqlen are skipped (evaluate.py:226-227).

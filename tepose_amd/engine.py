@@ -1,7 +1,10 @@
 """Host-side owner of one tepose_model handle: the packed-weight blob, the workspace,
 and the calls into the C ABI.  PyTorch is used for device memory and streams only.
 """
+import contextlib
 import ctypes
+import os
+import warnings
 from ctypes import c_double, c_int, c_int32, c_void_p
 
 import torch
@@ -62,6 +65,18 @@ class Engine:
         self.packed_generation = 0     # bumped by every (re)pack: the workspace size can depend on what was packed
         self._jreg_cache = {}
         self.profiling = False
+        # What happens when a persistent small-batch kernel gives up (TEPOSE_E_TIMEOUT, include/tepose_amd.h):
+        #   'sync' (default): every forward that may have launched one synchronises its stream and reads the handle's fault
+        #          word before returning -- on a fault the handle switches to the step-per-launch kernels, warns, and the
+        #          forward is re-run, so the caller never sees the NaN outputs (the reference's callers .cpu() the outputs
+        #          right after the forward, evaluate.py:258-261: the sync is theirs anyway);
+        #   'lazy': no sync; the fault surfaces as TeposeTimeout at the next call on the handle or at check_status() --
+        #          for callers that own their sync points (tepose_amd.driver, bench.py).
+        self.status_mode = os.environ.get('TEPOSE_STATUS_CHECK', 'sync')
+        if self.status_mode not in ('sync', 'lazy'):
+            raise ValueError("TEPOSE_STATUS_CHECK must be 'sync' or 'lazy'")
+        self._uses_persistent = {}
+        self.degraded = False          # a fault switched this handle to the step-per-launch kernels
 
     def __del__(self):
         try:
@@ -184,6 +199,59 @@ class Engine:
             hit = self._jreg_cache[key] = (buf, J)   # keep J alive so its data_ptr stays unique
         return hit[0], hit[0].data_ptr()
 
+    # ------------------------------------------------------------------ fault channel of the persistent kernels
+    def uses_persistent(self, B):
+        k = (int(B), self.packed_generation, self.degraded)
+        v = self._uses_persistent.get(k)
+        if v is None:
+            if len(self._uses_persistent) > 64:
+                self._uses_persistent.clear()
+            v = self._uses_persistent[k] = bool(self.lib.tepose_uses_persistent(self.handle, int(B), 0))
+        return v
+
+    def _degrade(self, what):
+        """A bounded wait expired: from now on this handle runs the step-per-launch HIP kernels (same results, no
+        residency requirement)."""
+        _lib.check(self.lib.tepose_set_persistent(self.handle, 0), 'tepose_set_persistent')
+        self.degraded = True
+        warnings.warn('tepose_amd: a persistent small-batch kernel gave up waiting for its peer workgroups (%s) -- is the GPU '
+                      'shared with another process or CU-masked?  This model now uses the step-per-launch kernels '
+                      '(set TEPOSE_PERSISTENT=0 to start that way).' % what, RuntimeWarning, stacklevel=4)
+
+    def check_status(self):
+        """Synchronise the current stream and raise TeposeTimeout if a forward on this handle gave up since the last
+        check (its outputs are NaN).  The handle is switched to the step-per-launch kernels first, so a re-run works."""
+        rc = self.lib.tepose_status(self.handle, self._stream())
+        if rc == _lib.E_TIMEOUT:
+            self._degrade('outputs since the last check are invalid')
+        _lib.check(rc, 'tepose_status')
+
+    @contextlib.contextmanager
+    def lazy_status(self):
+        old, self.status_mode = self.status_mode, 'lazy'
+        try:
+            yield self
+        finally:
+            self.status_mode = old
+
+    def _run(self, B, call):
+        """call() queues one forward on the current stream and returns its outputs."""
+        try:
+            out = call()
+        except _lib.TeposeTimeout:
+            # refused up front: an EARLIER forward on this handle gave up (lazy mode); clear, switch kernels, tell the caller
+            self.lib.tepose_status(self.handle, self._stream())
+            self._degrade('outputs of earlier forwards are invalid')
+            raise
+        if self.status_mode == 'sync' and self.uses_persistent(B) and not torch.cuda.is_current_stream_capturing():
+            rc = self.lib.tepose_status(self.handle, self._stream())
+            if rc == _lib.E_TIMEOUT:
+                self._degrade('re-running this forward')
+                out = call()
+                rc = self.lib.tepose_status(self.handle, self._stream())
+            _lib.check(rc, 'tepose_status')
+        return out
+
     # ------------------------------------------------------------------ forward
     def workspace(self, B, T, device):
         k = (int(B), int(T), self.packed_generation)
@@ -200,11 +268,14 @@ class Engine:
     def encoder_fwd(self, x, is_train):
         B, T = x.shape[:2]
         ws = self.workspace(B, T, x.device)
-        feat = torch.empty((B, 2, 2048) if is_train else (B, 2048), dtype=torch.float32, device=x.device)
-        _lib.check(self.lib.tepose_encoder_fwd(self.handle, x.data_ptr(), B, T, 1 if is_train else 0,
-                                               feat.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
-                   'tepose_encoder_fwd')
-        return feat
+
+        def call():
+            feat = torch.empty((B, 2, 2048) if is_train else (B, 2048), dtype=torch.float32, device=x.device)
+            _lib.check(self.lib.tepose_encoder_fwd(self.handle, x.data_ptr(), B, T, 1 if is_train else 0,
+                                                   feat.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                       'tepose_encoder_fwd')
+            return feat
+        return self._run(B, call)
 
     def regressor_fwd(self, feat, n_iter, J_regressor, ws_hint=None, init=(None, None, None)):
         N = feat.shape[0]
@@ -217,19 +288,16 @@ class Engine:
         ws = self.workspace(max(1, (N + 1) // 2), 1, dev) if ws_hint is None else ws_hint
         _, jp = self.jreg(J_regressor, dev)
         nj = 14 if J_regressor is not None else 49
-        out = {
-            'theta': torch.empty((N, 85), dtype=torch.float32, device=dev),
-            'verts': torch.empty((N, NUM_VERTS, 3), dtype=torch.float32, device=dev),
-            'kp_2d': torch.empty((N, nj, 2), dtype=torch.float32, device=dev),
-            'kp_3d': torch.empty((N, nj, 3), dtype=torch.float32, device=dev),
-            'rotmat': torch.empty((N, 24, 3, 3), dtype=torch.float32, device=dev),
-        }
-        _lib.check(self.lib.tepose_regressor_fwd_init(
-            self.handle, feat.data_ptr(), N, int(n_iter), *[None if t is None else t.data_ptr() for t in init], jp,
-            out['theta'].data_ptr(), out['verts'].data_ptr(),
-            out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
-            self._stream()), 'tepose_regressor_fwd_init')
-        return out
+
+        def call():
+            out = self._outputs(N, nj, dev)
+            _lib.check(self.lib.tepose_regressor_fwd_init(
+                self.handle, feat.data_ptr(), N, int(n_iter), *[None if t is None else t.data_ptr() for t in init], jp,
+                out['theta'].data_ptr(), out['verts'].data_ptr(),
+                out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
+                self._stream()), 'tepose_regressor_fwd_init')
+            return out
+        return self._run(N, call)
 
     @staticmethod
     def _outputs(N, nj, dev):
@@ -248,12 +316,15 @@ class Engine:
         ws = self.workspace(B, T, dev)
         _, jp = self.jreg(J_regressor, dev)
         nj = 14 if J_regressor is not None else 49
-        out = self._outputs(B, nj, dev)
-        _lib.check(self.lib.tepose_forward(
-            self.handle, x.data_ptr(), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
-            out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
-            self._stream()), 'tepose_forward')
-        return out
+
+        def call():
+            out = self._outputs(B, nj, dev)
+            _lib.check(self.lib.tepose_forward(
+                self.handle, x.data_ptr(), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
+                out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
+                self._stream()), 'tepose_forward')
+            return out
+        return self._run(B, call)
 
     def smpl_fwd(self, pose, betas, pose2rot):
         """pose [N,72] (axis-angle) or [N,24,3,3]; betas [N,10] -> verts [N,6890,3], joints [N,49,3]."""
@@ -283,19 +354,16 @@ class Engine:
         ws = self.workspace(B, T, dev)
         _, jp = self.jreg(J_regressor, dev)
         nj = 14 if J_regressor is not None else 49
-        out = {
-            'theta': torch.empty((B, 85), dtype=torch.float32, device=dev),
-            'verts': torch.empty((B, NUM_VERTS, 3), dtype=torch.float32, device=dev),
-            'kp_2d': torch.empty((B, nj, 2), dtype=torch.float32, device=dev),
-            'kp_3d': torch.empty((B, nj, 3), dtype=torch.float32, device=dev),
-            'rotmat': torch.empty((B, 24, 3, 3), dtype=torch.float32, device=dev),
-        }
-        _lib.check(self.lib.tepose_forward_cached(
-            self.handle, ring.data_ptr(), ring.shape[1], int(first_slot), ring.stride(0), newest.data_ptr(),
-            newest.stride(0), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(), out['kp_3d'].data_ptr(),
-            out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
-            'tepose_forward_cached')
-        return out
+
+        def call():
+            out = self._outputs(B, nj, dev)
+            _lib.check(self.lib.tepose_forward_cached(
+                self.handle, ring.data_ptr(), ring.shape[1], int(first_slot), ring.stride(0), newest.data_ptr(),
+                newest.stride(0), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(), out['kp_3d'].data_ptr(),
+                out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                'tepose_forward_cached')
+            return out
+        return self._run(B, call)
 
     # ------------------------------------------------------------------ VIBE bootstrap encoder
     def pack_vibe_encoder(self, enc, device):
@@ -354,7 +422,6 @@ def warn_if_training(module, *tensors):
     grad = torch.is_grad_enabled() and (any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors) or
                                         any(p.requires_grad for p in module.parameters()))
     if module.training or grad:
-        import warnings
         _warned_train[0] = True
         warnings.warn('tepose_amd is inference-only: outputs carry no autograd graph and Dropout is not applied'
                       + (' (module is in train mode: call model.eval())' if module.training else '')

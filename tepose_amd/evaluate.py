@@ -72,7 +72,7 @@ def gather_rank_stats(rank, seconds, lengths, mine):
     lock-step window steps, not by its frame total; `seconds_max_over_mean` is the measured imbalance."""
     row = torch.tensor([[float(rank), float(seconds), float(len(mine)), float(sum(lengths[i] for i in mine)),
                          float(max([lengths[i] for i in mine], default=0))]], dtype=torch.float64)
-    if D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1:
+    if D.dist.is_available() and D.dist.is_initialized():
         row = row.to(torch.device('cuda', torch.cuda.current_device())) if D.dist.get_backend() == 'nccl' else row
     allr = D.gather_records(row, dst=0)
     if allr is None:

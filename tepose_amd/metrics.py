@@ -103,7 +103,7 @@ def trainer_evaluate(model, acc, target, seqlen):
     ('kp_3d' [C, vidlen, J, 3], 'theta' [C, vidlen, 85], 'vidlen_each' [C, 1]).  Returns the trainer's eval_dict in mm:
     'mpjpe', 'pa-mpjpe' (pelvis = mean of joints 2, 3; similarity Procrustes: the device kernels of joint_metrics),
     'accel', 'accel_err' (eval_utils.py:53-107: per video the second differences of frames seqlen-1 .. vidlen-3 resp.
-    .. vidlen-5 of the pelvis-aligned [C, vidlen] tensors, normalised by sum(vidlen) - C (seqlen + 1) resp. (seqlen + 3)),
+    .. vidlen-5 of the [C, vidlen] tensors -- prediction pelvis-aligned per frame, target as trainer.py:470 leaves it --, normalised by sum(vidlen) - C (seqlen + 1) resp. (seqlen + 3)),
     'pve' (vertices against SMPL(target theta), eval_utils.py:141-175)."""
     T = int(seqlen)
     dev = acc['pred_kp_3d'].device
@@ -118,7 +118,11 @@ def trainer_evaluate(model, acc, target, seqlen):
     p = acc['pred_j3d_tsr'].to(dev).clone()
     g = kp_t.clone().float()
     p -= (p[:, :, [2]] + p[:, :, [3]]) / 2.0
-    g -= (g[:, :, [2]] + g[:, :, [3]]) / 2.0
+    # trainer.py:470 indexes the [C, vidlen, J, 3] target with `[:,[2],:]` / `[:,[3],:]`: FRAMES 2 and 3, not joints -- the
+    # ground truth loses one constant per clip and joint and keeps its raw accelerations (pelvis motion included), while
+    # the prediction (line above, trainer.py:469) is pelvis-aligned per frame.  Reproduced as written: accel_err of the
+    # reference contains the ground-truth pelvis acceleration.
+    g -= (g[:, [2]] + g[:, [3]]) / 2.0
     vl = torch.tensor(lens, dtype=torch.float32)
     a_p = p[:, 2:] - 2 * p[:, 1:-1] + p[:, :-2]
     a_g = g[:, 2:] - 2 * g[:, 1:-1] + g[:, :-2]

@@ -269,7 +269,9 @@ def padded_case(T_mod, name, L, H, lens, T, seed_w, seed_x):
     errors_pa = torch.sqrt(((S1_hat - tj) ** 2).sum(dim=-1)).mean(dim=-1).numpy()
     ptsr, ttsr = pred_j3d_tsr.clone(), target['kp_3d'].clone()
     ptsr -= (ptsr[:, :, [2], :] + ptsr[:, :, [3], :]) / 2.0
-    ttsr -= (ttsr[:, :, [2], :] + ttsr[:, :, [3], :]) / 2.0
+    # trainer.py:470 as written: `target_j3ds_tsr[:,[2],:]` on the [C, vidlen, J, 3] tensor indexes FRAMES 2 and 3, i.e. the
+    # ground truth loses one constant per clip and joint, not its per-frame pelvis (its accelerations stay the raw ones)
+    ttsr -= (ttsr[:, [2], :] + ttsr[:, [3], :]) / 2.0
     accel = compute_accel(ptsr, target['vidlen_each'], T) * 1000
     accel_err = compute_error_accel(joints_pred=ptsr, joints_gt=ttsr, vidlen_each=target['vidlen_each'], seqlen=T) * 1000
     evald = np.array([np.mean(errors) * 1000, np.mean(errors_pa) * 1000, float(accel), float(accel_err)], dtype=np.float64)

@@ -58,3 +58,21 @@ def _worker(rank, world, port, lengths):
 def test_broadcast_and_gather_world2_gloo():
     lengths = [300, 20, 75, 1200, 64, 333, 48]     # 7 clips -> ranks hold 3 and 4 (ragged gather)
     mp.spawn(_worker, args=(2, _free_port(), lengths), nprocs=2, join=True)
+
+
+def _worker_one(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        rec = torch.tensor([[0., 10., 5.], [1., 30., 15.]], dtype=torch.float64)
+        out = gather_records(rec, dst=0)              # a group of one rank still goes through all_gather + gather
+        assert torch.equal(out, rec)
+        out = gather_records(rec[:0], dst=0)          # ... also with no local clip at all
+        assert out.shape == (0, 3)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_runs_the_collectives_in_a_group_of_one():
+    """`--force-dist` (bench.py, tools/evaluate_clips.py): the N-GPU code path at world size 1."""
+    mp.spawn(_worker_one, args=(1, _free_port()), nprocs=1, join=True)

@@ -42,6 +42,29 @@ def test_single_rank_bench_path_is_unchanged():
     assert r['n_gpus'] == 1 and 'weight_broadcast_ms' not in r and r['outputs_finite'] is True
 
 
+def test_rccl_path_executes_at_world_size_one():
+    """`--force-dist`: dist.init_process_group('nccl', device_id=...) -- RCCL -- plus the blob broadcast, the all_reduce of
+    the step time and the gather of the per-rank records, on this 1-GPU box: the collectives of the 8-GPU run execute at
+    least once before the driver's node does it for real (reference shard axis: evaluate.py:214).  A second handle adopts
+    a copy of the broadcast blob and must reproduce rank 0's probe forward bit for bit."""
+    r = _run(['bench.py', '--force-dist', '--batch', '128', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extra'])
+    assert r['n_gpus'] == 1 and r['dist_backend'] == 'nccl'
+    assert r['weight_broadcast_ms'] > 0 and r['weight_blob_MB'] > 100
+    assert r['adopted_blob_matches'] is True and r['ranks_agree'] is True
+    assert len(r['per_rank']) == 1 and int(r['per_rank'][0][2]) == 128 * 2 and r['per_rank'][0][3] == 1.0
+    assert r['outputs_finite'] is True
+
+
+def test_clip_sharded_evaluation_runs_on_rccl_at_world_size_one():
+    common = ['tools/evaluate_clips.py', '--layers', '1', '--hidden', '64', '--seqlen', '5', '--clips', '7', '--min-len', '6',
+              '--max-len', '40']
+    one = _run(common)
+    rccl = _run(common + ['--force-dist'])
+    assert rccl['dist_backend'] == 'nccl' and rccl['n_gpus'] == 1
+    assert rccl['metrics_mm'] == one['metrics_mm']         # same clips, same batches: the gathers only move the records
+    assert rccl['per_rank']['clips'] == [7]
+
+
 def test_clip_sharded_evaluation_world2_equals_world1():
     common = ['tools/evaluate_clips.py', '--layers', '1', '--hidden', '64', '--seqlen', '5', '--clips', '7', '--min-len', '6',
               '--max-len', '40']

@@ -1,0 +1,153 @@
+"""GPU: the failure channel of the persistent small-batch kernels (include/tepose_amd.h "failure channel";
+csrc/gru_seq.hip, csrc/reg_seq.hip).  A launch whose workgroups cannot all be resident (GPU shared / CU-masked) gives up
+after a bounded wait.  The reference has no silent-garbage mode -- an exception ends evaluate.py:255 -- so here a give-up
+must surface as TEPOSE_E_TIMEOUT / TeposeTimeout or be repaired by a re-run on the step-per-launch HIP kernels; the
+caller never receives the NaN outputs with rc 0.
+
+The give-up is forced with the test-only knob TEPOSE_TEST_FAULT (read at tepose_create: the waits of that handle's
+persistent kernels expect one more arrival / tag than anybody publishes) and a short TEPOSE_SEQ_SPIN_LIMIT."""
+import ctypes
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from tepose_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def smpl_np():
+    return synth.synthetic_smpl(0)
+
+
+def _faulty_model(monkeypatch, smpl_np, bits, L=2, H=256, seed=21, mode=None):
+    from tepose_amd.testing import build_model
+    monkeypatch.setenv('TEPOSE_TEST_FAULT', str(bits))
+    monkeypatch.setenv('TEPOSE_SEQ_SPIN_LIMIT', '20000')          # ~20 ms instead of ~2 s per give-up
+    if mode:
+        monkeypatch.setenv('TEPOSE_STATUS_CHECK', mode)
+    model, state, _ = build_model(L, H, seed=seed, device='cuda', smpl_np=smpl_np)
+    monkeypatch.delenv('TEPOSE_TEST_FAULT')
+    monkeypatch.delenv('TEPOSE_SEQ_SPIN_LIMIT')
+    return model, state
+
+
+def _oracle(state, smpl_np, x, L, J):
+    from oracle import tepose_ref as O
+    return O.tepose_fwd(state, smpl_np, x, L, J_regressor=J)
+
+
+@pytest.mark.parametrize('B', [1, 3, 8, 40])         # granule mode (<= 4 rows) and counter mode, 1 / 4 row tiles
+def test_give_up_is_repaired_in_sync_mode(B, smpl_np, monkeypatch):
+    """Default status mode: model(x) notices the give-up before it returns, warns, re-runs on the step kernels and hands
+    out correct results."""
+    model, state = _faulty_model(monkeypatch, smpl_np, 1)
+    assert model._engine.status_mode == 'sync'
+    x = synth.synthetic_windows(B, 6, 9)
+    J = smpl_np['J_regressor_h36m']
+    with pytest.warns(RuntimeWarning, match='gave up'):
+        with torch.no_grad():
+            out = model(torch.from_numpy(x).cuda(), J_regressor=torch.from_numpy(J))[0]
+    assert model._engine.degraded
+    ref = _oracle(state, smpl_np, x, 2, J)
+    for k in ('theta', 'verts', 'kp_3d'):
+        got = out[k].cpu().numpy()
+        assert np.isfinite(got).all(), k
+        assert np.abs(got - ref[k].numpy()).max() < 1e-4, k
+    # the handle stays on the step kernels: no further warning, same results
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        with torch.no_grad():
+            out2 = model(torch.from_numpy(x).cuda(), J_regressor=torch.from_numpy(J))[0]
+    assert torch.equal(out2['verts'], out['verts'])
+
+
+def test_give_up_raises_in_lazy_mode_and_at_the_c_boundary(smpl_np, monkeypatch):
+    """Lazy mode (callers that own their sync points): the forward itself returns, the fault surfaces at check_status()
+    as TeposeTimeout; at the C boundary tepose_status_peek / tepose_status return TEPOSE_E_TIMEOUT and a forward entered
+    while the word is raised is refused with the same code."""
+    from tepose_amd import _lib
+    model, state = _faulty_model(monkeypatch, smpl_np, 1, mode='lazy')
+    eng = model._engine
+    assert eng.status_mode == 'lazy'
+    x = torch.from_numpy(synth.synthetic_windows(2, 5, 10)).cuda()
+    with torch.no_grad():
+        out = model(x)[0]
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out['verts']).all()        # what the boundary must never hand over silently
+    lib = eng.lib
+    assert lib.tepose_status_peek(eng.handle) == _lib.E_TIMEOUT
+    # a second forward is refused up front (rc, not NaN), the handle switches kernels, the exception reaches the caller
+    with pytest.warns(RuntimeWarning, match='gave up'):
+        with pytest.raises(_lib.TeposeTimeout):
+            with torch.no_grad():
+                model(x)
+    assert lib.tepose_status_peek(eng.handle) == 0
+    with torch.no_grad():
+        good = model(x)[0]
+    eng.check_status()                                    # nothing pending: no exception
+    assert torch.isfinite(good['verts']).all()
+    assert b'bounded wait' in lib.tepose_error_string(_lib.E_TIMEOUT)
+
+
+def test_check_status_raises_after_a_faulted_forward(smpl_np, monkeypatch):
+    from tepose_amd import _lib
+    model, _ = _faulty_model(monkeypatch, smpl_np, 1, mode='lazy')
+    x = torch.from_numpy(synth.synthetic_windows(5, 4, 11)).cuda()
+    with torch.no_grad():
+        model(x)
+    with pytest.warns(RuntimeWarning, match='gave up'):
+        with pytest.raises(_lib.TeposeTimeout):
+            model._engine.check_status()
+    assert model._engine.degraded and not model._engine.uses_persistent(5)
+
+
+def test_regressor_kernel_give_up(smpl_np, monkeypatch):
+    """The persistent FC-loop kernel (n_iter != 3 keeps the loop): same contract."""
+    from oracle import tepose_ref as O
+    model, state = _faulty_model(monkeypatch, smpl_np, 2)
+    feat = synth.normal('status/feat', (6, 2048), std=0.5)
+    with pytest.warns(RuntimeWarning, match='gave up'):
+        with torch.no_grad():
+            out = model.regressor(torch.from_numpy(feat).cuda(), n_iter=2)[0]
+    _, reg = O.split_state_dict(state, torch.float64)
+    with torch.no_grad():
+        ref = O.regressor_fwd(reg, O.smpl_tensors(smpl_np, torch.float64), torch.from_numpy(feat).double(), n_iter=2)
+    assert np.abs(out['verts'].cpu().numpy() - ref['verts'].numpy()).max() < 1e-4
+
+
+def test_driver_repeats_a_faulted_run(smpl_np, monkeypatch):
+    """run_clips queues its window steps without syncing; a give-up anywhere in the run is read at the end and the run
+    is repeated on the step kernels: same results as a healthy handle."""
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    good, _, _ = build_model(2, 256, seed=21, device='cuda', smpl_np=smpl_np)
+    bad, _ = _faulty_model(monkeypatch, smpl_np, 1)
+    feats = [torch.from_numpy(synth.normal('status/clip%d' % i, (n, 2048), std=0.5)) for i, n in enumerate((9, 7))]
+    th0 = [torch.from_numpy(synth.normal('status/th%d' % i, (3, 85), std=0.1)) for i in range(2)]
+    ref = run_clips(good, feats, th0, 4)
+    with pytest.warns(RuntimeWarning, match='gave up'):
+        got = run_clips(bad, feats, th0, 4)
+    for r, g in zip(ref, got):
+        assert torch.isfinite(g['verts']).all()
+        assert (r['verts'] - g['verts']).abs().max() < 2e-5      # persistent vs step kernels: K-partials grouped differently
+        assert (r['theta'] - g['theta']).abs().max() < 2e-5
+
+
+def test_persistent_kernels_can_be_switched_off_up_front(smpl_np, monkeypatch):
+    """TEPOSE_PERSISTENT=0: the documented start-up remedy for shared / CU-masked GPUs."""
+    from tepose_amd.testing import build_model
+    monkeypatch.setenv('TEPOSE_PERSISTENT', '0')
+    monkeypatch.setenv('TEPOSE_TEST_FAULT', '3')                  # would fault if a persistent kernel ran
+    model, state, _ = build_model(2, 256, seed=21, device='cuda', smpl_np=smpl_np)
+    x = synth.synthetic_windows(3, 5, 12)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        with torch.no_grad():
+            out = model(torch.from_numpy(x).cuda())[0]
+    assert not model._engine.uses_persistent(3)
+    ref = _oracle(state, smpl_np, x, 2, None)
+    assert np.abs(out['verts'].cpu().numpy() - ref['verts'].numpy()).max() < 1e-4

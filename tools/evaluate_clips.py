@@ -41,6 +41,8 @@ def main():
     ap.add_argument('--layers', type=int, default=2); ap.add_argument('--hidden', type=int, default=1024)
     ap.add_argument('--as-rank', type=int, default=-1, help='debug: process the share of this rank of --of-world in ONE process')
     ap.add_argument('--of-world', type=int, default=2)
+    ap.add_argument('--force-dist', action='store_true', help='world size 1: still initialise the process group (nccl = RCCL) and '
+                    'run the barrier / all_reduce / gathers, so that the N-GPU collectives execute on a 1-GPU box')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # GPU-free parent: the ranks are children of the stock launcher (never an exec of a process that touched HIP)
@@ -55,8 +57,15 @@ def main():
     local = 0 if args.share_device0 else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            import socket
+            sk = socket.socket(); sk.bind(('127.0.0.1', 0))
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+            sk.close()
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group(args.backend, device_id=dev) if args.backend == 'nccl' else dist.init_process_group(args.backend)
     T = args.seqlen
     smpl_np = synth.synthetic_smpl(0)
@@ -83,7 +92,7 @@ def main():
     vibe = vibe.to(dev).eval()
     J = torch.from_numpy(smpl_np['J_regressor_h36m']) if args.dataset != 'mpii3d' else None
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     if args.as_rank >= 0:
@@ -93,7 +102,7 @@ def main():
     torch.cuda.synchronize()
     mine_s = time.perf_counter() - t0
     el = torch.tensor([mine_s], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     res = gather_and_reduce(recs)
     stats = gather_rank_stats(rank, mine_s, [len(c['features']) for c in clips.values()], mine)
@@ -105,8 +114,10 @@ def main():
                'per_rank': stats,      # seconds, clips, frames and longest clip (= serial window chain) of every rank
                'frames_per_s': frames / float(el.item()), 'metrics_mm': res,
                'data': 'real' if args.db else 'synthetic db + random-init weights (metric values are meaningless)'}
+        if use_dist:
+            out['dist_backend'] = dist.get_backend()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
