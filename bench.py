@@ -152,11 +152,11 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
     single = 32 / (time.perf_counter() - t1)
     torch.set_num_threads(cores)
     # the reference path at the small shapes of BASELINE.json too (config 1: one window; config 2: 64 windows),
-    # each at the better of {8 threads, the thread count chosen above} -- a single window does not feed many cores
+    # each at the best of {1, 4, 8 threads, the thread count chosen above} -- a single window does not feed many cores
     small = {}
     for name, b, reps in (('b1_T%d' % T, 1, 12), ('b64_T%d' % T, 64, 3)):
         best_s = None
-        for nt in sorted({min(8, all_cores), cores}):
+        for nt in sorted({1, min(4, all_cores), min(8, all_cores), cores}):
             torch.set_num_threads(nt)
             O.tepose_fwd(state, smpl_np, x[:b], L, J_regressor=J, nn_gru=True)
             ts = time.perf_counter()

@@ -124,6 +124,16 @@ __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch
   constexpr int HM = 32 * WMF * NWM, HN = 32 * WNT * NWN, HK = 16;
   static_assert(NW == 8 || NW == 12, "8 or 12 waves");
   const H3SArgs& a = batch.p[blockIdx.y];
+  if constexpr (GRU) {
+    // EXPERIMENT (TEPOSE_GRU_STAGGER, 10 ns ticks): the launch's first 512 workgroups start together, two per CU, and each
+    // pair would reach its epilogue together; hold the second of each pair back so that one block's epilogue runs under
+    // the other's K-tiles (later workgroups start when one ends and inherit the phase)
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (batch.stagger && lin >= 256u && lin < 512u) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < batch.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   constexpr int RB = HK * 2;                             // 32 bytes per plane row of a stage
   constexpr int RPI = 1024 / RB;                         // 32 rows per DMA instruction
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;          // 32 KB
@@ -609,7 +619,10 @@ hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s) {
   // share a CU and cover each other's pipeline fill and store drain.  Measured against 128 x 128 units (148 VGPRs,
   // one block per CU): -1 % at B = 8192, and it keeps winning down to B ~ 2048; 256 rows x 64 units: +2.5 %.
   const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
-  hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 2, true>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
+  static const unsigned stagger = [] { const char* e = getenv("TEPOSE_GRU_STAGGER"); return e ? (unsigned)atoi(e) : 0u; }();
+  H3SBatch bb = b;
+  bb.stagger = stagger;
+  hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 2, true>), dim3(tm * tj, b.n), dim3(512), 0, s, bb, tm, tj);
   return hipGetLastError();
 }
 

@@ -63,6 +63,8 @@ __device__ __forceinline__ float sq_sigmoid(float x) {
 __device__ __forceinline__ float sq_tanh(float x) {
   return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
 }
+// relu that keeps NaN (fmaxf(NaN, 0) is 0: a poisoned state would reach the tail product as a plausible zero)
+__device__ __forceinline__ float sq_relu(float x) { return x < 0.f ? 0.f : x; }
 __device__ __forceinline__ int sq_slot(long row, int q) { return ((q ^ (int)((row >> 2) & 3)) << 3); }
 
 // two consecutive values of one row as hi / lo plane pairs (4 bytes each)
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
     store_planes2(a.phi + a.x_poff + po, a.plo + a.x_poff + po, hv[0], hv[1]);
     if (a.x_roff != kNoPlane) {
       const long ro = (long)a.x_roff + (long)(ej >> 5) * a.r_kst + plane_index(erow, ej & 31, 0);
-      store_planes2(a.rhi + ro, a.rlo + ro, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f));
+      store_planes2(a.rhi + ro, a.rlo + ro, sq_relu(hv[0]), sq_relu(hv[1]));
     }
   }
 
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
         if (st == T - 1 && a.r_off[dir] != kNoPlane) {
           const long ro = (long)a.r_off[dir] + (long)(j1 >> 5) * a.r_kst + plane_index(0, j1 & 31, 0);
           half_t rh, rl;
-          split_hi_lo(fmaxf(hv, 0.f), rh, rl);
+          split_hi_lo(sq_relu(hv), rh, rl);
           a.rhi[ro] = rh;
           a.rlo[ro] = rl;
         }
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(512) gru_seq_kernel(GruSeqArgs a) {
       }
       if (st == T - 1 && a.r_off[dir] != kNoPlane) {        // relu(final state): the tail linear's A operand
         const long ro = (long)a.r_off[dir] + (long)(ej >> 5) * a.r_kst + plane_index(erow, ej & 31, 0);
-        store_planes2(a.rhi + ro, a.rlo + ro, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f));
+        store_planes2(a.rhi + ro, a.rlo + ro, sq_relu(hv[0]), sq_relu(hv[1]));
       }
     }
     SEQ_STAMP(5);
