@@ -77,5 +77,32 @@ def sq(counter_path, trace_path):
           'wait_* = share of SQ_WAVE_CYCLES')
 
 
+def pmcavg(counter_path, trace_path):
+    """Any counter set: per kernel (recurrent / GEMM kernels only) the average duration and the average of every counter,
+    plus each counter per microsecond."""
+    dur = {}
+    for r in csv.DictReader(open(trace_path)):
+        dur[r['Dispatch_Id']] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    per = defaultdict(dict)
+    meta = {}
+    for r in csv.DictReader(open(counter_path)):
+        per[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
+        meta[r['Dispatch_Id']] = (short(r['Kernel_Name']), r['Grid_Size'])
+    agg = defaultdict(list)
+    for d, c in per.items():
+        if d in dur:
+            agg[meta[d]].append((dur[d], c))
+    for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
+        if not ('gru' in k or 'gemm_h3s' in k):
+            continue
+        n = len(v)
+        du = sum(x[0] for x in v) / n
+        names = sorted({c for x in v for c in x[1]})
+        print('%-44s grid %9s n %4d dur_us %10.1f' % (k, g, n, du))
+        for c in names:
+            val = sum(x[1].get(c, 0.) for x in v) / n
+            print('    %-36s %16.1f   per_us %12.1f' % (c, val, val / du))
+
+
 if __name__ == '__main__':
-    {'trace': trace, 'pmc': pmc, 'sq': sq}[sys.argv[1]](*sys.argv[2:])
+    {'trace': trace, 'pmc': pmc, 'sq': sq, 'pmcavg': pmcavg}[sys.argv[1]](*sys.argv[2:])

@@ -299,7 +299,7 @@ struct H3SArgs {
   int M, N;
   const float* row_scale;                // optional [M], as H3Args::row_scale (then pA = 1)
 };
-struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; unsigned stagger; };   // state_scale: scale of the
+struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // tag 0: the layer-0 projection (own kernel symbol for profiles)                                // state planes a GRU step writes
 hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
 bool gemm_h3s_mid_ok(const H3SArgs& a);

@@ -67,8 +67,12 @@ def test_gemm_rejects_bad_arguments():
                                       (1, 2048, 2, 6), (1, 2048, 800, 3), (3, 64, 777, 2),
                                       (2, 64, 100, 1), (2, 100, 120, 3), (1, 64, 97, 2),
                                       (2, 128, 70, 9), (2, 1024, 40, 16), (3, 100, 250, 3), (2, 64, 333, 4), (2, 192, 129, 4),   # 512 <= B*T < 8192, L >= 2: 128 x 288 tiles (ragged last row tile)
-                                      (2, 64, 1100, 8), (3, 100, 1030, 8), (2, 64, 4100, 3), (3, 100, 4097, 2), (2, 128, 2048, 2)])   # B*T >= 8192: single-accumulator
+                                      (2, 64, 1100, 8), (3, 100, 1030, 8), (2, 64, 4100, 3), (3, 100, 4097, 2), (2, 128, 2048, 2),   # B*T >= 8192: single-accumulator
                                       # layer-0 projection; B >= 2048: scaled-format recurrent path; class defaults: n_layers=1, hidden=2048
+                                      # B >= 2048 and hidden >= 192: the persistent fused GRU step (256-row tiles walked in 4 x 8 / 8 x 4 / 16 x 2 groups;
+                                      # full and ragged row tiles, unit-tile counts 3, 4, 5 (a group with empty slots), 8 and 16)
+                                      (2, 192, 2100, 3), (2, 256, 2304, 3), (1, 320, 2050, 2), (3, 512, 2049, 2), (2, 1024, 2048, 2),
+                                      (2, 1024, 2305, 3)])
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
     from oracle import tepose_ref as O
     model, state, _ = _model(L, H, 11, smpl_np)
