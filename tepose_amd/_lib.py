@@ -21,7 +21,7 @@ SYMBOLS = [
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
-    'tepose_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent',
+    'tepose_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
 ]
 
 _lib = None
@@ -113,6 +113,13 @@ def load():
         getattr(lib, name)              # AttributeError here = the built library is older than this binding
     if lib.tepose_version() != 1:
         raise ImportError('tepose_amd: ABI version mismatch (%d)' % lib.tepose_version())
+    lib.tepose_build_info.restype = c_char_p
+    info = (lib.tepose_build_info() or b'').decode()
+    if 'packed_fp32=off' not in info:
+        import warnings
+        warnings.warn('tepose_amd: %s was built WITH packed-fp32 VALU instructions (%r); on a GPU shared by two processes such a '
+                      'build returned wrong SMPL vertices in 1-3 %% of the launches (DESIGN.md section 10) -- rebuild with '
+                      '__graft_entry__.build()' % (LIB_PATH, info), RuntimeWarning)
     _lib = lib
     return lib
 

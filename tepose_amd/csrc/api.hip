@@ -608,6 +608,14 @@ extern "C" {
 
 int tepose_version(void) { return TEPOSE_ABI_VERSION; }
 
+const char* tepose_build_info(void) {
+#ifdef TEPOSE_NO_PACKED_FP32
+  return "gfx950 packed_fp32=off";
+#else
+  return "gfx950 packed_fp32=on";
+#endif
+}
+
 const char* tepose_error_string(int code) {
   switch (code) {
     case 0: return "ok";

@@ -124,10 +124,12 @@ __device__ __forceinline__ float gs_tanh(float x) {
 // Plain product: 4 x 2 waves of 64 x 128 (WMF 2, WNT 4) = 256 x 256 block.  GRU step: 4 x 2 waves of 32 x 96 (the
 // r, z, n tiles of 32 hidden units) = 128 rows x 64 hidden units x 3 gates, W_hh rows in the gate-interleaved tile
 // order, cell update in the epilogue, new state out as fp32 and as scaled planes.
-template <int WMF, int WNT, int NWM, int NWN, bool GRU>
+// NST: ring slots (NST - 1 stages requested ahead).  4 where a K-tile carries enough MFMA work to cover a stage's latency; the
+// 128 x 288 tile of mid-size batches (12 waves x 9 MFMAs per K-tile = 0.36 us of matrix work against ~2.5 us from request to
+// landing) was bound by 3 stages / latency = 0.89 us per K-tile: 6 slots (160 KB of LDS exactly), 5 stages ahead (round 3).
+template <int WMF, int WNT, int NWM, int NWN, bool GRU, int NST = 4>
 __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch, int tilesM, int tilesN) {
   constexpr int NW = NWM * NWN;                           // waves per block: 8, or 12 for the 128 x 288 tile of mid-size batches
-  constexpr int NST = 4;
   constexpr int HM = 32 * WMF * NWM, HN = 32 * WNT * NWN, HK = 16;
   static_assert(NW == 8 || NW == 12, "8 or 12 waves");
   const H3SArgs& a = batch.p[blockIdx.y];
@@ -149,8 +151,11 @@ __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch
   const int nd = Q + (wave < REM ? 1 : 0);               // this wave's share
   const int i0 = wave * Q + min(wave, REM);              // its first instruction of a stage
   // wait until at most n whole stages of this wave's DMA are still in flight (counted vmcnt, literal per share)
-  auto wait_n1 = [&]() __attribute__((always_inline)) { if (REM && wave < REM) wait_vms<Q + 1>(); else wait_vms<Q>(); };
-  auto wait_n2 = [&]() __attribute__((always_inline)) { if (REM && wave < REM) wait_vms<2 * (Q + 1)>(); else wait_vms<2 * Q>(); };
+  static_assert((NST - 2) * (Q + 1) <= 63, "vmcnt is 6 bits");
+  auto wait_stages = [&](auto n) __attribute__((always_inline)) {
+    constexpr int N = decltype(n)::value;
+    if (REM && wave < REM) wait_vms<N * (Q + 1)>(); else wait_vms<N * Q>();
+  };
   const char* gsrc[NDMA];
   long kst[NDMA];
 #pragma unroll
@@ -209,13 +214,15 @@ __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch
     }
   auto ktile = [&](int kt, auto dma) __attribute__((always_inline)) {
     constexpr bool DMA = decltype(dma)::value;
-    static_assert(NST == 4, "waits written for a 4-slot ring");
+    static_assert(NST == 4 || NST == 6, "waits written for a 4- or 6-slot ring");
     if constexpr (DMA) {
-      wait_n2();
+      wait_stages(std::integral_constant<int, NST - 2>{});
     } else {
-      const int newer = min(NST - 2, KT - 1 - kt);
-      if (newer >= 2) wait_n2();
-      else if (newer == 1) wait_n1();
+      const int newer = min(NST - 2, KT - 1 - kt);           // tail: stages younger than this K-tile's still in flight
+      if (NST == 6 && newer >= 4) wait_stages(std::integral_constant<int, NST == 6 ? 4 : 2>{});
+      else if (NST == 6 && newer == 3) wait_stages(std::integral_constant<int, NST == 6 ? 3 : 2>{});
+      else if (newer >= 2) wait_stages(std::integral_constant<int, 2>{});
+      else if (newer == 1) wait_stages(std::integral_constant<int, 1>{});
       else wait_vms<0>();
     }
     __builtin_amdgcn_s_barrier();
@@ -973,7 +980,9 @@ hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s) {
   const int tilesM = (a.M + 127) / 128, tilesN = a.N / 288;
   H3SBatch b{};
   b.p[0] = a; b.n = 1;
-  hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 3, false>), dim3(tilesM * tilesN, 1), dim3(768), 0, s, b, tilesM, tilesN);
+  static const bool deep = [] { const char* e = getenv("TEPOSE_MID_RING6"); return e ? atoi(e) != 0 : true; }();   // A/B: 4-slot ring
+  if (deep) hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 3, false, 6>), dim3(tilesM * tilesN, 1), dim3(768), 0, s, b, tilesM, tilesN);
+  else hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 3, false>), dim3(tilesM * tilesN, 1), dim3(768), 0, s, b, tilesM, tilesN);
   return hipGetLastError();
 }
 

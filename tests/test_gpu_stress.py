@@ -180,3 +180,53 @@ def test_single_accumulator_gemm_persistent_tiles_against_fp64(monkeypatch):
         lib.tepose_gemm_h3_f32(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr() if use_bias else None, C2.data_ptr(), ldc,
                                M, N, K, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         assert torch.equal(C[:, :N], C2[:, :N])                             # deterministic
+
+
+def test_persistent_split_gemm_is_bitwise_repeatable_next_to_a_memory_and_mfma_heavy_stream(monkeypatch):
+    """The persistent plain product (csrc/gemm_h3s.hip, gemm_h3s_persist_kernel) lets a finished tile's 32 stores per wave stay
+    in flight under the next tile's first K-tiles: `s_waitcnt vmcnt(2 Q + 32)` is only correct if memory instructions retire
+    from the counter in ISSUE order.  That is the documented behaviour of this part (MI355X_MICROARCH.md, "s_waitcnt": "Loads,
+    stores, atomics and LDS-DMA count together, in issue order (flat_* excepted ...)"; the kernel issues global_load_lds and
+    global_store only -- checked in the ISA), and this test is the empirical side: a violation would show as a K-tile
+    computed on a stage that has not landed, timing-dependent.  So: the kernel 200 times on shapes whose tile walk mixes full tiles (stores overlapped)
+    with edge tiles (drained path) and leaves ntiles % 256 != 0, while a second stream keeps HBM (1 GB copies) and the matrix
+    pipes (a bf16 GEMM) busy; every result must equal the first bit for bit, and the first must match fp64."""
+    from tepose_amd import _lib
+    lib = _lib.load()
+    monkeypatch.setenv('TEPOSE_H3S', '1')
+    g = torch.Generator(device='cuda').manual_seed(21)
+    side = torch.cuda.Stream()
+    big_a = torch.empty(256 << 20, dtype=torch.float32, device='cuda')        # 1 GB
+    big_b = torch.empty_like(big_a)
+    ma = torch.randn(4096, 4096, device='cuda', dtype=torch.bfloat16)
+    mb = torch.randn(4096, 4096, device='cuda', dtype=torch.bfloat16)
+    # (M, N, K): 41 x 13 = 533 tiles, last row and column of tiles partial, 2-3 tiles per workgroup in full / edge order
+    # mixes; 34 x 9 = 306 full tiles (50 workgroups take a second one); 300 full tiles with a short K (8 K-tiles: the
+    # smallest overlapped walk)
+    cases = [(10340, 3132, 1024, 140), (8704, 2304, 2144 // 32 * 32, 60), (6400, 3072, 128, 200)]
+    for M, N, K, reps in cases:
+        A = torch.randn(M, K, device='cuda', generator=g) * 3.0
+        W = torch.randn(N, K, device='cuda', generator=g) * 0.05
+        b = torch.randn(N, device='cuda', generator=g)
+        ws = torch.empty(lib.tepose_gemm_h3_workspace_bytes(M, N, K), dtype=torch.uint8, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            C = torch.full((M, N), float('nan'), device='cuda')
+            assert lib.tepose_gemm_h3_f32(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), C.data_ptr(), N, M, N, K,
+                                          ws.data_ptr(), ws.numel(), st) == 0
+            return C
+        first = run()
+        ref = A.double() @ W.double().t() + b.double()
+        mag = (A.double().abs() @ W.double().abs().t()).max().item() + 1.0
+        assert (first.double() - ref).abs().max().item() < 3e-6 * mag
+        del ref
+        bad = 0
+        for i in range(reps):
+            with torch.cuda.stream(side):                    # competing traffic, re-issued so that it overlaps every repeat
+                big_b.copy_(big_a, non_blocking=True)
+                torch.matmul(ma, mb)
+                big_a.copy_(big_b, non_blocking=True)
+            bad += int(not torch.equal(first, run()))
+        torch.cuda.synchronize()
+        assert bad == 0, (M, N, K, bad)

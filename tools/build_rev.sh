@@ -7,6 +7,6 @@ tmp=$(mktemp -d)
 mkdir -p $tmp/tepose_amd/csrc $tmp/include $(dirname $out)
 for f in $(git ls-tree --name-only $rev tepose_amd/csrc/); do git show $rev:$f > $tmp/tepose_amd/csrc/$(basename $f); done
 git show $rev:include/tepose_amd.h > $tmp/include/tepose_amd.h
-(cd $tmp/tepose_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -packed-fp32-ops "$@" -o $out *.hip)
+(cd $tmp/tepose_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -packed-fp32-ops -DTEPOSE_NO_PACKED_FP32=1 "$@" -o $out *.hip)
 rm -rf $tmp
 echo built $out from $rev
