@@ -14,9 +14,14 @@
 
 #include "common.h"
 
+#ifndef TEPOSE_H3S_ABL
+#define TEPOSE_H3S_ABL 0   // timing-only ablations of gemm_h3s_persist_kernel (wrong results): 1 no LDS-DMA after a tile's first three
+#endif                     // stages (the ring keeps real data: operand toggling, hence power, stays realistic), 4 fragment reads
+                           // only in a tile's first K-tile, 8 no C stores
 #ifndef TEPOSE_GRU_ABL
 #define TEPOSE_GRU_ABL 0   // timing-only ablations of the fused GRU step (wrong results): 1 no LDS-DMA, 2 no epilogue loads,
-#endif                     // 4 no epilogue stores, 8 no LDS turn, 16 no MFMA, 64 no epilogue at all.  CAUTION (round 3): every one
+#endif                     // 4 no epilogue stores, 8 no LDS turn, 16 no MFMA, 64 no epilogue at all, 256 no LDS-DMA after a tile's first
+                           // three stages.  CAUTION (round 3): every one but 256
                            // of them also changes the DATA the matrix pipes see (stale LDS, constant states, planes never
                            // written), and these kernels are power-limited: a build whose operands stop toggling clocks 10-25 %
                            // higher, so "no X" overstates the cost of X.
@@ -126,7 +131,8 @@ __device__ __forceinline__ float gs_tanh(float x) {
 // order, cell update in the epilogue, new state out as fp32 and as scaled planes.
 // NST: ring slots (NST - 1 stages requested ahead).  4 where a K-tile carries enough MFMA work to cover a stage's latency; the
 // 128 x 288 tile of mid-size batches (12 waves x 9 MFMAs per K-tile = 0.36 us of matrix work against ~2.5 us from request to
-// landing) was bound by 3 stages / latency = 0.89 us per K-tile: 6 slots (160 KB of LDS exactly), 5 stages ahead (round 3).
+// landing) looked bound by 3 stages / latency = 0.89 us per K-tile; with 6 slots (160 KB of LDS exactly, 5 stages ahead;
+// TEPOSE_MID_RING6=1) it measured 1 % SLOWER (round 3), so request depth is not what limits that shape.
 template <int WMF, int WNT, int NWM, int NWN, bool GRU, int NST = 4>
 __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch, int tilesM, int tilesN) {
   constexpr int NW = NWM * NWN;                           // waves per block: 8, or 12 for the 128 x 288 tile of mid-size batches
@@ -180,9 +186,10 @@ __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch
     kst[q] = ((long)__builtin_amdgcn_readfirstlane((int)(ks >> 32)) << 32) |
              (unsigned)__builtin_amdgcn_readfirstlane((int)ks);
   }
-  auto dma_part = [&](int stage, int q) {
+  auto dma_part = [&](int stage, int q, bool steady = false) {
     if (REM == 0 || q < nd) {
-      if (!(GRU && (TEPOSE_GRU_ABL & 1))) glds16s(gsrc[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
+      // (ablation 1: no LDS-DMA; 256: none after the first NST - 1 stages, so that the ring keeps real operand data)
+      if (!(GRU && ((TEPOSE_GRU_ABL & 1) || ((TEPOSE_GRU_ABL & 256) && steady)))) glds16s(gsrc[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
       gsrc[q] += kst[q];
     }
   };
@@ -248,7 +255,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch
         const int t = i * WNT + j;
 #pragma unroll
         for (; q < (t + 1) * NDMA / (WMF * WNT); ++q)
-          if constexpr (DMA) dma_part(kt + NST - 1, q);
+          if constexpr (DMA) dma_part(kt + NST - 1, q, true);
       }
     // the cross terms after all hi*hi products: consecutive MFMAs never share an accumulator
     if constexpr (!(GRU && (TEPOSE_GRU_ABL & 16))) {
@@ -440,8 +447,8 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int ti
       gsrc[q] = gbase[q] + grow * RB;
     }
   };
-  auto dma_part = [&](int stage, int q) {
-    glds16s(gsrc[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
+  auto dma_part = [&](int stage, int q, bool steady = false) {
+    if (!((TEPOSE_H3S_ABL & 1) && steady)) glds16s(gsrc[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
     gsrc[q] += kst[q];
   };
   const int sx = 16 * (h ^ ((r >> 3) & 1));
@@ -453,6 +460,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int ti
   constexpr int A_LO = HM * RB, W_LO = HN * RB;
   const int KT = a.Kp / HK;
   const bool overlap = KT >= 2 * NST;                     // the store-drain accounting below needs a few K-tiles
+  h16x8 ah[WMF], al[WMF], bh[WNT], bl[WNT];
   const bool vec = (((size_t)a.C | (size_t)a.bias) & 15) == 0 && (a.ldc & 3) == 0;
 
   f32x16 acc[WMF][WNT];
@@ -469,7 +477,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int ti
     }
     __builtin_amdgcn_s_barrier();
     const char* st = lds + (kt % NST) * STAGE;
-    h16x8 ah[WMF], al[WMF], bh[WNT], bl[WNT];
+    if (!(TEPOSE_H3S_ABL & 4) || kt == 0) {
 #pragma unroll
     for (int i = 0; i < WMF; ++i) {
       ah[i] = *(const h16x8*)(st + aoff[i]);
@@ -480,6 +488,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int ti
       bh[j] = *(const h16x8*)(st + boff[j]);
       bl[j] = *(const h16x8*)(st + W_LO + boff[j]);
     }
+    }
     int q = 0;
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
@@ -489,7 +498,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int ti
         const int t = i * WNT + j;
 #pragma unroll
         for (; q < (t + 1) * Q / (WMF * WNT); ++q)
-          if constexpr (DMA) dma_part(kt + NST - 1, q);
+          if constexpr (DMA) dma_part(kt + NST - 1, q, true);
       }
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
@@ -572,6 +581,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int ti
             f32x4p v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = acc[i][j][4 * g + c] * rs[i] + bq[g][c];
+            if ((TEPOSE_H3S_ABL & 8) && v[0] + v[1] != 1234.5678f) continue;
             *(f32x4p*)(c0 + (long)i * 32 * a.ldc + j * 32 + 8 * g) = v;
           }
       }
@@ -980,7 +990,7 @@ hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s) {
   const int tilesM = (a.M + 127) / 128, tilesN = a.N / 288;
   H3SBatch b{};
   b.p[0] = a; b.n = 1;
-  static const bool deep = [] { const char* e = getenv("TEPOSE_MID_RING6"); return e ? atoi(e) != 0 : true; }();   // A/B: 4-slot ring
+  static const bool deep = [] { const char* e = getenv("TEPOSE_MID_RING6"); return e ? atoi(e) != 0 : false; }();   // A/B (round 3): 0.577 vs 0.570 ms per B = 64 forward -- the 4-slot ring stays
   if (deep) hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 3, false, 6>), dim3(tilesM * tilesN, 1), dim3(768), 0, s, b, tilesM, tilesN);
   else hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 3, false>), dim3(tilesM * tilesN, 1), dim3(768), 0, s, b, tilesM, tilesN);
   return hipGetLastError();
