@@ -16,7 +16,7 @@ m = re.findall(r'B=\s*\d+ T=\s*\d+\s+[\d.]+ ms/forward\s+[\d.]+ windows/s', log)
 tr = glob.glob('gpurun_out/%s_%s_trace/*/*kernel_trace.csv' % (tag, shape))[0]
 rows = list(csv.DictReader(open(tr)))
 nf = max(sum(1 for r in rows if 'smpl_joints_kernel' in r['Kernel_Name']), 1)          # one per forward
-print('# rocprofv3 --kernel-trace of `python3 tools/sweep.py %s` (%d forwards, shipped binary, round 2 final): %s'
+print('# rocprofv3 --kernel-trace of `python3 tools/sweep.py %s` (%d forwards, shipped binary, round 3 final): %s'
       % (shape, nf, m[-1] if m else ''))
 trace(tr)
 for name, unit in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
