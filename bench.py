@@ -225,6 +225,9 @@ def main():
                     help='run the process-group path at world size 1 too: init_process_group (nccl = RCCL), blob broadcast, '
                          'all_reduce, gather -- so that the collectives of the N-GPU run execute on a 1-GPU box')
     args = ap.parse_args()
+    # the host driver of this pool only supports dmabuf IPC (RCCL and cross-process tensor sharing fail without it); the runtime
+    # reads the variable when HIP initialises, so it has to be in the environment before the first torch.cuda call
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves.  This process has not touched the GPU
@@ -252,7 +255,6 @@ def main():
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]), RANK='0', WORLD_SIZE='1',
                               LOCAL_RANK='0')
             sk.close()
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:

@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='world size 1: still initialise the process group (nccl = RCCL) and '
                     'run the barrier / all_reduce / gathers, so that the N-GPU collectives execute on a 1-GPU box')
     args = ap.parse_args()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the first HIP call (dmabuf IPC only on this pool)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # GPU-free parent: the ranks are children of the stock launcher (never an exec of a process that touched HIP)
         import socket
@@ -65,7 +66,6 @@ def main():
             sk = socket.socket(); sk.bind(('127.0.0.1', 0))
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
             sk.close()
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group(args.backend, device_id=dev) if args.backend == 'nccl' else dist.init_process_group(args.backend)
     T = args.seqlen
     smpl_np = synth.synthetic_smpl(0)
