@@ -378,6 +378,13 @@ def main():
                                    'kernel': 'gemm_h3s_persist_kernel<0> (single-accumulator split GEMM, 256x256 tiles walked by 256 persistent workgroups; layer-0 input projection, M=%d N=9216 K=2133)'
                                              % (B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n,
+                                   # what the chip sustains for this kernel's MFMA sequence with NO operand traffic (the same
+                                   # instruction stream minus LDS-DMA, fragment reads and stores, real operand data in the ring):
+                                   # 9.55 ms at 1.68 GHz, 92 % busy -- a committed measurement, not taken in this run
+                                   'power_limited_ceiling': {'frac_of_peak': 5.153e12 / 9.55e-3 / 1e12 / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS),
+                                                             'achieved_over_ceiling': (ach / (5.153e12 / 9.55e-3 / 1e12)) if (B, T) == (8192, 16) else None,
+                                                             'source': 'profiles/r03_projection_ablation.txt (tools/h3s_ablate.sh, SQ counter pass; '
+                                                                       'constant, not collected in this run)'},
                                    'note': 'achieved = algorithmic fp32-equivalent FLOP/s; the kernel issues %d fp16 MFMAs '
                                            'per product (hi*hi, hi*lo, lo*hi; fp32 accumulate), so peak = dense fp16 '
                                            'MFMA %.1f / %d; executed MFMA rate = %.0f TFLOP/s'
