@@ -72,6 +72,15 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes);
  * here, e.g. rank 0 -> all ranks over RCCL).                                          */
 int tepose_adopt_blob(tepose_model* m);
 
+/* Broadcast less: the blob interleaves the fp32 sections (packed matrices, biases, SMPL tables, the collapsed maps, the
+ * header) with the fp16 hi / lo plane copies the split-precision kernels read, and every plane is a function of the fp32
+ * section next to it.  tepose_fp32_ranges fills offsets[] / sizes[] (bytes, at most `cap` entries, returns the count or a
+ * negative error) with the ranges a sender has to transmit -- 276 of 770 MB at n_layers = 2 / hidden = 1024; the receiver
+ * copies them into a zeroed blob of tepose_packed_bytes(), registers it with tepose_set_blob and calls tepose_derive_planes,
+ * which rebuilds every plane (bit-identical to the sender's) and then adopts the blob as tepose_adopt_blob does.            */
+int tepose_fp32_ranges(const tepose_model* m, size_t* offsets, size_t* sizes, int cap);
+int tepose_derive_planes(tepose_model* m, void* stream);
+
 /* Pack encoder weights.  `w` = HOST array of DEVICE pointers in the reference's
  * state-dict order, n_w = 8*L + 16*L... precisely:
  *   for l in 0..L-1:  gru_fwd.{weight_ih,weight_hh,bias_ih,bias_hh}_l{l}

@@ -22,6 +22,7 @@ SYMBOLS = [
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
     'tepose_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
+    'tepose_fp32_ranges', 'tepose_derive_planes',
 ]
 
 _lib = None
@@ -102,6 +103,8 @@ def load():
     lib.tepose_gemm_h3_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.tepose_gemm_h3_workspace_bytes.restype = c_size_t
     lib.tepose_gemm_h3_f32.argtypes = [fp, c_long, fp, c_long, fp, fp, c_long, c_int, c_int, c_int, fp, c_size_t, c_void_p]
+    lib.tepose_fp32_ranges.argtypes = [c_void_p, POINTER(c_size_t), POINTER(c_size_t), c_int]
+    lib.tepose_derive_planes.argtypes = [c_void_p, c_void_p]
     lib.tepose_status.argtypes = [c_void_p, c_void_p]
     lib.tepose_status_peek.argtypes = [c_void_p]
     lib.tepose_set_persistent.argtypes = [c_void_p, c_int]

@@ -754,6 +754,89 @@ int tepose_adopt_blob(tepose_model* m) {
   return 0;
 }
 
+// ---- broadcast less (round 3): every hi / lo plane in the blob is a function of the fp32 sections next to it --------------
+// The blob interleaves source-of-truth fp32 sections (packed matrices, biases, SMPL tables, the fp64-derived collapsed maps
+// rounded to fp32, the header) with the plane copies the split-precision kernels read.  tepose_fp32_ranges lists the former as
+// byte ranges; a rank that received only those (276 of 770 MB at L = 2 / H = 1024) rebuilds the rest with tepose_derive_planes,
+// which also does what tepose_adopt_blob does.  The planes come out bit-identical to the packing rank's
+// (tests/test_gpu_multirank.py::test_planes_derived_from_the_fp32_sections_are_bit_identical).
+int tepose_fp32_ranges(const tepose_model* m, size_t* offsets, size_t* sizes, int cap) {
+  if (!m || !offsets || !sizes) return TEPOSE_E_ARG;
+  size_t r[6][2];
+  int n = 0;
+  const size_t enc_planes = m->kind == 0 ? m->wih0_p : m->w1a;   // VIBE handles keep no encoder planes
+  r[n][0] = 0; r[n][1] = enc_planes; ++n;                          // header + encoder fp32
+  if (m->kind == 0) { r[n][0] = m->w1a; r[n][1] = m->w1a_p; ++n; } else r[0][1] = m->w1a_p;   // regressor + SMPL fp32
+  r[n][0] = m->mf; r[n][1] = m->mf_p; ++n;
+  if (m->kind == 0) {
+    r[n][0] = m->k0; r[n][1] = m->mt_p; ++n;                       // k0 | mt
+    r[n][0] = m->kt; r[n][1] = m->blob_floats; ++n;
+  } else {
+    r[n][0] = m->k0; r[n][1] = m->blob_floats; ++n;
+  }
+  if (n > cap) return TEPOSE_E_ARG;
+  for (int i = 0; i < n; ++i) { offsets[i] = r[i][0] * sizeof(float); sizes[i] = (r[i][1] - r[i][0]) * sizeof(float); }
+  return n;
+}
+
+int tepose_derive_planes(tepose_model* m, void* stream) {
+  if (!m) return TEPOSE_E_ARG;
+  if (!m->blob) return TEPOSE_E_STATE;
+  int rc = tepose_adopt_blob(m);                 // header check, packed / range / collapse flags
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* B = m->blob;
+  const int Hp = m->Hp, L = m->L;
+  const int n128 = round_up(3 * Hp, 128);
+  // blocked planes of a packed [rows][Kp] matrix whose plane copy has R >= rows rows (zero beyond)
+  auto planes_rows = [&](size_t src, int rows, int Kp, size_t dst, int R) -> int {
+    CK(launch_fill(B + dst, (size_t)R * Kp, 0.f, s));
+    half_t* hi = (half_t*)(B + dst);
+    return (int)launch_split_planes(B + src, Kp, rows, Kp, Kp, R, hi, hi + (size_t)R * Kp, s);
+  };
+  if (m->kind == 0 && m->enc_packed) {
+    CK((hipError_t)planes_of(B + m->wih0, round_up(9 * Hp, 128), kInputP, B + m->wih0_p, s));
+    CK((hipError_t)scaled_planes_of(B + m->wih0, 9 * Hp, kInputP, B + m->wih0_s, round_up(9 * Hp, 256), B + m->wih0_scale,
+                                    &m->w0_scale, s));
+    for (int l = 0; l < L; ++l) {
+      DirW* dirs[3] = {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]};
+      for (int k = 0; k < 3; ++k) {
+        DirW* d = dirs[k];
+        const int Kp = k == 0 ? Hp : 2 * Hp;
+        if (l > 0) {
+          CK((hipError_t)planes_of(B + d->wih, n128, Kp, B + d->wih_p, s));
+          CK((hipError_t)scaled_planes_of(B + d->wih, 3 * Hp, Kp, B + d->wih_s, round_up(3 * Hp, 256), B + d->scales,
+                                          &d->wih_scale, s));
+        }
+        CK((hipError_t)planes_rows(d->whh, 3 * Hp, Hp, d->whh_p, n128));
+        CK((hipError_t)scaled_planes_of(B + d->whh, 3 * Hp, Hp, B + d->whh_s, round_up(3 * Hp, 384), B + d->scales + 1,
+                                        &d->whh_scale, s));
+      }
+    }
+    CK((hipError_t)planes_of(B + m->wlf, kFeat, Hp, B + m->wlf_p, s));
+    CK((hipError_t)planes_of(B + m->wlr, kFeat, 2 * Hp, B + m->wlr_p, s));
+    {  // [W_lf | W_lr] side by side along K
+      half_t* hi = (half_t*)(B + m->wlfr_p);
+      half_t* lo = hi + (size_t)kFeat * 3 * Hp;
+      const long kst = (long)kFeat * 32;
+      CK(launch_split_planes(B + m->wlf, Hp, kFeat, Hp, Hp, kFeat, hi, lo, s));
+      CK(launch_split_planes(B + m->wlr, 2 * Hp, kFeat, 2 * Hp, 2 * Hp, kFeat, hi + (size_t)(Hp / 32) * kst,
+                             lo + (size_t)(Hp / 32) * kst, s));
+    }
+    if (m->tail_collapsed) CK((hipError_t)planes_of(B + m->mt, 256, 3 * Hp, B + m->mt_p, s));
+  }
+  if (m->reg_packed) {
+    CK((hipError_t)planes_of(B + m->w1a, 1024, kFeat, B + m->w1a_p, s));
+    CK((hipError_t)planes_of(B + m->w1b, 1024, kState, B + m->w1b_p, s));
+    CK((hipError_t)planes_of(B + m->w2, 1024, 1024, B + m->w2_p, s));
+    CK((hipError_t)planes_of(B + m->wdec, 256, 1024, B + m->wdec_p, s));
+    if (m->reg_collapsed) CK((hipError_t)planes_of(B + m->mf, 256, kFeat, B + m->mf_p, s));
+  }
+  if (m->smpl_packed) CK((hipError_t)planes_of(B + m->smpl.blendW, kBlendN, kBlendK, B + m->blendW_p, s));
+  CK(hipStreamSynchronize(s));
+  return 0;
+}
+
 int tepose_pack_vibe_encoder(tepose_model* m, const float* const* w, int n_w, void* stream) {
   if (!m || !w || m->kind != 1) return TEPOSE_E_ARG;
   if (!m->blob) return TEPOSE_E_STATE;

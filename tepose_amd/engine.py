@@ -101,14 +101,28 @@ class Engine:
             self._ws = None
             self._jreg_cache = {}
 
-    def adopt_blob(self, blob, model):
+    def fp32_ranges(self):
+        """(offset, size) byte ranges of the blob that a sender has to transmit: the fp32 sections and the header; every
+        hi / lo plane is re-derived from them by the receiver (adopt_blob(..., derive=True))."""
+        from ctypes import c_size_t
+        off, size = (c_size_t * 8)(), (c_size_t * 8)()
+        n = self.lib.tepose_fp32_ranges(self.handle, off, size, 8)
+        if n < 0:
+            _lib.check(n, 'tepose_fp32_ranges')
+        return [(int(off[i]), int(size[i])) for i in range(n)]
+
+    def adopt_blob(self, blob, model, derive=False):
         """Use a packed blob produced by another Engine of the same (n_layers, hidden) --
         e.g. received through an RCCL broadcast from rank 0 -- instead of packing `model`'s
-        own parameters, which are then ignored until one of them changes."""
+        own parameters, which are then ignored until one of them changes.  derive=True: only the
+        fp32_ranges() of `blob` are valid (the rest zero); the planes are rebuilt here."""
         assert blob.dtype == torch.uint8 and blob.numel() >= self.packed_bytes
         self.blob, self.device = blob, blob.device
         _lib.check(self.lib.tepose_set_blob(self.handle, blob.data_ptr(), blob.numel()), 'tepose_set_blob')
-        _lib.check(self.lib.tepose_adopt_blob(self.handle), 'tepose_adopt_blob')
+        if derive:
+            _lib.check(self.lib.tepose_derive_planes(self.handle, self._stream()), 'tepose_derive_planes')
+        else:
+            _lib.check(self.lib.tepose_adopt_blob(self.handle), 'tepose_adopt_blob')
         self.packed_generation += 1
         self._sig_enc = _sig(self._enc_tensors(model.encoder))
         self._sig_reg = _sig(self._reg_tensors(model.regressor))

@@ -29,6 +29,7 @@ def test_bench_starts_its_own_ranks_and_they_agree():
     assert r['n_gpus'] == 2 and r['steps'] == steps and r['scaling'] == 'weak'
     assert r['ranks_agree'] is True                      # every rank's probe forward on the broadcast blob
     assert r['weight_broadcast_ms'] > 0 and r['weight_blob_MB'] > 100
+    assert r['weight_broadcast_MB'] < 0.45 * r['weight_blob_MB']          # only the fp32 sections travel; planes re-derived per rank
     assert len(r['per_rank']) == 2
     assert sorted(int(x[0]) for x in r['per_rank']) == [0, 1]
     assert sum(int(x[2]) for x in r['per_rank']) == 2 * B * steps          # N * B windows per step counted
@@ -49,7 +50,7 @@ def test_rccl_path_executes_at_world_size_one():
     a copy of the broadcast blob and must reproduce rank 0's probe forward bit for bit."""
     r = _run(['bench.py', '--force-dist', '--batch', '128', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extra'])
     assert r['n_gpus'] == 1 and r['dist_backend'] == 'nccl'
-    assert r['weight_broadcast_ms'] > 0 and r['weight_blob_MB'] > 100
+    assert r['weight_broadcast_ms'] > 0 and r['weight_blob_MB'] > 100 and r['weight_broadcast_MB'] < 0.45 * r['weight_blob_MB']
     assert r['adopted_blob_matches'] is True and r['ranks_agree'] is True
     assert len(r['per_rank']) == 1 and int(r['per_rank'][0][2]) == 128 * 2 and r['per_rank'][0][3] == 1.0
     assert r['outputs_finite'] is True
@@ -126,6 +127,37 @@ def test_adopt_blob_rejects_a_foreign_blob_and_accepts_its_own():
     junk = torch.randint(0, 255, (eng.packed_bytes,), dtype=torch.uint8, device='cuda')
     assert lib.tepose_set_blob(eng.handle, junk.data_ptr(), junk.numel()) == 0
     assert lib.tepose_adopt_blob(eng.handle) == -4
+
+
+@pytest.mark.parametrize('L,H', [(2, 128), (1, 64), (2, 1024)])
+def test_planes_derived_from_the_fp32_sections_are_bit_identical(L, H):
+    """Broadcast less: a receiver that gets only the blob's fp32 ranges (tepose_fp32_ranges: header, packed
+    matrices, tables, collapsed maps) and rebuilds the hi / lo planes itself (tepose_derive_planes) must end up with the SAME
+    BYTES as the packing rank's blob, and the same forward."""
+    import torch
+    from tepose_amd import synth
+    from tepose_amd.testing import build_model
+    smpl_np = synth.synthetic_smpl(0)
+    model, _, _ = build_model(L, H, seed=5, device='cuda', smpl_np=smpl_np)
+    x = torch.from_numpy(synth.synthetic_windows(70, 4, 3)).cuda()        # split-precision path (planes in use)
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    with torch.no_grad():
+        ref = model(x, J_regressor=J)[0]
+    src = model._engine.blob
+    ranges = model._engine.fp32_ranges()
+    sent = sum(n for _, n in ranges)
+    assert 0 < sent < (0.4 if H == 1024 else 0.5) * src.numel()             # under half of the blob travels (36 % at the published size)
+    twin, _, _ = build_model(L, H, seed=77, device='cuda', smpl_np=smpl_np)  # other weights: must not matter
+    blob = torch.zeros_like(src)
+    for off, n in ranges:
+        blob[off:off + n] = src[off:off + n]
+    twin._engine.adopt_blob(blob, twin, derive=True)
+    torch.cuda.synchronize()
+    assert torch.equal(blob, src)
+    with torch.no_grad():
+        out = twin(x, J_regressor=J)[0]
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
 
 
 def test_two_processes_running_persistent_kernels_stay_bit_identical():
