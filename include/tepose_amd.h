@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - every function returns 0 on success, a positive hipError_t, or a negative
- *     TEPOSE_E_* argument error; nothing throws, aborts or synchronises the device;
+ *     TEPOSE_E_* error; nothing throws or aborts; no forward entry point synchronises
+ *     (tepose_status does, on the stream it is given: that is its purpose; the pack /
+ *     adopt / derive functions synchronise at set-up time);
  *   - all `const float*` / `float*` arguments are DEVICE pointers owned by the caller
  *     (fp32, contiguous unless a stride is given); the library never frees them and keeps
  *     none beyond the call, except the packed-weight blob registered in a model handle;
