@@ -48,6 +48,8 @@ struct tepose_model {
   float w0_scale = 1.f;                         // host copy of blob[wih0_scale]
   bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
   bool gru_single_acc = true;                   // large batches: layer >= 1 projections and GRU steps on it too
+  int mfma16 = 0;                               // TEPOSE_MFMA16 bit mask: 1 = plain scaled-plane products, 2 = fused GRU step on
+                                                // v_mfma_f32_16x16x32_f16 (gemm_h3s16.hip) instead of 32x32x16
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
@@ -516,6 +518,8 @@ static void read_env_knobs(tepose_model* m) {
   m->g0_single_acc = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
   m->gru_single_acc = !(e && atoi(e) == 0);
+  e = getenv("TEPOSE_MFMA16");                      // MFMA shape of the scaled-plane kernels (bit 1: plain products, bit 2: GRU step)
+  m->mfma16 = e ? atoi(e) : 0;
   e = getenv("TEPOSE_COLLAPSE_REGRESSOR");          // 0: the regressor's FC loop is always run as a loop
   m->collapse_env = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
@@ -1178,6 +1182,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       const half_t* sh = (const half_t*)(Bl + w_s);
       H3SArgs a{v.hi, v.lo, v.kst, sh, sh + r256 * K, (long)r256 * 16, K, out, (long)H3, Bl + bias,
                 1.f / (kStateScale * w_scale), M, H3};
+      a.shape16 = m->mfma16 & 1;
       return (int)launch_gemm_h3s(a, s);
     }
     const EncWs::View v = w.view(in);
@@ -1552,6 +1557,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       const half_t* sh = (const half_t*)(Bl + m->wih0_s);
       H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
                 Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0, w.rs};
+      a.shape16 = m->mfma16 & 1;
       if (g0mid) CK(launch_gemm_h3s_mid(a, s));
       else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {
@@ -1938,7 +1944,8 @@ int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const
   // operand scales for the ranges of tools/h3_loop.py / h3_bench.py and tests/test_gpu_stress.py
   const char* pe = getenv("TEPOSE_H3S");
   if (pe && atoi(pe) && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
-    CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, bias));
+    CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, bias,
+                           atoi(pe) == 2));                     // TEPOSE_H3S=2: the 16x16x32 MFMA shape (gemm_h3s16.hip)
     return 0;
   }
   CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream));

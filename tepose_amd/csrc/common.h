@@ -298,10 +298,13 @@ struct H3SArgs {
   float inv_scale;                       // 1 / (pA * pW)
   int M, N;
   const float* row_scale;                // optional [M], as H3Args::row_scale (then pA = 1)
+  int shape16;                           // 1: v_mfma_f32_16x16x32_f16 instead of 32x32x16 (gemm_h3s16.hip; needs Kp % 32 == 0)
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // tag 0: the layer-0 projection (own kernel symbol for profiles)                                // state planes a GRU step writes
 hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
+bool gemm_h3s16_ok(const H3SArgs& a);
+hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag);   // gemm_h3s16.hip
 bool gemm_h3s_mid_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s);   // 128 x 288 tiles, N % 288 == 0
 hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
@@ -309,6 +312,7 @@ hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, in
 hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);
 size_t gemm_h3s_ws_bytes(int M, int N, int K);
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
-                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias = nullptr);
+                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias = nullptr,
+                               int shape16 = 0);
 
 }  // namespace tepose

@@ -971,6 +971,7 @@ hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag) {
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   H3SBatch b{};
   b.p[0] = a; b.n = 1;
+  if (h3s_persist() && a.shape16 && gemm_h3s16_ok(a)) return launch_gemm_h3s16(a, s, tag);
   if (h3s_persist()) {
     const int nt = tilesM * tilesN;
     if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
@@ -1029,7 +1030,7 @@ size_t gemm_h3s_ws_bytes(int M, int N, int K) {
 
 // test / bench entry: fp32 A[M,K], W[N,K] (no bias) -> scaled planes in ws -> C; pA / pW: power-of-two operand scales
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
-                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias) {
+                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias, int shape16) {
   const int Kp = round_up(K, 16), Np = round_up(N, 256);
   char* p = (char*)ws;
   _Float16* Ah = (_Float16*)p; p += align_up((size_t)M * Kp * 2, 256);
@@ -1041,6 +1042,7 @@ hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ld
   if ((e = launch_split_planes16(A, lda, M, K, Kp, M, pA, Ah, Al, s)) != hipSuccess) return e;
   if ((e = launch_split_planes16(W, ldw, N, K, Kp, Np, pW, Wh, Wl, s)) != hipSuccess) return e;
   H3SArgs a{Ah, Al, (long)M * 16, Wh, Wl, (long)Np * 16, Kp, C, ldc, bias, 1.f / (pA * pW), M, N};
+  a.shape16 = shape16;
   return launch_gemm_h3s(a, s);
 }
 

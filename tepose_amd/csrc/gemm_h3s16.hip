@@ -1,0 +1,328 @@
+// The persistent single-accumulator split GEMM of gemm_h3s.hip on the OTHER fp16 MFMA shape: v_mfma_f32_16x16x32_f16.
+//
+// Why a second shape: these kernels are power-limited (the chip holds 1.65-1.8 GHz of 2.4 under them), and the clock the chip
+// holds depends on the MFMA shape -- MI355X_MICROARCH.md "DVFS give-back" item 7 measured 1.12-1.15 x the FLOP/s for 16x16x32
+// over 32x32x16 at equal cycles per FLOP, on random data, operands re-read from LDS.  Same output tile per wave (64 x 128),
+// same planes ([K/16][R][16] scaled hi / lo, gemm_h3s.hip), same ring bytes, same three products per k (hi*hi, lo*hi, hi*lo).
+//
+// What the shape changes: one MFMA spans 32 k, i.e. TWO K-tiles of the 16-wide plane format.  Lane group g = lane >> 4 of an
+// operand holds 8 consecutive k: g = 0, 1 are the two 16-byte slots of a row in stage s, g = 2, 3 those of the same row in
+// stage s + 1 (the same assignment on both operands, so the products pair up).  The K loop therefore walks PAIRS of stages:
+//   wait (pair p landed) | barrier | fragment reads and 72 MFMAs (W side in quarters) | barrier B' | 24 MFMAs with the requests of pair p + 2 between
+// The second barrier is what keeps the request depth: once every wave holds pair p's fragments in registers its two ring slots
+// are free, so pair p + 2 is requested DURING interval p and has until barrier p + 2 to land -- up to 4 stages (128 KB) in
+// flight against the 3 of the 32x32x16 kernel (whose "two K-tiles per barrier" variant lost 3.5 % by requesting only one pair
+// ahead).  Barriers per k: the same (2 per 32).
+// C layout of the transposed product (W fragment = the MFMA's row operand): lane (t = lane & 15, g) owns 4 consecutive columns
+// 4 g .. 4 g + 3 of row t of a 16 x 16 tile = one 16-byte store per tile, 32 per wave as before (vmcnt accounting unchanged).
+#include <type_traits>
+
+#include "common.h"
+
+#ifndef TEPOSE_S16_STAMPS
+#define TEPOSE_S16_STAMPS 0   // diagnostic builds only (tools/s16_stamps.py): wave 0 of workgroup 0 stamps s_memtime at the phases
+#endif                        // of its pair steps into a buffer of its own; the shipped kernel executes no stamp
+
+namespace tepose {
+
+#if TEPOSE_S16_STAMPS
+__device__ unsigned long long tepose_s16_stamp_buf[8192];
+#endif
+
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8q __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16q(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmq() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void h3s16_tile_of_block(int bid, int nwg, int tilesM, int tilesN, int& tm, int& tn) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  constexpr int GM = 4;
+  const int group = lin / (GM * tilesN), rem = lin - group * GM * tilesN;
+  const int gm = min(GM, tilesM - group * GM);
+  tm = group * GM + rem % gm;
+  tn = rem / gm;
+}
+
+template <int TAG>
+__global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int tilesM, int tilesN) {
+  constexpr int NWN = 2, NST = 4, MT = 4, NT = 8;         // 4 x 2 waves of 64 x 128 = 4 x 8 MFMA tiles of 16 x 16
+  constexpr int HM = 256, HN = 256, HK = 16, RB = HK * 2, RPI = 1024 / RB;
+  constexpr int STAGE = (2 * HM + 2 * HN) * RB, TOT = STAGE / 1024, Q = TOT / 8;
+  constexpr int PQ = 2 * Q;                               // LDS-DMA instructions per wave and pair of stages
+  constexpr int NSTORE = MT * NT;                         // 16-byte stores per wave and tile
+  static_assert(TOT % 8 == 0 && NST * STAGE + HN * 4 <= 160 * 1024 && 2 * PQ + NSTORE <= 63, "ring / vmcnt budget");
+  // ONE __shared__ object (ring + bias row), as in gemm_h3s_persist_kernel
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE + HN * 4];
+  float* sbias = (float*)(lds + NST * STAGE);
+  const int ntiles = tilesM * tilesN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int t = lane & 15, g = lane >> 4;
+  // Register budget: 128 accumulators + 64 fragment registers leave ~60 for everything else, and hipcc hoists every
+  // lane-derived address of the tile set-up and of the epilogue out of the K loop, where they stay live.  Those two places
+  // derive what they need from an opaque copy of the lane number instead (one asm statement: nothing to hoist).
+  auto fresh_lane = [&]() __attribute__((always_inline)) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  // A wave's LDS-DMA instructions each move 32 whole rows of one plane, so the plane (and its K stride) is wave-uniform:
+  // base pointers and K positions live in SGPRs (advanced by scalar adds), a lane keeps one 32-bit byte offset per instruction
+  const int i0 = wave * Q;
+  bool isA[Q];
+  int lrow0[Q];
+  long kst[Q];
+  const char* pbase[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    int ri = (i0 + q) * RPI;                              // first row of the stage image [A_hi | A_lo | W_hi | W_lo]
+    isA[q] = ri < 2 * HM;
+    if (!isA[q]) ri -= 2 * HM;
+    const bool lo = ri >= (isA[q] ? HM : HN);
+    lrow0[q] = lo ? ri - (isA[q] ? HM : HN) : ri;
+    pbase[q] = (const char*)(isA[q] ? (lo ? a.Al : a.Ah) : (lo ? a.Wl : a.Wh));
+    kst[q] = (isA[q] ? a.a_kst : a.w_kst) * 2;
+  }
+  const char* sbase[Q];                                   // SGPR: plane base + K position
+  unsigned voff[Q];                                       // VGPR: this lane's row * 32 + its 16-byte half
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int tile) {
+    int tm, tn;
+    h3s16_tile_of_block(tile, ntiles, tilesM, tilesN, tm, tn);
+    m0 = tm * HM; n0 = tn * HN;
+    const int l = fresh_lane();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int grow = isA[q] ? min(m0 + lrow0[q] + l / 2, a.M - 1) : n0 + lrow0[q] + l / 2;
+      voff[q] = (unsigned)grow * RB + 16u * (l & 1);
+      sbase[q] = pbase[q];
+    }
+  };
+  auto dma_part = [&](int stage, int q) {
+    // (the K position passes through an opaque SGPR pair: otherwise loop strength reduction folds base + offset back into one
+    // 64-bit VGPR pointer per instruction that it advances with VALU adds -- 16 more VGPRs, and the kernel spills)
+    unsigned long long sb = (unsigned long long)sbase[q];
+    asm volatile("" : "+s"(sb));
+    glds16q((const char*)sb + voff[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
+    sbase[q] = (const char*)(sb + (unsigned long long)kst[q]);
+  };
+  auto request_pair = [&](int p) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) dma_part(2 * p + s, q);
+  };
+  // fragment addresses: row (tile row t) * 32 + 16 * (slot ^ swz(row)), slot = g & 1, stage of the pair = g >> 1; the tile
+  // origins are multiples of 16 rows, so the swizzle bit is that of t
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const unsigned sx = 16u * ((g & 1) ^ ((t >> 3) & 1)) + (unsigned)(g >> 1) * STAGE;
+  const unsigned abase = lds0 + (unsigned)(wm * 16 * MT + t) * RB + sx;
+  const unsigned bbase = lds0 + 2 * HM * RB + (unsigned)(wn * 16 * NT + t) * RB + sx;
+  constexpr int A_LO = HM * RB, W_LO = HN * RB;
+  const int KT = a.Kp / HK, NP = KT / 2;                  // the launcher guarantees an even KT >= 4
+  const bool overlap = NP >= 6;
+  const bool vec = (((size_t)a.C | (size_t)a.bias) & 15) == 0 && (a.ldc & 3) == 0;
+
+  f32x4q acc[MT][NT];
+#if TEPOSE_S16_STAMPS
+  int stamp_n = 0;
+  auto stamp = [&](int id) __attribute__((always_inline)) {
+    if (blockIdx.x == 0 && wave == 0 && stamp_n < 8190) {
+      const unsigned long long tm = __builtin_amdgcn_s_memtime();
+      if (lane == 0) tepose_s16_stamp_buf[stamp_n] = (tm << 8) | (unsigned)id;
+      ++stamp_n;
+    }
+  };
+#define STAMP(id) stamp(id)
+#else
+#define STAMP(id)
+#endif
+  // NEWER: LDS-DMA instructions younger than pair p's that may stay in flight (PQ: pair p + 1's; 0 at the last pair);
+  // EXTRA: the previous tile's stores, younger than the first two pairs of this tile
+  auto pairstep = [&](int p, auto dma, auto newer, auto extra) __attribute__((always_inline)) {
+    constexpr bool DMA = decltype(dma)::value;
+    constexpr int NEWER = decltype(newer)::value, EXTRA = decltype(extra)::value;
+    STAMP(1);
+    wait_vmq<NEWER + EXTRA>();
+    STAMP(2);
+    __builtin_amdgcn_s_barrier();
+    STAMP(3);
+    const unsigned par = (unsigned)(p & 1) * 2u * STAGE;
+    const unsigned ab = abase + par, bb = bbase + par;
+    // Register budget (128 accumulators): the W-side fragments come in four quarters of 2 tiles through two alternating
+    // buffers, quarter n + 1 requested before quarter n's MFMAs; the A-side fragments (all 4 row tiles) stay for the pair.
+    // asm reads and counted lgkmcnt waits: the order below is the order executed.
+    h16x8q ah[MT], al[MT], bh[2][2], bl[2][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[i]) : "v"(ab), "n"(i * 16 * RB));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[i]) : "v"(ab), "n"(i * 16 * RB + A_LO));
+    }
+#define TEPOSE_READ_B(QD)                                                                                                     \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                             \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[(QD) & 1][u]) : "v"(bb), "n"((2 * (QD) + u) * 16 * RB));          \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[(QD) & 1][u]) : "v"(bb), "n"((2 * (QD) + u) * 16 * RB + W_LO));   \
+  }
+    TEPOSE_READ_B(0)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int X = qd & 1;
+      if (qd < 3) {
+        TEPOSE_READ_B(qd + 1)
+        asm volatile("s_waitcnt lgkmcnt(4)"
+                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]),
+                       "+v"(bh[X][0]), "+v"(bh[X][1]), "+v"(bl[X][0]), "+v"(bl[X][1])
+                     :
+                     : "memory");
+        STAMP(4 + qd);
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[X][0]), "+v"(bh[X][1]), "+v"(bl[X][0]), "+v"(bl[X][1]) : : "memory");
+        STAMP(7);
+        __builtin_amdgcn_s_barrier();
+        STAMP(8);                      // B': every wave holds what it needs of pair p -> its two slots are free
+      }
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          acc[i][2 * qd + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], ah[i], acc[i][2 * qd + u], 0, 0, 0);
+          const int n = i * 2 + u;
+#pragma unroll
+          for (; q < (n + 1) * PQ / (MT * 2); ++q)
+            if (DMA && qd == 3) dma_part(2 * p + 4 + q / Q, q % Q);
+        }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          acc[i][2 * qd + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[X][u], ah[i], acc[i][2 * qd + u], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          acc[i][2 * qd + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], al[i], acc[i][2 * qd + u], 0, 0, 0);
+    }
+#undef TEPOSE_READ_B
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using I0 = std::integral_constant<int, 0>;
+  using IP = std::integral_constant<int, PQ>;
+  using IS = std::integral_constant<int, NSTORE>;
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  setup(tile);
+  request_pair(0);
+  request_pair(1);
+  bool pending = false;
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4q{0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    if (pending) {
+      pairstep(0, T_{}, IP{}, IS{});
+      pairstep(1, T_{}, IP{}, IS{});
+      p = 2;
+    }
+    for (; p + 2 < NP; ++p) pairstep(p, T_{}, IP{}, I0{});
+    pairstep(NP - 2, F_{}, IP{}, I0{});
+    pairstep(NP - 1, F_{}, I0{}, I0{});
+
+    const int tm0 = m0, tn0 = n0;
+    const int next = tile + (int)gridDim.x;
+    const bool full = tm0 + HM <= a.M && tn0 + HN <= a.N && vec;
+    float rs[MT];
+    const int le = fresh_lane(), t = le & 15, g = le >> 4;   // (shadow the kernel-scope t, g on purpose)
+    if (full) {
+      if (wave == 0)
+        *(f32x4q*)(sbias + 4 * le) = a.bias ? *(const f32x4q*)(a.bias + tn0 + 4 * le) : f32x4q{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = tm0 + wm * 16 * MT + i * 16 + t;
+        rs[i] = a.row_scale ? a.row_scale[row] * a.inv_scale : a.inv_scale;
+      }
+      wait_vmq<0>();
+    }
+    const bool ov = full && overlap && next < ntiles;
+    __syncthreads();                                       // sbias is written; (the ring has been free since the last B')
+    if (next < ntiles) {
+      setup(next);
+      if (ov) { request_pair(0); request_pair(1); }
+    }
+    if (full) {
+      const unsigned sb = (unsigned)(size_t)sbias + (unsigned)(wn * 16 * NT + 4 * g) * 4u;
+      float* c0 = a.C + (long)(tm0 + wm * 16 * MT + t) * a.ldc + tn0 + wn * 16 * NT + 4 * g;
+#pragma unroll
+      for (int jj = 0; jj < NT; jj += 4) {
+        f32x4q bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[u]) : "v"(sb), "n"((jj + u) * 16 * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            f32x4q v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = acc[i][jj + u][c] * rs[i] + bq[u][c];
+            *(f32x4q*)(c0 + (long)i * 16 * a.ldc + (jj + u) * 16) = v;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = tm0 + wm * 16 * MT + i * 16 + t;
+        if (row >= a.M) continue;
+        const float rsv = a.row_scale ? a.row_scale[row] * a.inv_scale : a.inv_scale;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int col = tn0 + wn * 16 * NT + j * 16 + 4 * g + c;
+            if (col < a.N) a.C[(long)row * a.ldc + col] = acc[i][j][c] * rsv + (a.bias ? a.bias[col] : 0.f);
+          }
+      }
+    }
+    if (next >= ntiles) break;
+    tile = next;
+    if (!ov) {                                            // partial tile / short K: drain, then fill the ring as a first tile does
+      wait_vmq<0>();
+      request_pair(0);
+      request_pair(1);
+    }
+    pending = ov;
+  }
+}
+
+bool gemm_h3s16_ok(const H3SArgs& a) { return a.Kp % 32 == 0 && a.Kp >= 64; }
+
+#if TEPOSE_S16_STAMPS
+extern "C" int tepose_debug_s16_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tepose_s16_stamp_buf), (size_t)n * 8);
+}
+#endif
+
+hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (!gemm_h3s16_ok(a)) return hipErrorInvalidValue;
+  const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
+  const int nt = tilesM * tilesN;
+  if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
+  else hipLaunchKernelGGL(gemm_h3s_persist16_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
+  return hipGetLastError();
+}
+
+}  // namespace tepose

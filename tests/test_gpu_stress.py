@@ -146,20 +146,22 @@ def test_both_numerics_modes_vs_fp64_oracle_at_the_published_size(monkeypatch, c
         assert (got['theta'][:, 75:] - ref['theta'][:, 75:]).abs().max() < 2e-5
 
 
-def test_single_accumulator_gemm_persistent_tiles_against_fp64(monkeypatch):
+@pytest.mark.parametrize('h3s', ['1', '2'])   # 1: v_mfma_f32_32x32x16_f16 (gemm_h3s.hip), 2: 16x16x32 (gemm_h3s16.hip: pairs of K-tiles)
+def test_single_accumulator_gemm_persistent_tiles_against_fp64(monkeypatch, h3s):
     """csrc/gemm_h3s.hip, the plain product as a persistent kernel (256 workgroups walking the 256 x 256 tiles, the next
     tile's stages requested before the finished tile's stores): more tiles than workgroups, partial edge tiles (their own
     drained path), unaligned C rows (scalar stores), short K (no overlap), with and without bias; and the one-workgroup-
     per-tile kernel (TEPOSE_H3S_PERSIST is latched per process, so that one is compared in tools/h3_bench.py)."""
     from tepose_amd import _lib
     lib = _lib.load()
-    monkeypatch.setenv('TEPOSE_H3S', '1')
+    monkeypatch.setenv('TEPOSE_H3S', h3s)
     g = torch.Generator(device='cuda').manual_seed(9)
     cases = [(8192, 2304, 2144 // 32 * 32, 2304, True),      # 32 x 9 = 288 full tiles: 32 workgroups take a second tile
              (5000, 5000, 256, 5000, True),                   # 400 tiles, partial last row / column of tiles
              (4096, 4608, 64, 4608, False),                   # KT = 4: the no-overlap path, 288 tiles
              (2100, 2050, 512, 2051, True),                   # C rows not 16-byte aligned: scalar stores
-             (300, 200, 128, 200, False), (256, 256, 1024, 256, True), (65536, 512, 96, 512, True)]
+             (300, 200, 128, 200, False), (256, 256, 1024, 256, True), (65536, 512, 96, 512, True),
+             (1500, 1024, 192, 1024, True), (777, 333, 352, 340, True)]  # 6 / 11 pairs of K-tiles: the 16x16x32 walk's short cases
     for M, N, K, ldc, use_bias in cases:
         A = torch.randn(M, K, device='cuda', generator=g) * 3.0             # |a| * 256 < 65504
         W = torch.randn(N, K, device='cuda', generator=g) * 0.05            # |w| * 16384 < 65504
@@ -182,7 +184,8 @@ def test_single_accumulator_gemm_persistent_tiles_against_fp64(monkeypatch):
         assert torch.equal(C[:, :N], C2[:, :N])                             # deterministic
 
 
-def test_persistent_split_gemm_is_bitwise_repeatable_next_to_a_memory_and_mfma_heavy_stream(monkeypatch):
+@pytest.mark.parametrize('h3s', ['1', '2'])
+def test_persistent_split_gemm_is_bitwise_repeatable_next_to_a_memory_and_mfma_heavy_stream(monkeypatch, h3s):
     """The persistent plain product (csrc/gemm_h3s.hip, gemm_h3s_persist_kernel) lets a finished tile's 32 stores per wave stay
     in flight under the next tile's first K-tiles: `s_waitcnt vmcnt(2 Q + 32)` is only correct if memory instructions retire
     from the counter in ISSUE order.  That is the documented behaviour of this part (MI355X_MICROARCH.md, "s_waitcnt": "Loads,
@@ -193,7 +196,7 @@ def test_persistent_split_gemm_is_bitwise_repeatable_next_to_a_memory_and_mfma_h
     pipes (a bf16 GEMM) busy; every result must equal the first bit for bit, and the first must match fp64."""
     from tepose_amd import _lib
     lib = _lib.load()
-    monkeypatch.setenv('TEPOSE_H3S', '1')
+    monkeypatch.setenv('TEPOSE_H3S', h3s)
     g = torch.Generator(device='cuda').manual_seed(21)
     side = torch.cuda.Stream()
     big_a = torch.empty(256 << 20, dtype=torch.float32, device='cuda')        # 1 GB
