@@ -305,6 +305,8 @@ hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // t
 hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
 bool gemm_h3s16_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag);   // gemm_h3s16.hip
+bool gru_h3s16_ok(const H3SBatch& b);
+hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s);          // the fused GRU step on 16x16x32 (gemm_h3s16.hip)
 bool gemm_h3s_mid_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s);   // 128 x 288 tiles, N % 288 == 0
 hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,

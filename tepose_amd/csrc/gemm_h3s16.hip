@@ -51,6 +51,13 @@ __device__ __forceinline__ void h3s16_tile_of_block(int bid, int nwg, int tilesM
   tn = rem / gm;
 }
 
+__device__ __forceinline__ float s16_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float s16_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+}
+
 template <int TAG>
 __global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int tilesM, int tilesN) {
   constexpr int NWN = 2, NST = 4, MT = 4, NT = 8;         // 4 x 2 waves of 64 x 128 = 4 x 8 MFMA tiles of 16 x 16
@@ -305,6 +312,206 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int 
     }
     pending = ov;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The fused GRU cell step of large batches (gemm_h3s_kernel<1, 3, 4, 2, true> in gemm_h3s.hip) on the 16x16x32 shape.
+// Same block: 128 rows x 64 hidden units x 3 gates, 4 x 2 waves of 32 rows x (r, z, n of 32 units), W_hh rows in the
+// gate-interleaved tile order, 20 KB stages, 4-slot ring (80 KB: two workgroups per CU cover each other's stalls).
+// Differences: the K loop walks pairs of stages (barrier | 16 fragment reads | barrier B' | 36 MFMAs with the requests of pair
+// p + 2 between, as the first form of the projection kernel above), and the product is formed TRANSPOSED (W fragment = the
+// MFMA's row operand), so that lane (t = lane & 15, g = lane >> 4) of a 16 x 16 tile owns row t and the 4 consecutive hidden
+// units 4 g .. 4 g + 3 -- for r, z and n alike.  That is the layout the cell update wants: 16-byte loads of the gate
+// pre-activations / previous state, one 16-byte state store, two 8-byte plane stores, with NO turn through LDS (the 32x32x16
+// form stages every accumulator through the idle ring to get there: 3 x 16 ds_write_b32 + 12 ds_read_b128 per 32-row fragment
+// and a workgroup barrier).
+template <int TAG>
+__global__ void __launch_bounds__(512) gru_h3s16_kernel(H3SBatch batch, int tilesM, int tilesN) {
+  constexpr int NWN = 2, NW = 8, NST = 4, MT = 2, NT = 6;  // wave = 2 row tiles x (3 gates x 2 unit tiles) of 16 x 16
+  constexpr int HM = 128, HN = 192, HK = 16, RB = HK * 2, RPI = 1024 / RB;
+  constexpr int STAGE = (2 * HM + 2 * HN) * RB;            // 20 KB
+  constexpr int TOT = STAGE / 1024, Q = TOT / NW, REM = TOT % NW;   // 20 instructions per stage: waves < 4 issue 3, the others 2
+  static_assert(STAGE % 1024 == 0 && NST * STAGE <= 80 * 1024 && 4 * (Q + 1) <= 63, "ring / vmcnt budget");
+  typedef _Float16 h16x4q __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
+  const H3SArgs& a = batch.p[blockIdx.y];
+  int tm, tn;
+  h3s16_tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
+  const int m0 = tm * HM, n0 = tn * HN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int t = lane & 15, g = lane >> 4;
+  const int nd = Q + (wave < REM ? 1 : 0);
+  const int i0 = wave * Q + min(wave, REM);
+
+  // LDS-DMA requests: plane base + K position in SGPRs, one 32-bit lane offset per instruction (see dma_part above)
+  constexpr int ND = Q + (REM ? 1 : 0);
+  const char* sbase[ND];
+  long kst[ND];
+  unsigned voff[ND];
+#pragma unroll
+  for (int q = 0; q < ND; ++q) {
+    int ri = min(i0 + q, TOT - 1) * RPI;                   // first row of the stage image [A_hi | A_lo | W_hi | W_lo]
+    const bool isA = ri < 2 * HM;
+    if (!isA) ri -= 2 * HM;
+    const bool lo = ri >= (isA ? HM : HN);
+    const int lrow0 = lo ? ri - (isA ? HM : HN) : ri;
+    sbase[q] = (const char*)(isA ? (lo ? a.Al : a.Ah) : (lo ? a.Wl : a.Wh));
+    kst[q] = (isA ? a.a_kst : a.w_kst) * 2;
+    const int grow = isA ? min(m0 + lrow0 + lane / 2, a.M - 1) : n0 + lrow0 + lane / 2;
+    voff[q] = (unsigned)grow * RB + 16u * (lane & 1);
+  }
+  auto dma_part = [&](int stage, int q) {
+    if (REM == 0 || q < nd) {
+      const unsigned dst = (unsigned)(size_t)lds + (unsigned)((stage % NST) * STAGE + (i0 + q) * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :
+                   : "v"(voff[q]), "s"(sbase[q]), "s"(dst)
+                   : "m0", "memory");
+      sbase[q] += kst[q];
+    }
+  };
+  auto request_pair = [&](int p) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < ND; ++q) dma_part(2 * p + s, q);
+  };
+  const unsigned sx = 16u * ((g & 1) ^ ((t >> 3) & 1)) + (unsigned)(g >> 1) * STAGE;
+  const unsigned abase = (unsigned)(size_t)lds + (unsigned)(wm * 16 * MT + t) * RB + sx;
+  const unsigned bbase = (unsigned)(size_t)lds + 2 * HM * RB + (unsigned)(wn * 16 * NT + t) * RB + sx;
+  constexpr int A_LO = HM * RB, W_LO = HN * RB;
+  const int NP = a.Kp / (2 * HK);                          // the launcher guarantees Kp % 32 == 0, NP >= 2
+
+  f32x4q acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4q{0.f, 0.f, 0.f, 0.f};
+  request_pair(0);
+  request_pair(1);
+  // NEWER: pairs younger than pair p whose requests may stay in flight (1, or 0 at the last pair)
+  auto pairstep = [&](int p, auto dma, auto newer) __attribute__((always_inline)) {
+    constexpr bool DMA = decltype(dma)::value;
+    constexpr int NEWER = decltype(newer)::value;
+    if (REM && wave < REM) wait_vmq<NEWER * 2 * (Q + 1)>(); else wait_vmq<NEWER * 2 * Q>();
+    __builtin_amdgcn_s_barrier();
+    const unsigned par = (unsigned)(p & 1) * 2u * STAGE;
+    const unsigned ab = abase + par, bb = bbase + par;
+    h16x8q ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[i]) : "v"(ab), "n"(i * 16 * RB));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[i]) : "v"(ab), "n"(i * 16 * RB + A_LO));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[j]) : "v"(bb), "n"(j * 16 * RB));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[j]) : "v"(bb), "n"(j * 16 * RB + W_LO));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]),
+                   "+v"(bh[4]), "+v"(bh[5]), "+v"(bl[0]), "+v"(bl[1]), "+v"(bl[2]), "+v"(bl[3]), "+v"(bl[4]), "+v"(bl[5])
+                 :
+                 : "memory");
+    __builtin_amdgcn_s_barrier();                          // B': every wave holds pair p in registers -> its two slots are free
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        const int n = i * NT + j;
+#pragma unroll
+        for (; q < (n + 1) * 2 * ND / (MT * NT); ++q)
+          if constexpr (DMA) dma_part(2 * p + 4 + q / ND, q % ND);
+      }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  int p = 0;
+  for (; p + 2 < NP; ++p) pairstep(p, T_{}, I1{});
+  pairstep(NP - 2, F_{}, I1{});
+  pairstep(NP - 1, F_{}, I0{});
+
+  // ---- cell update: lane (t, g) holds, for row tile i and unit tile u, rows m0 + wm * 32 + i * 16 + t and the hidden units
+  // jb + u * 16 + 4 g .. + 3 of the three gates (W_hh tile j = gate * 2 + u of this wave's 96 rows)
+  const GateDir& d = batch.gate[blockIdx.y];
+  const int Hp = batch.Hp;
+  const int jb = tn * (32 * NWN) + wn * 32;
+  const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev | (size_t)d.bhh) & 15) == 0 && (d.ldo & 3) == 0 &&
+                   (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = jb + u * 16 + 4 * g;
+    if (j >= Hp) continue;
+    f32x4q br, bz, bn;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { br[c] = d.bhh[j + c]; bz[c] = d.bhh[Hp + j + c]; bn[c] = d.bhh[2 * Hp + j + c]; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = m0 + wm * 16 * MT + i * 16 + t;
+      if (row >= a.M) continue;
+      const float* gi = d.gi + (long)row * d.ldgi + j;
+      const float* hq = d.hprev + (long)row * d.ldh + j;
+      f32x4q gr, gz, gn, hp;
+      if (vec) {
+        gr = *(const f32x4q*)gi; gz = *(const f32x4q*)(gi + Hp); gn = *(const f32x4q*)(gi + 2 * Hp);
+        hp = *(const f32x4q*)hq;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { gr[c] = gi[c]; gz[c] = gi[Hp + c]; gn[c] = gi[2 * Hp + c]; hp[c] = hq[c]; }
+      }
+      f32x4q v;
+      _Float16 hh[4], ll[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float hr = acc[i][0 + u][c] * a.inv_scale, hz = acc[i][2 + u][c] * a.inv_scale, hn = acc[i][4 + u][c] * a.inv_scale;
+        const float rg = s16_sigmoid(gr[c] + (hr + br[c]));
+        const float zg = s16_sigmoid(gz[c] + (hz + bz[c]));
+        const float ng = s16_tanh(gn[c] + rg * (hn + bn[c]));
+        v[c] = (1.f - zg) * ng + zg * hp[c];
+        const float sv = v[c] * batch.state_scale;
+        hh[c] = (_Float16)sv;
+        ll[c] = (_Float16)(sv - (float)hh[c]);
+      }
+      float* ho = d.hout + (long)row * d.ldo + j;
+      const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
+      if (vec) {
+        *(f32x4q*)ho = v;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ho[c] = v[c];
+      }
+      *(h16x4q*)((_Float16*)d.hout_hi + o) = h16x4q{hh[0], hh[1], hh[2], hh[3]};
+      *(h16x4q*)((_Float16*)d.hout_lo + o) = h16x4q{ll[0], ll[1], ll[2], ll[3]};
+    }
+  }
+}
+
+bool gru_h3s16_ok(const H3SBatch& b) {
+  if (b.n < 1 || b.Hp % 64 != 0) return false;
+  for (int d = 0; d < b.n; ++d)
+    if (b.p[d].Kp % 32 != 0 || b.p[d].Kp < 64 || b.p[d].M != b.p[0].M) return false;
+  return true;
+}
+
+hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s) {
+  if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
+  if (!gru_h3s16_ok(b)) return hipErrorInvalidValue;
+  const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
+  hipLaunchKernelGGL(gru_h3s16_kernel<0>, dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
+  return hipGetLastError();
 }
 
 bool gemm_h3s16_ok(const H3SArgs& a) { return a.Kp % 32 == 0 && a.Kp >= 64; }

@@ -4,7 +4,7 @@
 # (objects of the unmodified sources: build/obj/*.o, rebuilt here when missing)
 set -e
 stem=$1; macro=$2; prefix=$3; shift 3
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DTEPOSE_NO_PACKED_FP32=1"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -DTEPOSE_NO_PACKED_FP32=1 -Wno-inline-asm"
 mkdir -p build/obj build/abl
 for f in gemm gemm_h3 gemm_h3s gemm_h3s16 skinny skinny_h3 gru_seq reg_seq misc smpl metrics filters api; do
   if [ ! -f build/obj/$f.o ] || [ tepose_amd/csrc/$f.hip -nt build/obj/$f.o ] || [ tepose_amd/csrc/common.h -nt build/obj/$f.o ]; then
