@@ -61,12 +61,14 @@ def synthetic_windows_device(B, T, seed, device):
     return x
 
 
-def pmc_traffic(B, T, split):
+def pmc_traffic(B, T, split, kernels=None):
     """(bytes, provenance): HBM-side bytes per launch of the dominant kernel.  NOT measured in this run -- PMC counters
     need their own rocprofv3 passes -- but read from the newest committed pass of this same command
     (profiles/rNN_traffic_{split,exact}.json; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section).
-    (None, reason) when the workload differs from the profiled one."""
+    (None, reason) when the workload differs from the profiled one -- or when the profile is STALE: it names another kernel
+    symbol than the one the running library launches for this handle (`kernels` = Engine.kernel_info())."""
     import glob
+    pmc_traffic.gru = None
     if (B, T) != (8192, 16):
         return None, 'no PMC pass committed for this batch / window length'
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic_%s.json' % ('split' if split else 'exact'))))
@@ -74,6 +76,16 @@ def pmc_traffic(B, T, split):
         return None, 'no PMC pass committed'
     with open(files[-1]) as f:
         d = json.load(f)
+    rel = os.path.relpath(files[-1], ROOT)
+    if kernels:
+        def names(entry, sym):                   # the profile entry is about this symbol (template arguments compared without blanks)
+            return entry is not None and sym.replace(' ', '') in str(entry.get('kernel', '')).replace(' ', '')
+        if not names(d.get('gru_step'), kernels.get('gru_step', '?')):
+            d = dict(d, gru_step=None)
+        if not names(d, kernels.get('projection', '?')):
+            pmc_traffic.gru = d.get('gru_step')
+            return None, ('STALE: %s profiles %r, the running library launches %r -- re-run tools/profile.sh and '
+                          'profiles/summarize.py traffic' % (rel, str(d.get('kernel', ''))[:60], kernels.get('projection')))
     pmc_traffic.gru = d.get('gru_step')          # the fused GRU step's pass of the same run, for roofline_gru_steps
     return d.get('traffic_bytes_per_launch'), ('constant from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, '
                                                'FETCH x2-corrected; not collected in this run)' % os.path.relpath(files[-1], ROOT))
@@ -116,6 +128,27 @@ def cpu_model_string():
     return platform.processor() or platform.machine()
 
 
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo); None if that cannot be read."""
+    try:
+        seen, phys, core = set(), None, None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    phys = line.split(':')[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':')[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=None):
     """Reference op sequence on the host cores (oracle, torch CPU), windows/s -- and, on the same 256-window
     sample, the largest absolute difference between that CPU result and each GPU numerics mode (the north-star
@@ -128,13 +161,16 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
     # pick the thread count that serves the reference path best on this host (all cores is
     # not always it: at B=256 the CPU GRU saturates well below 128 threads)
     all_cores = os.cpu_count() or torch.get_num_threads()
+    phys = physical_cores() or all_cores
     best = (0.0, all_cores)
-    for nt in sorted({min(64, all_cores), min(32, all_cores), min(16, all_cores)}):    # >64 threads only oversubscribe
+    sweep = []                                            # every (threads, windows/s) pair tried: SURVEY 8d asks for ALL
+    for nt in sorted({min(n, all_cores) for n in (8, 16, 32, 64, phys, all_cores)}):   # physical cores and 1 (below)
         torch.set_num_threads(nt)
         O.tepose_fwd(state, smpl_np, x[:16], L, J_regressor=J, nn_gru=True)  # warm-up
         t0 = time.perf_counter()
         O.tepose_fwd(state, smpl_np, x[:64], L, J_regressor=J, nn_gru=True)
         r = 64 / (time.perf_counter() - t0)
+        sweep.append([nt, r])
         if r > best[0]:
             best = (r, nt)
     cores = best[1]
@@ -168,7 +204,8 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
         small[name] = {'ms_per_forward': best_s[0], 'windows_per_s': b / best_s[0] * 1e3, 'threads': best_s[1]}
     torch.set_num_threads(cores)
     res = {'value': n / el, 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
-           'single_thread_value': single, 'host_cpus': all_cores, 'cpu_model': cpu_model_string(),
+           'single_thread_value': single, 'host_cpus': all_cores, 'physical_cores': phys, 'cpu_model': cpu_model_string(),
+           'thread_sweep': sweep + [[1, single]],        # [threads, windows/s] on 64-window batches; `cores` = the best of them
            'small_shapes': small,
            'sample': '%d windows of [%d,2133] in batches of %d, torch %s CPU, nn.GRU op sequence, %.1f s'
                      % (n, T, Bc, torch.__version__, el)}
@@ -278,26 +315,19 @@ def main():
         model = TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='', smpl=SMPL.from_tables(smpl_np),
                        smpl_mean_params=mean).to(device).eval()
         eng = model._engine
-        blob = torch.empty(eng.packed_bytes, dtype=torch.uint8, device=device)
         state = None
     bcast_ms = None
+    n_ranks_seen = None
     if use_dist:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
         # RCCL over xGMI, once: only the fp32 sections of the blob travel (276 of 770 MB: header, packed matrices, tables,
         # collapsed maps); every rank rebuilds the hi / lo planes from them (tepose_derive_planes: bit-identical planes)
-        ranges = eng.fp32_ranges()
-        if rank != 0:
-            blob.zero_()
-        for off, n in ranges:
-            dist.broadcast(blob[off:off + n], src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-        bcast_bytes = sum(n for _, n in ranges)
-        if rank != 0:
-            eng.adopt_blob(blob, model, derive=True)
-        elif args.force_dist and world == 1:
+        from tepose_amd.distributed import broadcast_model_weights, count_distinct_devices
+        bc = broadcast_model_weights(model, src=0)
+        bcast_ms, bcast_bytes = bc['ms'], bc['bytes']
+        # all_gather of the device identities: N ranks must sit on N distinct GPUs for the line to be an N-GPU number
+        n_ranks_seen, rank_devices = count_distinct_devices(device)
+        blob = eng.blob
+        if args.force_dist and world == 1:
             # one rank: exercise the receiving side too -- a second handle adopts a copy of the broadcast blob and must
             # reproduce rank 0's probe forward bit for bit (checked below as `adopted_blob_matches`)
             from tepose_amd.smpl import SMPL
@@ -305,7 +335,7 @@ def main():
             twin = TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='', smpl=SMPL.from_tables(smpl_np),
                           smpl_mean_params=synth.synthetic_mean_params(0)).to(device).eval()
             rx = torch.zeros_like(blob)
-            for off, n in ranges:
+            for off, n in eng.fp32_ranges():
                 rx[off:off + n] = blob[off:off + n]
             twin._engine.adopt_blob(rx, twin, derive=True)
 
@@ -381,26 +411,23 @@ def main():
             ach = k_flops / (k_ms / k_n * 1e-3) / 1e12
             if split:
                 peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
-                tr, tr_src = pmc_traffic(B, T, True)
+                tr, tr_src = pmc_traffic(B, T, True, eng.kernel_info())
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                    'traffic': tr, 'traffic_source': tr_src,
                                    'algorithmic_bytes': float(B * T) * 2133 * 4 + 9216.0 * 2133 * 4 + float(B * T) * 9216 * 4,
-                                   'kernel': 'gemm_h3s_persist_kernel<0> (single-accumulator split GEMM, 256x256 tiles walked by 256 persistent workgroups; layer-0 input projection, M=%d N=9216 K=2133)'
-                                             % (B * T),
+                                   'kernel': '%s (single-accumulator split GEMM on scaled fp16 hi / lo planes, 256x256 tiles walked by 256 '
+                                             'persistent workgroups; layer-0 input projection, M=%d N=9216 K=2133)'
+                                             % (eng.kernel_info().get('projection', '?'), B * T),
                                    'launches': k_n, 'avg_ms': k_ms / k_n,
-                                   # what the chip sustains for this kernel's MFMA sequence with NO operand traffic (the same
-                                   # instruction stream minus LDS-DMA, fragment reads and stores, real operand data in the ring):
-                                   # 9.55 ms at 1.68 GHz, 92 % busy -- a committed measurement, not taken in this run
-                                   'power_limited_ceiling': {'frac_of_peak': 5.153e12 / 9.55e-3 / 1e12 / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS),
-                                                             'achieved_over_ceiling': (ach / (5.153e12 / 9.55e-3 / 1e12)) if (B, T) == (8192, 16) else None,
-                                                             'source': 'profiles/r03_projection_ablation.txt (tools/h3s_ablate.sh, SQ counter pass; '
-                                                                       'constant, not collected in this run)'},
+                                   # (what the chip sustains for the 32x32x16 form of this MFMA sequence with no operand traffic
+                                   # at all was measured once in round 3 -- profiles/r03_projection_ablation.txt: 9.55 ms at
+                                   # 1.68 GHz, 92 % busy; that constant is no longer mixed into this live line)
                                    'note': 'achieved = algorithmic fp32-equivalent FLOP/s; the kernel issues %d fp16 MFMAs '
                                            'per product (hi*hi, hi*lo, lo*hi; fp32 accumulate), so peak = dense fp16 '
                                            'MFMA %.1f / %d; executed MFMA rate = %.0f TFLOP/s'
                                            % (SPLIT_PRODUCTS, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS, ach * SPLIT_PRODUCTS)}
             else:
-                tr, tr_src = pmc_traffic(B, T, False)
+                tr, tr_src = pmc_traffic(B, T, False, eng.kernel_info())
                 res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': tr, 'traffic_source': tr_src,
                                    'kernel': 'gemm_f32_kernel<false> (layer-0 input projection, M=%d N=9216 K=2133)'
@@ -429,6 +456,8 @@ def main():
             sums = [r[4] for r in res['per_rank']]
             res['ranks_agree'] = bool(max(sums) - min(sums) <= 1e-6 * max(sums))
             res['dist_backend'] = dist.get_backend()
+            res['n_ranks_seen'] = n_ranks_seen                    # distinct GPUs among the ranks (all_gather of device identities)
+            res['rank_devices'] = rank_devices
             # lower bound of the broadcast on this node: the blob crosses at least one xGMI link (~153 GB/s per link,
             # MI355X_MICROARCH.md); at world 1 there is no link and the figure is the collective's fixed cost
             res['weight_broadcast_xgmi_floor_ms'] = bcast_bytes / 153e9 * 1e3 if world > 1 else 0.0

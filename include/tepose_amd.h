@@ -63,6 +63,11 @@ const char* tepose_error_string(int code);
  * n_layers >= 1, hidden >= 1 (padded internally to a multiple of 64).               */
 int tepose_create(int n_layers, int hidden, tepose_model** out);
 void tepose_destroy(tepose_model* m);
+/* "projection=<kernel symbol>;gru_step=<kernel symbol>": the kernels this handle's knobs (environment at creation) select for
+ * the two dominant launch families of a large-batch forward, as a rocprofv3 kernel trace spells them.  A committed profile
+ * (profiles/rNN_traffic_*.json) describes the running binary only if it names the same symbols; bench.py marks it stale
+ * otherwise.  The string lives as long as the handle.                                                                    */
+const char* tepose_kernel_info(const tepose_model* m);
 
 /* Bytes of the single device blob that holds every packed constant of the model
  * (encoder + regressor + SMPL tables).  The caller allocates it; it is what gets
@@ -156,14 +161,22 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
  * therefore bounded (~2 s), and a launch that gives up poisons that forward's outputs with NaN AND raises the
  * handle's fault word (pinned host memory, written by the kernel).  The reference has no silent-garbage mode
  * (an exception ends evaluate.py:255); neither has this boundary:
- *   - tepose_status(m, stream): synchronises `stream`, returns TEPOSE_E_TIMEOUT if a forward on `m` gave up
- *     since the last call (and clears the word), else 0.  Call it wherever the outputs are about to be trusted.
- *   - tepose_status_peek(m): the same test without synchronising or clearing.
+ *   - tepose_forward_status(m, workspace, stream): synchronises `stream` and answers for ONE forward -- the last one that ran
+ *     with this workspace: TEPOSE_E_TIMEOUT (once; the workspace's status words and the handle's word are cleared) if one of
+ *     its persistent launches gave up, else 0.  The status words live in the workspace, which concurrent forwards never
+ *     share, so this is the call for a handle that several streams / threads drive at once.
+ *   - tepose_status(m, stream): synchronises `stream`, returns TEPOSE_E_TIMEOUT if ANY forward on `m` gave up since the last
+ *     call (and clears the handle's word), else 0.  Handle-wide: with one handle on several streams the caller that polls
+ *     first collects the fault, whichever forward raised it -- use it only with one stream per handle, or use
+ *     tepose_forward_status.  Call one of the two wherever the outputs are about to be trusted.
+ *   - tepose_status_peek(m): the handle-wide test without synchronising or clearing.
  *   - every forward entry point (tepose_forward, tepose_forward_cached, tepose_encoder_fwd,
  *     tepose_regressor_fwd[_init]) returns TEPOSE_E_TIMEOUT up front while the word is raised.
  *   - tepose_set_persistent(m, 0) (or TEPOSE_PERSISTENT=0 at tepose_create): the step-per-launch HIP kernels at
- *     every batch size -- same results, no residency requirement; the remedy after a TEPOSE_E_TIMEOUT.
+ *     every batch size -- same results, no residency requirement; the remedy after a TEPOSE_E_TIMEOUT.  The switch is one
+ *     atomic flag: it may be flipped while other threads run forwards on the handle (each forward reads it once).
  *   - tepose_uses_persistent(m, B, T): 1 if a forward of B windows may launch a persistent kernel.          */
+int tepose_forward_status(tepose_model* m, void* workspace, void* stream);
 int tepose_status(tepose_model* m, void* stream);
 int tepose_status_peek(const tepose_model* m);
 int tepose_set_persistent(tepose_model* m, int on);

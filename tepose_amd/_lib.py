@@ -21,8 +21,8 @@ SYMBOLS = [
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
-    'tepose_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
-    'tepose_fp32_ranges', 'tepose_derive_planes',
+    'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
+    'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info',
 ]
 
 _lib = None
@@ -106,6 +106,7 @@ def load():
     lib.tepose_fp32_ranges.argtypes = [c_void_p, POINTER(c_size_t), POINTER(c_size_t), c_int]
     lib.tepose_derive_planes.argtypes = [c_void_p, c_void_p]
     lib.tepose_status.argtypes = [c_void_p, c_void_p]
+    lib.tepose_forward_status.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.tepose_status_peek.argtypes = [c_void_p]
     lib.tepose_set_persistent.argtypes = [c_void_p, c_int]
     lib.tepose_uses_persistent.argtypes = [c_void_p, c_int, c_int]
@@ -117,6 +118,8 @@ def load():
     if lib.tepose_version() != 1:
         raise ImportError('tepose_amd: ABI version mismatch (%d)' % lib.tepose_version())
     lib.tepose_build_info.restype = c_char_p
+    lib.tepose_kernel_info.restype = c_char_p
+    lib.tepose_kernel_info.argtypes = [c_void_p]
     info = (lib.tepose_build_info() or b'').decode()
     if 'packed_fp32=off' not in info:
         import warnings

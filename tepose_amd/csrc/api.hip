@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <new>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -48,6 +49,7 @@ struct tepose_model {
   float w0_scale = 1.f;                         // host copy of blob[wih0_scale]
   bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
   bool gru_single_acc = true;                   // large batches: layer >= 1 projections and GRU steps on it too
+  std::string kinfo;                            // tepose_kernel_info(): the kernel symbols the knobs select for the dominant launches
   int mfma16 = 1;                               // TEPOSE_MFMA16 bit mask: 1 = plain scaled-plane products (default since round 4:
                                                 // -3 % on the projections, the chip holds 1.88 instead of 1.66 GHz), 2 = fused GRU
                                                 // step (measured neutral: 1.99 vs 1.74 GHz but 0.50 vs 0.57 busy) on
@@ -532,6 +534,21 @@ static void read_env_knobs(tepose_model* m) {
   if (e && atol(e) > 0) m->spin_limit = (unsigned)atol(e);
   e = getenv("TEPOSE_TEST_FAULT");                  // tests only: make the persistent kernels' waits unmeetable
   m->test_fault = e ? (unsigned)atoi(e) : 0u;
+  // the symbols a rocprofv3 kernel trace of a large-batch forward (B >= s_min_b, B * T >= 8192) lists for the two dominant
+  // launch families -- what a committed profile must name to describe THIS binary with THESE knobs (bench.py checks)
+  const char* h3sp = getenv("TEPOSE_H3S_PERSIST");
+  const bool persist_plain = !(h3sp && atoi(h3sp) == 0);
+  const char* gp = getenv("TEPOSE_GRU_PERSIST");
+  m->kinfo = std::string("projection=") +
+             (!m->split ? "gemm_f32_kernel"
+              : !m->g0_single_acc ? "gemm_h3_kernel"
+              : !persist_plain ? "gemm_h3s_kernel"
+              : (m->mfma16 & 1) ? "gemm_h3s_persist16_kernel<0>" : "gemm_h3s_persist_kernel<0>") +
+             ";gru_step=" +
+             (!m->split ? "gru_step_kernel"
+              : !m->gru_single_acc ? "gemm_h3_kernel"
+              : (m->mfma16 & 2) ? "gru_h3s16_kernel<0>"
+              : (gp && atoi(gp) != 0) ? "gru_h3s_persist_kernel<0>" : "gemm_h3s_kernel<1, 3, 4, 2, true, 4>");
 }
 
 namespace {
@@ -622,6 +639,8 @@ const char* tepose_build_info(void) {
 #endif
 }
 
+const char* tepose_kernel_info(const tepose_model* m) { return m ? m->kinfo.c_str() : ""; }
+
 const char* tepose_error_string(int code) {
   switch (code) {
     case 0: return "ok";
@@ -674,7 +693,9 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
 static inline bool fault_pending(const tepose_model* m) {
   return m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) != 0u;
 }
-static inline bool persist_on(const tepose_model* m) { return m->persist && m->fault != nullptr; }
+static inline bool persist_on(const tepose_model* m) {
+  return __atomic_load_n(&m->persist, __ATOMIC_RELAXED) && m->fault != nullptr;   // (tepose_set_persistent may run on another thread)
+}
 
 int tepose_status_peek(const tepose_model* m) {
   if (!m) return TEPOSE_E_ARG;
@@ -688,9 +709,25 @@ int tepose_status(tepose_model* m, void* stream) {
   return __atomic_exchange_n(m->fault, 0u, __ATOMIC_RELAXED) != 0u ? TEPOSE_E_TIMEOUT : 0;
 }
 
+int tepose_forward_status(tepose_model* m, void* workspace, void* stream) {
+  if (!m || !workspace) return TEPOSE_E_ARG;
+  CK(hipStreamSynchronize((hipStream_t)stream));
+  // the sync region is the first carve of every workspace (carve_encoder / carve_regressor): [.. | gru status | .. | reg status]
+  unsigned* sy = (unsigned*)workspace;
+  unsigned st[2] = {0u, 0u};
+  CK(hipMemcpy(&st[0], sync_gru_status(m, sy), sizeof(unsigned), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(&st[1], sync_reg_status(m, sy), sizeof(unsigned), hipMemcpyDeviceToHost));
+  if ((st[0] | st[1]) == 0u) return 0;
+  // once per faulted forward: a later forward that launches no persistent kernel does not clear the words itself
+  CK(hipMemset(sync_gru_status(m, sy), 0, sizeof(unsigned)));
+  CK(hipMemset(sync_reg_status(m, sy), 0, sizeof(unsigned)));
+  if (m->fault) __atomic_store_n(m->fault, 0u, __ATOMIC_RELAXED);   // or every entry point would go on refusing
+  return TEPOSE_E_TIMEOUT;
+}
+
 int tepose_set_persistent(tepose_model* m, int on) {
   if (!m) return TEPOSE_E_ARG;
-  m->persist = on != 0;
+  __atomic_store_n(&m->persist, on != 0, __ATOMIC_RELAXED);
   return 0;
 }
 

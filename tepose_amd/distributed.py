@@ -59,3 +59,62 @@ def gather_records(records, dst=0):
     if rank != dst:
         return None
     return torch.cat([b[:int(c.item())] for b, c in zip(bufs, counts)], dim=0)
+
+
+def broadcast_model_weights(model, src=0):
+    """The weight collective of SURVEY 8e: rank `src` holds the loaded model (TePose or the VIBE bootstrap), every other rank a
+    freshly constructed one of the same architecture.  `src` packs (if it has not yet), then only the fp32 sections of the packed blob travel -- one broadcast
+    per byte range of `Engine.fp32_ranges()` (header, packed matrices, biases, SMPL tables, collapsed maps: 276 of 770 MB at
+    L = 2 / H = 1024) -- and every receiver rebuilds the hi / lo planes on its own GPU (`tepose_derive_planes`: byte-identical
+    to the sender's blob).  Backend nccl = RCCL over xGMI.  Returns {'ms', 'bytes', 'blob_bytes'} (ms includes the receivers'
+    plane derivation); with no initialised process group it only packs and reports ms = None."""
+    import time
+    eng = model._engine
+    dev = next(model.parameters()).device
+    if not (dist.is_available() and dist.is_initialized()):
+        eng.pack_model(model, dev)
+        return {'ms': None, 'bytes': 0, 'blob_bytes': eng.packed_bytes}
+    rank = dist.get_rank()
+    with torch.cuda.device(dev):
+        if rank == src:
+            eng.pack_model(model, dev)
+            blob = eng.blob
+        else:
+            blob = torch.zeros(eng.packed_bytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        ranges = eng.fp32_ranges()
+        for off, n in ranges:
+            dist.broadcast(blob[off:off + n], src=src)
+        if rank != src:
+            eng.adopt_blob(blob, model, derive=True)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) * 1e3
+    return {'ms': ms, 'bytes': sum(n for _, n in ranges), 'blob_bytes': eng.packed_bytes}
+
+
+def device_identity(device):
+    """A string that is equal on two ranks exactly when they drive the same physical GPU: the device UUID where the runtime
+    exposes one, else the PCI bus id."""
+    props = torch.cuda.get_device_properties(device)
+    uuid = getattr(props, 'uuid', None)
+    if uuid is not None and str(uuid).strip('0-') != '':
+        return 'uuid:%s' % uuid
+    bus = getattr(props, 'pci_bus_id', None)
+    dom = getattr(props, 'pci_domain_id', 0)
+    dv = getattr(props, 'pci_device_id', 0)
+    if bus is not None:
+        return 'pci:%04x:%02x:%02x' % (int(dom), int(bus), int(dv))
+    return 'index:%d' % torch.device(device).index
+
+
+def count_distinct_devices(device):
+    """all_gather of `device_identity` over the ranks -> (number of distinct GPUs, list of identities by rank).  An N-rank run on
+    N GPUs reports N; N ranks sharing one GPU (the CPU-box test set-up) report 1."""
+    me = device_identity(device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, [me]
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, me)
+    return len(set(ids)), ids

@@ -124,7 +124,7 @@ class Engine:
         else:
             _lib.check(self.lib.tepose_adopt_blob(self.handle), 'tepose_adopt_blob')
         self.packed_generation += 1
-        self._sig_enc = _sig(self._enc_tensors(model.encoder))
+        self._sig_enc = _sig(self._vibe_enc_tensors(model.encoder) if self.kind == 'vibe' else self._enc_tensors(model.encoder))
         self._sig_reg = _sig(self._reg_tensors(model.regressor))
         self._sig_smpl = (id(model.regressor.smpl),) + _sig(self._smpl_tensors(model.regressor.smpl))
         self._ws = None
@@ -229,8 +229,18 @@ class Engine:
         _lib.check(self.lib.tepose_set_persistent(self.handle, 0), 'tepose_set_persistent')
         self.degraded = True
         warnings.warn('tepose_amd: a persistent small-batch kernel gave up waiting for its peer workgroups (%s) -- is the GPU '
-                      'shared with another process or CU-masked?  This model now uses the step-per-launch kernels '
-                      '(set TEPOSE_PERSISTENT=0 to start that way).' % what, RuntimeWarning, stacklevel=4)
+                      'shared with another process or CU-masked?  This model now uses the step-per-launch kernels FOR THE REST OF '
+                      'ITS LIFE (set TEPOSE_PERSISTENT=0 to start that way; Engine.set_persistent(True) -- '
+                      'model._engine.set_persistent(True) -- switches back once the GPU is yours again).' % what,
+                      RuntimeWarning, stacklevel=4)
+
+    def set_persistent(self, on):
+        """Select the persistent small-batch kernels (True: the default) or the step-per-launch kernels (False).  A fault
+        switches a handle to the latter for good (`degraded`); this is the way back after a transient contention.  Graphs
+        captured with `torch.cuda.graph` keep the kernels they were captured with: re-capture after a switch."""
+        _lib.check(self.lib.tepose_set_persistent(self.handle, 1 if on else 0), 'tepose_set_persistent')
+        self.degraded = False if on else self.degraded
+        self._uses_persistent.clear()
 
     def check_status(self):
         """Synchronise the current stream and raise TeposeTimeout if a forward on this handle gave up since the last
@@ -248,8 +258,18 @@ class Engine:
         finally:
             self.status_mode = old
 
-    def _run(self, B, call):
-        """call() queues one forward on the current stream and returns its outputs."""
+    def _forward_status(self, ws):
+        """Did the forward that just ran with workspace `ws` give up?  Per forward (the status words live in its workspace), so
+        the answer does not depend on what other streams / handles-sharing threads did in the meantime."""
+        if ws is None:
+            return self.lib.tepose_status(self.handle, self._stream())
+        return self.lib.tepose_forward_status(self.handle, ws.data_ptr(), self._stream())
+
+    def _run(self, B, call, ws=None):
+        """call() queues one forward on the current stream and returns its outputs.  (One Engine = one workspace: a model is
+        driven by one stream / thread at a time; concurrent streams take one model each, or the C ABI with one workspace each.)
+        sync mode synchronises the stream of every small-batch forward; a forward captured into a hipGraph is NOT checked at
+        replay -- call check_status() after replays, and re-capture after a fault switched the kernels."""
         try:
             out = call()
         except _lib.TeposeTimeout:
@@ -258,12 +278,12 @@ class Engine:
             self._degrade('outputs of earlier forwards are invalid')
             raise
         if self.status_mode == 'sync' and self.uses_persistent(B) and not torch.cuda.is_current_stream_capturing():
-            rc = self.lib.tepose_status(self.handle, self._stream())
+            rc = self._forward_status(ws)
             if rc == _lib.E_TIMEOUT:
                 self._degrade('re-running this forward')
                 out = call()
-                rc = self.lib.tepose_status(self.handle, self._stream())
-            _lib.check(rc, 'tepose_status')
+                rc = self._forward_status(ws)
+            _lib.check(rc, 'tepose_forward_status')
         return out
 
     # ------------------------------------------------------------------ forward
@@ -289,7 +309,7 @@ class Engine:
                                                    feat.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                        'tepose_encoder_fwd')
             return feat
-        return self._run(B, call)
+        return self._run(B, call, ws)
 
     def regressor_fwd(self, feat, n_iter, J_regressor, ws_hint=None, init=(None, None, None)):
         N = feat.shape[0]
@@ -311,7 +331,7 @@ class Engine:
                 out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
                 self._stream()), 'tepose_regressor_fwd_init')
             return out
-        return self._run(N, call)
+        return self._run(N, call, ws)
 
     @staticmethod
     def _outputs(N, nj, dev):
@@ -338,7 +358,7 @@ class Engine:
                 out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
                 self._stream()), 'tepose_forward')
             return out
-        return self._run(B, call)
+        return self._run(B, call, ws)
 
     def smpl_fwd(self, pose, betas, pose2rot):
         """pose [N,72] (axis-angle) or [N,24,3,3]; betas [N,10] -> verts [N,6890,3], joints [N,49,3]."""
@@ -377,16 +397,29 @@ class Engine:
                 out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                 'tepose_forward_cached')
             return out
-        return self._run(B, call)
+        return self._run(B, call, ws)
 
     # ------------------------------------------------------------------ VIBE bootstrap encoder
-    def pack_vibe_encoder(self, enc, device):
+    def _vibe_enc_tensors(self, enc):
         ts = []
         for l in range(self.n_layers):
             for sfx in ('', '_reverse') if enc.gru.bidirectional else ('',):
                 ts += [getattr(enc.gru, '%s_l%d%s' % (k, l, sfx)) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
         if enc.linear is not None:
             ts += [enc.linear.weight, enc.linear.bias]
+        return ts
+
+    def pack_model(self, model, device):
+        """Pack every part of a TePose / VIBE module (encoder, regressor, SMPL) that changed since the last pack."""
+        with on_device(device):
+            if self.kind == 'vibe':
+                self.pack_vibe_encoder(model.encoder, device)
+            else:
+                self.pack_encoder(model.encoder, device)
+            self.pack_regressor(model.regressor, device)
+
+    def pack_vibe_encoder(self, enc, device):
+        ts = self._vibe_enc_tensors(enc)
         sig = _sig(ts)
         if sig == self._sig_enc and self.device == device:
             return
@@ -407,6 +440,11 @@ class Engine:
                                                     feat.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                    'tepose_vibe_encoder_fwd')
         return feat
+
+    def kernel_info(self):
+        """{'projection': symbol, 'gru_step': symbol}: the kernels this handle's knobs select for the dominant launches."""
+        txt = (self.lib.tepose_kernel_info(self.handle) or b'').decode()
+        return dict(kv.split('=', 1) for kv in txt.split(';') if '=' in kv) if txt else {}
 
     # ------------------------------------------------------------------ profiling hook (bench.py)
     def profile_enable(self, on):

@@ -76,3 +76,48 @@ def _worker_one(rank, world, port):
 def test_gather_runs_the_collectives_in_a_group_of_one():
     """`--force-dist` (bench.py, tools/evaluate_clips.py): the N-GPU code path at world size 1."""
     mp.spawn(_worker_one, args=(1, _free_port()), nprocs=1, join=True)
+
+
+def _worker_many(rank, world, port, lengths):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        parts = partition_clips(lengths, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(lengths)))
+        mine = parts[rank]
+        # per-clip records as tepose_amd.evaluate builds them: clip id, frames, sum of per-frame errors, two more sums
+        rec = torch.tensor([[float(i), float(lengths[i]), 0.5 * lengths[i], 0.25 * lengths[i], float(rank)] for i in mine],
+                           dtype=torch.float64).reshape(-1, 5)
+        out = gather_records(rec, dst=0)
+        # the step-time reduction of bench.py / evaluate_clips: max over ranks
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t) == float(world)
+        if rank == 0:
+            assert out.shape == (len(lengths), 5)
+            assert sorted(int(v) for v in out[:, 0].tolist()) == list(range(len(lengths)))
+            if lengths:
+                assert abs(float(out[:, 2].sum() / out[:, 1].sum()) - 0.5) < 1e-12      # frame-weighted mean, evaluate.py:461
+            # every clip's record came from the rank the partition names
+            owner = {i: r for r, p in enumerate(parts) for i in p}
+            assert all(int(row[4]) == owner[int(row[0])] for row in out.tolist())
+            # ranks without a clip contributed nothing
+            empty = [r for r, p in enumerate(parts) if not p]
+            assert not set(empty) & set(int(v) for v in out[:, 4].tolist())
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,lengths', [
+    (4, [300, 20, 75]),                                   # 3 clips on 4 ranks: one rank holds none
+    (4, [1824, 910, 777, 1500, 64, 333, 2048, 12, 905]),
+    (8, [640, 1200, 87, 64, 333]),                        # 5 clips on 8 ranks: three ranks hold none
+    (8, [1824, 910, 777, 1500, 64, 333, 2048, 12, 905, 640, 1200, 87, 1000, 5, 5, 5, 77, 431, 222, 90, 1403]),
+    (8, []),                                              # no clip at all: every rank gathers an empty record set
+])
+def test_partition_and_gather_world4_and_world8_gloo_with_empty_ranks(world, lengths):
+    """The clip-sharded evaluation's collectives at the node's real rank counts (3DPW-test has only a few dozen
+    clips; H36M / a single video can have fewer clips than GPUs, so ranks with ZERO clips must take part in every collective)."""
+    mp.spawn(_worker_many, args=(world, _free_port(), lengths), nprocs=world, join=True)

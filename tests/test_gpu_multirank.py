@@ -36,6 +36,8 @@ def test_bench_starts_its_own_ranks_and_they_agree():
     assert all(x[3] == 1.0 for x in r['per_rank'])       # finite outputs on every rank
     assert abs(r['value'] - 2 * B * steps / (r['ms_per_step'] * steps / 1e3)) < 1e-6 * r['value']
     assert r['outputs_finite'] is True
+    # all_gather of the device identities: two ranks, ONE physical GPU here (an 8-GPU run must report 8)
+    assert r['n_ranks_seen'] == 1 and len(r['rank_devices']) == 2 and r['rank_devices'][0] == r['rank_devices'][1]
 
 
 def test_single_rank_bench_path_is_unchanged():
@@ -64,6 +66,8 @@ def test_clip_sharded_evaluation_runs_on_rccl_at_world_size_one():
     assert rccl['dist_backend'] == 'nccl' and rccl['n_gpus'] == 1
     assert rccl['metrics_mm'] == one['metrics_mm']         # same clips, same batches: the gathers only move the records
     assert rccl['per_rank']['clips'] == [7]
+    # the evaluation tool runs the weight collective too (both models: TePose and the VIBE bootstrap)
+    assert rccl['weight_broadcast_ms'] > 0 and 0 < rccl['weight_broadcast_MB'] < rccl['weight_blob_MB'] and rccl['n_ranks_seen'] == 1
 
 
 def test_clip_sharded_evaluation_world2_equals_world1():
@@ -76,6 +80,8 @@ def test_clip_sharded_evaluation_world2_equals_world1():
         # same clips, each processed whole on one rank: only the lock-step batch composition differs (rounding of
         # different kernels, amplified by the theta feedback of ~35 window steps)
         assert abs(one['metrics_mm'][k] - two['metrics_mm'][k]) < 2e-5 * abs(one['metrics_mm'][k]) + 1e-3, k
+    # rank 1 never loaded a weight: it ran on the blobs broadcast by rank 0 (TePose + VIBE), planes re-derived on its side
+    assert two['weight_broadcast_ms'] > 0 and two['n_ranks_seen'] == 1 and len(two['rank_devices']) == 2
     st = two['per_rank']
     assert len(st['seconds']) == 2 and sum(st['clips']) == 7 and sum(st['frames']) == two['frames']
     assert st['seconds_max_over_mean'] >= 1.0 and two['imbalance_max_over_mean_rank_frames'] >= 1.0

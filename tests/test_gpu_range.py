@@ -144,3 +144,102 @@ def test_cached_projection_driver_with_large_features(smpl_np):
         for k in ra:
             assert torch.isfinite(ra[k]).all() and torch.isfinite(rb[k]).all()
             assert (ra[k] - rb[k]).abs().max() < 5e-4, k      # both fp32-conditioned at this magnitude; they share the kernels
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Catastrophic cancellation ("error bound").  The split product's error is bounded relative to
+# sum_k |a_k w_k| -- 3 * 2^-22 from operand rounding and the dropped lo*lo term, plus the fp32 accumulation roundings -- exactly as an
+# fp32 fmaf chain's is (K * 2^-24).  Rows engineered so that |sum a w| is >= 1e4 times smaller than sum |a w| make that visible:
+# the RELATIVE error of such a dot product is 1e4 times the bound in any fp32 implementation.  The bar: the split kernels are
+# no further from fp64 than a small multiple of what the exact-fp32 kernel is on the same operands, and within the written bound.
+def _cancelling_operands(M, N, K, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    A = (torch.randn(M, K, device='cuda', generator=g).abs() * 0.5 + 0.05).float()          # features are non-negative
+    W = ((torch.rand(N, K, device='cuda', generator=g) * 2 - 1) * 0.03).float()
+    # entry (m, m % N) is made to cancel: the last operand of row m is solved for in fp64 and rounded to fp32
+    cols = torch.arange(M, device='cuda') % N
+    Wm = W[cols].double()                                               # [M, K]
+    part = (A[:, :-1].double() * Wm[:, :-1]).sum(1)
+    A[:, -1] = (-part / Wm[:, -1]).float()
+    return A, W, cols
+
+
+@pytest.mark.parametrize('h3s', ['0', '1', '2'])      # two-accumulator planes; scaled planes on 32x32x16; on 16x16x32
+def test_cancelling_dot_products_through_the_split_gemm(monkeypatch, h3s):
+    from tepose_amd import _lib
+    lib = _lib.load()
+    M, N, K = 4096, 768, 2144            # K = the layer-0 projection's (2133 padded)
+    A, W, cols = _cancelling_operands(M, N, K, 5)
+    # the last operand is large (it balances 2143 terms): keep it inside the fp16 range of the unscaled test entry
+    keep = A[:, -1].abs() < 200.0
+    ref = A.double() @ W.double().t()
+    mag = A.double().abs() @ W.double().abs().t()
+    idx = torch.arange(M, device='cuda')
+    ratio = (mag[idx, cols] / ref[idx, cols].abs().clamp_min(1e-30))[keep]
+    assert keep.sum() > M // 2 and ratio.median() > 1e4, (int(keep.sum()), float(ratio.median()))
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(fn_env):
+        for k, v in fn_env.items():
+            monkeypatch.setenv(k, v)
+        C = torch.full((M, N), float('nan'), device='cuda')
+        ws = torch.empty(lib.tepose_gemm_h3_workspace_bytes(M, N, K), dtype=torch.uint8, device='cuda')
+        assert lib.tepose_gemm_h3_f32(A.data_ptr(), K, W.data_ptr(), K, None, C.data_ptr(), N, M, N, K, ws.data_ptr(), ws.numel(), st) == 0
+        return C.double()
+    Cs = run({'TEPOSE_H3S': h3s})
+    Ce = torch.empty(M, N, device='cuda')
+    wse = torch.empty(lib.tepose_gemm_workspace_bytes(N, K), dtype=torch.uint8, device='cuda')
+    assert lib.tepose_gemm_f32(A.data_ptr(), K, W.data_ptr(), K, None, Ce.data_ptr(), N, M, N, K, 0, wse.data_ptr(), wse.numel(), st) == 0
+    Ce = Ce.double()
+    rows = idx[keep]
+    es = ((Cs - ref).abs() / mag)[rows]            # error relative to sum |a w|, every entry of the kept rows
+    ee = ((Ce - ref).abs() / mag)[rows]
+    # the written bound: 3 * 2^-22 (representation) + roundings * 2^-24 (accumulation; <= 3 K / 16 + 16 MFMA results per
+    # accumulator for the split kernels, K for the fmaf chain)
+    bound_split = 3 * 2.0 ** -22 + (3 * K / 16 + 16) * 2.0 ** -24
+    bound_exact = K * 2.0 ** -24
+    assert float(es.max()) <= bound_split, (float(es.max()), bound_split)
+    assert float(ee.max()) <= bound_exact, (float(ee.max()), bound_exact)
+    # ... and measured against each other: the split kernel is no worse than a small multiple of the fp32 chain, on the
+    # cancelling entries themselves and over all entries
+    canc_s = ((Cs - ref).abs() / mag)[idx, cols][keep]
+    canc_e = ((Ce - ref).abs() / mag)[idx, cols][keep]
+    assert float(canc_s.max()) <= 2.0 * float(canc_e.max()) + 3 * 2.0 ** -22, (float(canc_s.max()), float(canc_e.max()))
+    assert float(es.mean()) <= 2.0 * float(ee.mean()) + 2.0 ** -22, (float(es.mean()), float(ee.mean()))
+
+
+def test_cancelling_gate_preactivations_through_a_full_forward(smpl_np, monkeypatch):
+    """Layer-0 input weights built so that EVERY gate pre-activation of the three directions is a difference of two large sums:
+    W_ih[:, 1024:2048] = -(1 + 2^-9) W_ih[:, :1024] and the features repeat (x[1024:2048] = x[:1024]), so each of the 9 H dot
+    products cancels to 2^-9 of its magnitude (sum |a w| / |sum a w| ~ 1e4 .. 1e5).  Default (split) and exact-fp32 handles
+    against the fp64 oracle, through encoder, regressor and SMPL."""
+    from oracle import tepose_ref as O
+    from tepose_amd.testing import build_model
+    L, H, B, T = 2, 256, 2100, 4                        # B * T >= 8192: the scaled-plane projection and the fused GRU step kernels
+    state = {k: np.array(v, copy=True) for k, v in synth.synthetic_state_dict(L, H, 13).items()}
+    for name in ('encoder.gru_fwd.weight_ih_l0', 'encoder.gru_rec.weight_ih_l0', 'encoder.gru_rec.weight_ih_l0_reverse'):
+        w = state[name]
+        w[:, :1024] *= np.float32(24.0)                 # large halves: sum |a w| ~ 1e3 per gate row
+        w[:, 1024:2048] = -(np.float32(1.0) + np.float32(2.0 ** -9)) * w[:, :1024]
+    x = synth.synthetic_windows(B, T, 38)
+    x[:, :, 1024:2048] = x[:, :, :1024]
+    # how strongly do the layer-0 pre-activations cancel?  (fp64, a sample of rows)
+    w64 = torch.from_numpy(state['encoder.gru_fwd.weight_ih_l0']).double()
+    xs = torch.from_numpy(x[:64].reshape(-1, 2133)).double()
+    ratio = (xs.abs() @ w64.abs().t()) / (xs @ w64.t()).abs().clamp_min(1e-30)
+    assert float(ratio.median()) > 1e4, float(ratio.median())
+    J = smpl_np['J_regressor_h36m']
+    sub = np.r_[0:40, B - 24:B]                          # oracle rows (first tile and the ragged last one)
+    r64 = O.tepose_fwd(state, smpl_np, x[sub], L, J_regressor=J, dtype=torch.float64)
+    errs = {}
+    for mode, env in (('split', '0'), ('exact', '1')):
+        monkeypatch.setenv('TEPOSE_EXACT_FP32', env)
+        model, _, _ = build_model(L, H, seed=13, device='cuda', smpl_np=smpl_np, state=state)
+        with torch.no_grad():
+            out = model(torch.from_numpy(x).cuda(), J_regressor=torch.from_numpy(J))[0]
+        errs[mode] = {k: float((out[k][sub].cpu().double() - r64[k]).abs().max()) for k in ('verts', 'kp_3d', 'rotmat', 'theta')}
+        assert all(torch.isfinite(out[k]).all() for k in out)
+    monkeypatch.delenv('TEPOSE_EXACT_FP32')
+    for k in ('verts', 'kp_3d', 'rotmat'):
+        assert errs['split'][k] <= max(2e-5, 3.0 * errs['exact'][k]), (k, errs)
+        assert errs['split'][k] < 1e-4, (k, errs)

@@ -151,3 +151,51 @@ def test_persistent_kernels_can_be_switched_off_up_front(smpl_np, monkeypatch):
     assert not model._engine.uses_persistent(3)
     ref = _oracle(state, smpl_np, x, 2, None)
     assert np.abs(out['verts'].cpu().numpy() - ref['verts'].numpy()).max() < 1e-4
+
+
+def test_fault_is_attributed_to_the_forward_not_the_handle(smpl_np, monkeypatch):
+    """One handle, two streams, two workspaces (the re-entrancy the C header documents).  The forward on stream A gives up; the
+    forward on stream B -- a batch that launches no persistent kernel -- is queued before A's wait expires and is healthy.
+    tepose_forward_status answers per forward (the status words live in the workspace): B's caller, polling FIRST, gets 0 and
+    does not consume A's fault; A's caller gets TEPOSE_E_TIMEOUT exactly once.  (The handle-wide tepose_status would have handed
+    A's fault to whoever polls first: ADVICE r03.)  Engine.set_persistent(True) re-arms a degraded model."""
+    from tepose_amd import _lib
+    model, state = _faulty_model(monkeypatch, smpl_np, 1, mode='lazy')
+    eng, lib = model._engine, model._engine.lib
+    T, BA, BB = 5, 3, 200
+    xa = torch.from_numpy(synth.synthetic_windows(BA, T, 14)).cuda()
+    xb = torch.from_numpy(synth.synthetic_windows(BB, T, 15)).cuda()
+    with torch.no_grad():
+        model(xb)                                                   # packs; B = 200 runs no persistent kernel, so no fault
+    eng.check_status()
+    assert eng.uses_persistent(BA) and not eng.uses_persistent(BB)
+
+    def buffers(B):
+        ws = torch.empty(int(lib.tepose_workspace_bytes(eng.handle, B, T)), dtype=torch.uint8, device='cuda')
+        return ws, eng._outputs(B, 49, xa.device)
+
+    wsa, oa = buffers(BA)
+    wsb, ob = buffers(BB)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def fwd(x, B, ws, o, st):
+        return lib.tepose_forward(eng.handle, x.data_ptr(), B, T, None, o['theta'].data_ptr(), o['verts'].data_ptr(), o['kp_3d'].data_ptr(),
+                                  o['kp_2d'].data_ptr(), o['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(), st.cuda_stream)
+    assert fwd(xa, BA, wsa, oa, sa) == 0                            # will give up after its bounded wait (~20 ms)
+    assert fwd(xb, BB, wsb, ob, sb) == 0                            # queued before the fault word is raised: not refused
+    assert lib.tepose_forward_status(eng.handle, wsb.data_ptr(), sb.cuda_stream) == 0          # B polls first ...
+    assert torch.isfinite(ob['verts']).all()
+    assert lib.tepose_forward_status(eng.handle, wsa.data_ptr(), sa.cuda_stream) == _lib.E_TIMEOUT   # ... A's fault is still A's
+    assert not torch.isfinite(oa['verts']).all()
+    assert lib.tepose_forward_status(eng.handle, wsa.data_ptr(), sa.cuda_stream) == 0          # once
+    assert lib.tepose_status_peek(eng.handle) == 0                  # and the handle is usable again
+    ref = _oracle(state, smpl_np, xb.cpu().numpy()[:8], 2, None)
+    assert np.abs(ob['verts'][:8].cpu().numpy() - ref['verts'].numpy()).max() < 1e-4
+    # the remedy and the way back
+    eng.set_persistent(False)
+    assert not eng.uses_persistent(BA)
+    assert fwd(xa, BA, wsa, oa, sa) == 0 and lib.tepose_forward_status(eng.handle, wsa.data_ptr(), sa.cuda_stream) == 0
+    assert torch.isfinite(oa['verts']).all()
+    eng.set_persistent(True)
+    assert eng.uses_persistent(BA) and not eng.degraded

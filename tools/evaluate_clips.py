@@ -75,21 +75,40 @@ def main():
         lens = (args.min_len + (args.max_len - args.min_len) * synth.uniform01('evalclips', args.clips)).astype(int)
         db, pse = synthetic_eval_db(list(lens), seed=0)
         clips = split_db_into_clips(db, pse)
-    model, _, _ = build_model(args.layers, args.hidden, seed=0, device=dev, smpl_np=smpl_np, seqlen=T)
+    # Weights: rank 0 loads (checkpoint files or the synthetic state dicts) and packs; every other rank constructs the bare
+    # architecture and adopts rank 0's blob from the RCCL broadcast (tepose_amd.distributed.broadcast_model_weights: the fp32
+    # sections travel, the hi / lo planes are re-derived per GPU) -- the collective SURVEY 8e / the north star name.
+    mean_t = synth.synthetic_mean_params(0)
     vstate = synth.synthetic_vibe_state_dict(args.layers, args.hidden, 1)
-    mean = {'pose': vstate['regressor.init_pose'][0], 'shape': vstate['regressor.init_shape'][0],
-            'cam': vstate['regressor.init_cam'][0]}
-    vibe = VIBE(seqlen=T, n_layers=args.layers, hidden_size=args.hidden, add_linear=True, use_residual=True, pretrained='',
-                smpl=SMPL.from_tables(smpl_np), smpl_mean_params=mean)
-    sd = vibe.state_dict()
-    for k, v in vstate.items():
-        sd[k] = torch.from_numpy(v)
-    vibe.load_state_dict(sd)
-    if args.ckpt:
-        model.load_state_dict(load_generator_state_dict(args.ckpt), strict=True)          # evaluate.py:121-124
-    if args.vibe_ckpt:
-        vibe.load_state_dict(load_generator_state_dict(args.vibe_ckpt), strict=False)     # evaluate.py:103-105
+    mean_v = {'pose': vstate['regressor.init_pose'][0], 'shape': vstate['regressor.init_shape'][0],
+              'cam': vstate['regressor.init_cam'][0]}
+    if rank == 0 or not use_dist:
+        model, _, _ = build_model(args.layers, args.hidden, seed=0, device=dev, smpl_np=smpl_np, seqlen=T)
+        vibe = VIBE(seqlen=T, n_layers=args.layers, hidden_size=args.hidden, add_linear=True, use_residual=True, pretrained='',
+                    smpl=SMPL.from_tables(smpl_np), smpl_mean_params=mean_v)
+        sd = vibe.state_dict()
+        for k, v in vstate.items():
+            sd[k] = torch.from_numpy(v)
+        vibe.load_state_dict(sd)
+        if args.ckpt:
+            model.load_state_dict(load_generator_state_dict(args.ckpt), strict=True)          # evaluate.py:121-124
+        if args.vibe_ckpt:
+            vibe.load_state_dict(load_generator_state_dict(args.vibe_ckpt), strict=False)     # evaluate.py:103-105
+    else:
+        from tepose_amd.tepose import TePose
+        model = TePose(seqlen=T, n_layers=args.layers, hidden_size=args.hidden, pretrained='', smpl=SMPL.from_tables(smpl_np),
+                       smpl_mean_params=mean_t).to(dev).eval()
+        vibe = VIBE(seqlen=T, n_layers=args.layers, hidden_size=args.hidden, add_linear=True, use_residual=True, pretrained='',
+                    smpl=SMPL.from_tables(smpl_np), smpl_mean_params=mean_v)
     vibe = vibe.to(dev).eval()
+    bcast = None
+    if use_dist:
+        from tepose_amd.distributed import broadcast_model_weights, count_distinct_devices
+        b1 = broadcast_model_weights(model, src=0)
+        b2 = broadcast_model_weights(vibe, src=0)
+        n_seen, rank_devs = count_distinct_devices(dev)
+        bcast = {'weight_broadcast_ms': b1['ms'] + b2['ms'], 'weight_broadcast_MB': (b1['bytes'] + b2['bytes']) / 1e6,
+                 'weight_blob_MB': (b1['blob_bytes'] + b2['blob_bytes']) / 1e6, 'n_ranks_seen': n_seen, 'rank_devices': rank_devs}
     J = torch.from_numpy(smpl_np['J_regressor_h36m']) if args.dataset != 'mpii3d' else None
     torch.cuda.synchronize()
     if use_dist:
@@ -116,6 +135,7 @@ def main():
                'data': 'real' if args.db else 'synthetic db + random-init weights (metric values are meaningless)'}
         if use_dist:
             out['dist_backend'] = dist.get_backend()
+            out.update(bcast)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
