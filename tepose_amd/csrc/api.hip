@@ -1290,7 +1290,9 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
   const bool seq = h3 && !sf && w.sync && persist_on(m) && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
   const size_t gran_bytes = seq_gran_words(m, B) * sizeof(float);
-  if (seq && !sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
+  // every forward clears its sync region -- arrival counters, granules, and the two STATUS words that tepose_forward_status
+  // reads -- whether or not a persistent kernel will run (a stale or uninitialised status word would read as a give-up)
+  if (!sync_zeroed && w.sync) CK(hipMemsetAsync(w.sync, 0, seq ? sync_zero_bytes(m, B) : sync_words(m) * sizeof(unsigned), s));
   for (int l = 0; l < L; ++l) {
     const bool top = l == L - 1;
     float* sf = w.sf[l & 1];
@@ -1696,9 +1698,12 @@ int tepose_forward_cached(const tepose_model* m, const float* ring_base, int rin
   if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
   if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  float* feat = (float*)workspace;
-  char* rest = (char*)workspace + align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
-  const size_t rest_bytes = ws_bytes - (size_t)(rest - (char*)workspace);
+  // [shared scratch | feature]: the scratch comes FIRST, so that its first carve -- the sync region with the forward's status
+  // words -- sits at the workspace base for every entry point (tepose_forward_status reads it there)
+  const size_t feat_bytes = align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
+  char* rest = (char*)workspace;
+  const size_t rest_bytes = (ws_bytes & ~(size_t)255) - feat_bytes;
+  float* feat = (float*)(rest + rest_bytes);
   Carver c(rest, rest_bytes);
   EncWs w;
   carve_encoder(m, B, T, c, w);
@@ -1709,7 +1714,7 @@ int tepose_forward_cached(const tepose_model* m, const float* ring_base, int rin
   int rc = encoder_core(m, src, B, T, 0, feat, w, s, nullptr, false, col ? feat : nullptr);
   if (rc) return rc;
   return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
-                        rest_bytes, stream, false, false, col ? feat : nullptr);
+                        rest_bytes, stream, false, true, col ? feat : nullptr);    // (encoder_core cleared the shared sync region)
 }
 
 int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter, const void* jreg_packed,
@@ -1742,6 +1747,9 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   const float* Bl = m->blob;
+  // a stand-alone regressor call clears its sync region (counters + the status words tepose_forward_status reads); inside
+  // tepose_forward / tepose_forward_cached the encoder part has done it (sync_zeroed) and may have left a give-up there
+  if (!sync_zeroed && w.sync) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
   // xc = cat[x, pose, shape, cam]; fc1(xc) = x W1a^T + b1 (iteration-invariant) + state W1b^T
   if (xs_ready) {
     // the encoder's last product already produced the final state rows (collapsed regressor + tail)
@@ -1753,7 +1761,6 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   } else if (w.split_fc && N <= reg_seq_max_n() && persist_on(m)) {
     // small batches: the whole FC loop in one persistent launch (reg_seq.hip)
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
-    if (!sync_zeroed) CK(hipMemsetAsync(w.sync, 0, sync_words(m) * sizeof(unsigned), s));
     RegSeqArgs ra{};
     ra.fh = w.featP.hi; ra.fl = w.featP.lo; ra.f_kst = w.featP.kst;
     const half_t* p;
@@ -1830,10 +1837,13 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
   if (!m || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
   if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
   if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
-  // [feature | shared scratch]: the encoder's scratch is dead once `feat` exists
-  float* feat = (float*)workspace;
-  char* rest = (char*)workspace + align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
-  const size_t rest_bytes = ws_bytes - (size_t)(rest - (char*)workspace);
+  // [shared scratch | feature]: the encoder's scratch is dead once `feat` exists; the scratch comes FIRST, so that its first
+  // carve -- the sync region with the forward's status words -- sits at the workspace base for every entry point
+  // (tepose_forward_status reads it there)
+  const size_t feat_bytes = align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
+  char* rest = (char*)workspace;
+  const size_t rest_bytes = (ws_bytes & ~(size_t)255) - feat_bytes;
+  float* feat = (float*)(rest + rest_bytes);
   // the regressor's first A operand (planes of the feature) is written by the encoder's tail product
   RegWs rw;
   {

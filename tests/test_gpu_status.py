@@ -155,7 +155,7 @@ def test_persistent_kernels_can_be_switched_off_up_front(smpl_np, monkeypatch):
 
 def test_fault_is_attributed_to_the_forward_not_the_handle(smpl_np, monkeypatch):
     """One handle, two streams, two workspaces (the re-entrancy the C header documents).  The forward on stream A gives up; the
-    forward on stream B -- a batch that launches no persistent kernel -- is queued before A's wait expires and is healthy.
+    forward on stream B -- a batch that launches no persistent kernel -- runs concurrently and is healthy.
     tepose_forward_status answers per forward (the status words live in the workspace): B's caller, polling FIRST, gets 0 and
     does not consume A's fault; A's caller gets TEPOSE_E_TIMEOUT exactly once.  (The handle-wide tepose_status would have handed
     A's fault to whoever polls first: ADVICE r03.)  Engine.set_persistent(True) re-arms a degraded model."""
@@ -182,8 +182,8 @@ def test_fault_is_attributed_to_the_forward_not_the_handle(smpl_np, monkeypatch)
     def fwd(x, B, ws, o, st):
         return lib.tepose_forward(eng.handle, x.data_ptr(), B, T, None, o['theta'].data_ptr(), o['verts'].data_ptr(), o['kp_3d'].data_ptr(),
                                   o['kp_2d'].data_ptr(), o['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(), st.cuda_stream)
-    assert fwd(xa, BA, wsa, oa, sa) == 0                            # will give up after its bounded wait (~20 ms)
-    assert fwd(xb, BB, wsb, ob, sb) == 0                            # queued before the fault word is raised: not refused
+    assert fwd(xb, BB, wsb, ob, sb) == 0                            # healthy; queued first (an entry point refuses once the word is up)
+    assert fwd(xa, BA, wsa, oa, sa) == 0                            # gives up after its bounded wait (~20 ms), concurrently with B
     assert lib.tepose_forward_status(eng.handle, wsb.data_ptr(), sb.cuda_stream) == 0          # B polls first ...
     assert torch.isfinite(ob['verts']).all()
     assert lib.tepose_forward_status(eng.handle, wsa.data_ptr(), sa.cuda_stream) == _lib.E_TIMEOUT   # ... A's fault is still A's
