@@ -534,6 +534,29 @@ def main():
                 run_clips(model, feats, init, t, keep=('theta', 'verts', 'kp_3d'))
                 torch.cuda.synchronize()
                 extra['cfgE_stream_per_frame_ms' if t == 32 else 'stream_T16_per_frame_ms'] = (time.perf_counter() - te) / (nfr - t + 1) * 1e3
+            # config 5 as a LIVE stream: frames arrive one at a time on the host (tepose_amd.stream.StreamSession: one captured
+            # hipGraph replay per frame -- H2D of the feature, window shift, forward, theta feedback, D2H of the results).
+            # Latency = host clock from "the frame's feature is in host memory" to "theta / kp_3d / verts are readable in
+            # (pinned) host memory"; every frame waits for its own result, nothing is queued ahead.
+            from tepose_amd.stream import StreamSession
+            for t in (32, 16):
+                nfr = 400 + t
+                wv = synthetic_windows_device(1, nfr, 6, device)[0].cpu()
+                for keep in (('theta', 'kp_3d', 'verts'), ('theta', 'kp_3d')):
+                    ses = StreamSession(model, t, wv[:t - 1, :2048].contiguous(), wv[:t - 1, 2048:].contiguous(), J_regressor=None, keep=keep)
+                    lat = []
+                    for fidx in range(t - 1, nfr):
+                        f = wv[fidx, :2048]
+                        te = time.perf_counter()
+                        ses.push(f)
+                        lat.append((time.perf_counter() - te) * 1e3)
+                    lat = sorted(lat[20:])
+                    key = ('cfgE_live_stream_T32' if t == 32 else 'live_stream_T16') + ('' if 'verts' in keep else '_without_verts')
+                    extra[key] = {'arrival_to_host_ms_p50': lat[len(lat) // 2], 'arrival_to_host_ms_p99': lat[int(len(lat) * 0.99)],
+                                  'arrival_to_host_ms_min': lat[0], 'arrival_to_host_ms_max': lat[-1], 'frames': len(lat),
+                                  'results_to_host': list(keep),
+                                  'how': 'StreamSession.push: one hipGraph replay + one event wait per frame, pinned host rows'}
+                    del ses
             extra['note'] = ('BASELINE.json configs 1 / 2 / 5 (synthetic stand-ins: random-init weights, synthetic features; the '
                              'licence-gated 3DPW data and repr_wpw_3dpw checkpoint are absent, so MPJPE vs that checkpoint is '
                              'UNMEASURED); the recurrent layers and the regressor loop run as persistent kernels '

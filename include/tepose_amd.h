@@ -181,6 +181,10 @@ int tepose_status(tepose_model* m, void* stream);
 int tepose_status_peek(const tepose_model* m);
 int tepose_set_persistent(tepose_model* m, int on);
 int tepose_uses_persistent(const tepose_model* m, int B, int T);
+/* Tests only: what TEPOSE_TEST_FAULT sets at tepose_create (bit 0 / 1: the waits of the persistent recurrent / regressor
+ * kernels launched from now on expect an arrival that never comes), changeable on a live handle -- e.g. between the warm-up
+ * and the capture of a hipGraph, so that the give-up happens inside a replay (tests/test_gpu_stream.py).                  */
+int tepose_debug_set_test_fault(tepose_model* m, unsigned bits);
 
 /* ---- sliding-window driver with cached layer-0 projections ---------------
  * Consecutive windows of a clip share T-1 frames, and a frame's layer-0 gate pre-activations

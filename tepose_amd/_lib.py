@@ -5,7 +5,7 @@ fails with instructions, and every non-zero return code raises.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+from ctypes import c_uint, POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = (os.environ.get("TEPOSE_AMD_LIB") or os.path.join(_HERE, 'libtepose_hip.so'))   # override: A/B builds
@@ -22,7 +22,7 @@ SYMBOLS = [
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
     'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
-    'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info',
+    'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info', 'tepose_debug_set_test_fault',
 ]
 
 _lib = None
@@ -107,6 +107,7 @@ def load():
     lib.tepose_derive_planes.argtypes = [c_void_p, c_void_p]
     lib.tepose_status.argtypes = [c_void_p, c_void_p]
     lib.tepose_forward_status.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.tepose_debug_set_test_fault.argtypes = [c_void_p, c_uint]
     lib.tepose_status_peek.argtypes = [c_void_p]
     lib.tepose_set_persistent.argtypes = [c_void_p, c_int]
     lib.tepose_uses_persistent.argtypes = [c_void_p, c_int, c_int]

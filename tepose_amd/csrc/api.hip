@@ -731,6 +731,12 @@ int tepose_set_persistent(tepose_model* m, int on) {
   return 0;
 }
 
+int tepose_debug_set_test_fault(tepose_model* m, unsigned bits) {
+  if (!m) return TEPOSE_E_ARG;
+  m->test_fault = bits;
+  return 0;
+}
+
 int tepose_uses_persistent(const tepose_model* m, int B, int T) {
   if (!m || B < 1) return 0;
   if (!persist_on(m) || !m->split || B <= split_min_m()) return 0;

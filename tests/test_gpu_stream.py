@@ -1,0 +1,127 @@
+"""GPU: the frame-at-a-time live-stream session (tepose_amd/stream.py; reference loop demo.py:238-252, BASELINE config 5).
+`StreamSession.push(feature)` = one captured hipGraph replay per arriving frame; it must reproduce the clip-at-once driver
+(`run_clips`, itself pinned by the reference-loop goldens) bit for bit, stay within 1e-4 of the reference golden through the
+theta feedback, and survive a give-up of the persistent kernels inside a replayed graph."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tepose_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def smpl_np():
+    return synth.synthetic_smpl(0)
+
+
+def _stream_clip(model, w, theta_init, T, J, graph=True, keep=('theta', 'kp_3d', 'verts')):
+    from tepose_amd.stream import StreamSession
+    feats = torch.from_numpy(w[:, :2048].copy())
+    ses = StreamSession(model, T, feats[:T - 1], torch.from_numpy(theta_init), J_regressor=J, keep=keep, graph=graph)
+    out = {k: [] for k in keep}
+    for f in feats[T - 1:]:
+        r = ses.push(f)
+        for k in keep:
+            out[k].append(r[k].clone())
+    return {k: torch.stack(v) for k, v in out.items()}, ses
+
+
+@pytest.mark.parametrize('name', ['driver_L2H128_N40T6', 'driver_L1H64_N9T4'])
+def test_stream_session_equals_run_clips_and_the_reference_golden(name, smpl_np):
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    L, H, N, T, seed_w, seed_x = [int(v) for v in g['meta']]
+    model, _, _ = build_model(L, H, seed=seed_w, device='cuda', smpl_np=smpl_np)
+    w = synth.synthetic_windows(1, N, seed_x)[0]
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    ref = run_clips(model, [torch.from_numpy(w[:, :2048].copy())], [torch.from_numpy(g['theta_init'])], T, J_regressor=J,
+                    keep=('theta', 'kp_3d', 'verts'))[0]
+    got, ses = _stream_clip(model, w, g['theta_init'], T, J)
+    assert ses.graph is not None and ses.frames == N - T + 1
+    for k in ('theta', 'kp_3d', 'verts'):
+        assert torch.equal(got[k], ref[k].cpu()), k                       # same forward on the same window, frame after frame
+    assert np.abs(got['kp_3d'].numpy() - g['kp_3d']).max() < 1e-4         # 35 feedback steps against the reference's own loop
+    assert np.abs(got['verts'].numpy()[:, ::53] - g['verts_sub']).max() < 1e-4
+    assert np.abs(got['theta'].numpy()[:, :3] - g['theta'][:, :3]).max() < 1e-4
+    assert np.abs(got['theta'].numpy()[:, 75:] - g['theta'][:, 75:]).max() < 1e-4
+    # the same session without a graph (eager step) gives the same bits
+    eager, ses2 = _stream_clip(model, w, g['theta_init'], T, J, graph=False)
+    assert ses2.graph is None
+    for k in got:
+        assert torch.equal(eager[k], got[k]), k
+
+
+def test_stream_session_at_the_live_stream_configuration(smpl_np):
+    """BASELINE config 5: seqlen 32, batch 1, the published architecture (n_layers 2, hidden 1024), no joint regressor
+    (demo.py passes none: 49 joints)."""
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    T, N = 32, 56
+    model, _, _ = build_model(2, 1024, seed=3, device='cuda', smpl_np=smpl_np, seqlen=T)
+    w = synth.synthetic_windows(1, N, 77)[0]
+    th0 = w[:T - 1, 2048:].copy()
+    ref = run_clips(model, [torch.from_numpy(w[:, :2048].copy())], [torch.from_numpy(th0)], T, keep=('theta', 'kp_3d'))[0]
+    got, ses = _stream_clip(model, w, th0, T, None, keep=('theta', 'kp_3d'))
+    assert got['kp_3d'].shape == (N - T + 1, 49, 3)
+    for k in got:
+        assert torch.isfinite(got[k]).all()
+        assert torch.equal(got[k], ref[k].cpu()), k
+
+
+def test_a_give_up_inside_the_replayed_graph_is_repaired(smpl_np, monkeypatch):
+    """The persistent recurrent launches of this handle start giving up AFTER the session's graph has been captured (the test
+    hook is set between warm-up and capture), so the first replay returns NaN.  push notices (fault word after its wait),
+    switches the model to the step kernels, re-captures, recomputes the frame from the saved window: the stream's results equal
+    a healthy model's run to rounding and are never NaN."""
+    from tepose_amd.driver import run_clips
+    from tepose_amd.stream import StreamSession
+    from tepose_amd.testing import build_model
+    L, H, T, N = 2, 256, 6, 14
+    good, _, _ = build_model(L, H, seed=21, device='cuda', smpl_np=smpl_np)
+    monkeypatch.setenv('TEPOSE_SEQ_SPIN_LIMIT', '20000')         # ~20 ms instead of ~2 s per give-up
+    bad, _, _ = build_model(L, H, seed=21, device='cuda', smpl_np=smpl_np)
+    monkeypatch.delenv('TEPOSE_SEQ_SPIN_LIMIT')
+    w = synth.synthetic_windows(1, N, 78)[0]
+    th0 = w[:T - 1, 2048:].copy()
+    feats = torch.from_numpy(w[:, :2048].copy())
+    ref = run_clips(good, [feats], [torch.from_numpy(th0)], T, keep=('theta', 'verts'))[0]
+    ses = StreamSession(bad, T, feats[:T - 1], torch.from_numpy(th0), keep=('theta', 'verts'), graph=False)   # healthy warm-up
+    eng = bad._engine
+    assert eng.uses_persistent(1) and not eng.degraded
+    assert eng.lib.tepose_debug_set_test_fault(eng.handle, 1) == 0
+    ses.use_graph = True
+    with torch.no_grad(), torch.cuda.stream(ses.stream):
+        ses._capture()                                            # kernel arguments (the unmeetable wait) are baked in here
+    ses.stream.synchronize()
+    assert eng.lib.tepose_debug_set_test_fault(eng.handle, 0) == 0   # (the re-captured graph uses the step kernels anyway)
+    for j, f in enumerate(feats[T - 1:]):
+        if j == 0:
+            with pytest.warns(RuntimeWarning, match='gave up'):
+                r = ses.push(f)
+            assert eng.degraded
+        else:
+            r = ses.push(f)
+        assert torch.isfinite(r['verts']).all()
+        assert (r['verts'] - ref['verts'][j].cpu()).abs().max() < 2e-5      # step kernels vs persistent kernels: rounding
+        assert (r['theta'] - ref['theta'][j].cpu()).abs().max() < 2e-5
+
+
+def test_a_give_up_during_session_setup_is_repaired_too(smpl_np, monkeypatch):
+    from tepose_amd.stream import StreamSession
+    from tepose_amd.testing import build_model
+    monkeypatch.setenv('TEPOSE_TEST_FAULT', '1')
+    monkeypatch.setenv('TEPOSE_SEQ_SPIN_LIMIT', '20000')
+    bad, _, _ = build_model(2, 256, seed=21, device='cuda', smpl_np=smpl_np)
+    monkeypatch.delenv('TEPOSE_TEST_FAULT')
+    monkeypatch.delenv('TEPOSE_SEQ_SPIN_LIMIT')
+    w = synth.synthetic_windows(1, 9, 79)[0]
+    with pytest.warns(RuntimeWarning, match='gave up'):
+        ses = StreamSession(bad, 6, torch.from_numpy(w[:5, :2048].copy()), torch.from_numpy(w[:5, 2048:].copy()), keep=('theta',))
+    assert bad._engine.degraded
+    assert torch.isfinite(ses.push(torch.from_numpy(w[5, :2048].copy()))['theta']).all()
