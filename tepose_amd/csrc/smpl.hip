@@ -365,6 +365,21 @@ hipError_t launch_lbs_compact(const float* lbsW, int* cidx, float* cval, int* ma
 // thread = vertex with its <= 4 (joint, weight) pairs in registers; persons looped; the 4 joint
 // transforms are gathered from the LDS copy of A (3 x 16-byte reads per joint).  HBM-bound:
 // 12 B in + 12 B out per (person, vertex).
+#ifndef TEPOSE_SKIN_DIAG
+#define TEPOSE_SKIN_DIAG 0   // diagnostic builds only (tools/race_probe_smpl_diag.py): every wave of the skinning
+#endif                       // kernel records when it ran and where (s_memrealtime at entry / exit, HW_ID at entry / exit)
+#if TEPOSE_SKIN_DIAG
+__device__ unsigned tepose_skin_check_buf[16 + 64 * 32];
+extern "C" int tepose_debug_skin_check(unsigned* host, int n, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tepose_skin_check_buf), (size_t)n * 4);
+  if (reset) { unsigned z = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(tepose_skin_check_buf), &z, 4); }
+  return rc;
+}
+__device__ unsigned long long tepose_skin_diag_buf[64 * 27 * 4 * 4];
+extern "C" int tepose_debug_skin_diag(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tepose_skin_diag_buf), (size_t)n * 8);
+}
+#endif
 __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__ cidx,
                                                          const float* __restrict__ cval,
                                                          const float* __restrict__ vposed,
@@ -372,6 +387,10 @@ __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__
                                                          float* __restrict__ verts, int pg) {
   __shared__ __attribute__((aligned(16))) float As[kNJ * 12];
   typedef float f4 __attribute__((ext_vector_type(4)));
+#if TEPOSE_SKIN_DIAG
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned diag_hw0 = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID, all 32 bits
+#endif
   const int v = blockIdx.x * 256 + threadIdx.x;
   const bool ok = v < kNV;
   int jx[4];
@@ -400,8 +419,41 @@ __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__
       o[0] = t[0] * x + t[1] * y + t[2] * z + t[3];
       o[1] = t[4] * x + t[5] * y + t[6] * z + t[7];
       o[2] = t[8] * x + t[9] * y + t[10] * z + t[11];
+#if TEPOSE_SKIN_DIAG >= 2
+      // self-check: the first row of the blended transform again, from a SECOND read of the LDS copy and with scalar FMAs the
+      // compiler cannot pack (asm); a lane whose packed accumulators differ records what it saw
+      {
+        float u[4] = {0.f, 0.f, 0.f, 0.f};
+        f4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          q[k] = *(volatile const f4*)(As + jx[k]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(u[e]) : "v"(wv[k]), "v"(q[k][e]));
+        }
+        const bool diff = __float_as_uint(u[0]) != __float_as_uint(t[0]) || __float_as_uint(u[1]) != __float_as_uint(t[1]) ||
+                          __float_as_uint(u[2]) != __float_as_uint(t[2]) || __float_as_uint(u[3]) != __float_as_uint(t[3]);
+        if (diff) {
+          const unsigned slot = atomicAdd(&tepose_skin_check_buf[0], 1u);
+          if (slot < 64) {
+            unsigned* d = tepose_skin_check_buf + 16 + slot * 32;
+            d[0] = (unsigned)p; d[1] = (unsigned)v;
+            for (int e = 0; e < 4; ++e) { d[2 + e] = __float_as_uint(t[e]); d[6 + e] = __float_as_uint(u[e]); }
+            for (int k = 0; k < 4; ++k) { d[10 + k] = __float_as_uint(wv[k]); d[14 + k] = (unsigned)jx[k]; d[18 + k] = __float_as_uint(q[k][0]); }
+          }
+        }
+      }
+#endif
     }
   }
+#if TEPOSE_SKIN_DIAG
+  if ((threadIdx.x & 63) == 0 && blockIdx.y < 64) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw1 = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    unsigned long long* d = tepose_skin_diag_buf + (((size_t)blockIdx.y * 27 + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4;
+    d[0] = diag_t0; d[1] = t1; d[2] = diag_hw0; d[3] = hw1;
+  }
+#endif
 }
 
 hipError_t launch_smpl_skin(const SmplConsts& c, const float* vposed, const float* Amat, int N,
