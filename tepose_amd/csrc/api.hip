@@ -50,10 +50,11 @@ struct tepose_model {
   bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
   bool gru_single_acc = true;                   // large batches: layer >= 1 projections and GRU steps on it too
   std::string kinfo;                            // tepose_kernel_info(): the kernel symbols the knobs select for the dominant launches
-  int mfma16 = 1;                               // TEPOSE_MFMA16 bit mask: 1 = plain scaled-plane products (default since round 4:
-                                                // -3 % on the projections, the chip holds 1.88 instead of 1.66 GHz), 2 = fused GRU
-                                                // step (measured neutral: 1.99 vs 1.74 GHz but 0.50 vs 0.57 busy) on
-                                                // v_mfma_f32_16x16x32_f16 (gemm_h3s16.hip) instead of 32x32x16
+  int mfma16 = 5;                               // TEPOSE_MFMA16 bit mask, kernels on v_mfma_f32_16x16x32_f16 (gemm_h3s16.hip) instead of
+                                                // 32x32x16: 1 = plain scaled-plane products (default since round 4: -3 % on the
+                                                // projections, the chip holds 1.88 instead of 1.66 GHz); 2 = fused GRU step as eight
+                                                // waves of 32 x 96 (neutral: 1.99 vs 1.74 GHz but 0.50 vs 0.57 busy); 4 = fused GRU
+                                                // step as four waves of 64 x 96 with streamed W fragments (default: -4 %)
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
@@ -523,7 +524,7 @@ static void read_env_knobs(tepose_model* m) {
   e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
   m->gru_single_acc = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_MFMA16");                      // MFMA shape of the scaled-plane kernels (bit 1: plain products, bit 2: GRU step)
-  m->mfma16 = e ? atoi(e) : 1;
+  m->mfma16 = e ? atoi(e) : 5;
   e = getenv("TEPOSE_COLLAPSE_REGRESSOR");          // 0: the regressor's FC loop is always run as a loop
   m->collapse_env = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
@@ -547,7 +548,7 @@ static void read_env_knobs(tepose_model* m) {
              ";gru_step=" +
              (!m->split ? "gru_step_kernel"
               : !m->gru_single_acc ? "gemm_h3_kernel"
-              : (m->mfma16 & 2) ? "gru_h3s16_kernel<0>"
+              : (m->mfma16 & 4) ? "gru_h3s16_kernel<0, 2>" : (m->mfma16 & 2) ? "gru_h3s16_kernel<0, 4>"
               : (gp && atoi(gp) != 0) ? "gru_h3s_persist_kernel<0>" : "gemm_h3s_kernel<1, 3, 4, 2, true, 4>");
 }
 
@@ -1256,7 +1257,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           const half_t* sh = (const half_t*)(Bl + dw[d]->whh_s);
           b.p[d] = H3SArgs{vi.hi, vi.lo, vi.kst, sh, sh + r384 * Hp, (long)r384 * 16, Hp, nullptr, 0, nullptr,
                            1.f / (kStateScale * dw[d]->whh_scale), B, H3};
-          b.p[d].shape16 = (m->mfma16 >> 1) & 1;
+          b.p[d].shape16 = (m->mfma16 & 4) ? 2 : ((m->mfma16 >> 1) & 1);      // 2: the four-wave form of the 16x16x32 step
         }
       }
       if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s, 1);

@@ -325,13 +325,16 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int 
 // pre-activations / previous state, one 16-byte state store, two 8-byte plane stores, with NO turn through LDS (the 32x32x16
 // form stages every accumulator through the idle ring to get there: 3 x 16 ds_write_b32 + 12 ds_read_b128 per 32-row fragment
 // and a workgroup barrier).
-template <int TAG>
-__global__ void __launch_bounds__(512) gru_h3s16_kernel(H3SBatch batch, int tilesM, int tilesN) {
-  constexpr int NWN = 2, NW = 8, NST = 4, MT = 2, NT = 6;  // wave = 2 row tiles x (3 gates x 2 unit tiles) of 16 x 16
+// NWM = 4: eight waves of 32 rows x 96 columns (122 VGPRs, four waves per SIMD with two workgroups per CU).  NWM = 2 (round 4): FOUR
+// waves of 64 x 96 -- 20 fragment reads per 72 MFMAs instead of 16 per 36, i.e. 160 + 80 KB of LDS traffic per pair of stages and CU
+// instead of 256 + 80 (the eight-wave form is LDS-bound: 2688 LDS cycles against 2304 MFMA cycles per pair and CU), two waves per SIMD.
+template <int TAG, int NWM>
+__global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(H3SBatch batch, int tilesM, int tilesN) {
+  constexpr int NWN = 2, NW = NWM * NWN, NST = 4, MT = 8 / NWM, NT = 6;  // wave = MT row tiles x (3 gates x 2 unit tiles) of 16 x 16
   constexpr int HM = 128, HN = 192, HK = 16, RB = HK * 2, RPI = 1024 / RB;
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;            // 20 KB
   constexpr int TOT = STAGE / 1024, Q = TOT / NW, REM = TOT % NW;   // 20 instructions per stage: waves < 4 issue 3, the others 2
-  static_assert(STAGE % 1024 == 0 && NST * STAGE <= 80 * 1024 && 4 * (Q + 1) <= 63, "ring / vmcnt budget");
+  static_assert(STAGE % 1024 == 0 && NST * STAGE <= 80 * 1024 && 4 * (Q + (REM ? 1 : 0)) <= 63, "ring / vmcnt budget");
   typedef _Float16 h16x4q __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
   const H3SArgs& a = batch.p[blockIdx.y];
@@ -341,6 +344,7 @@ __global__ void __launch_bounds__(512) gru_h3s16_kernel(H3SBatch batch, int tile
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int t = lane & 15, g = lane >> 4;
+  static_assert(NWM == 4 || NWM == 2, "eight or four waves");
   const int nd = Q + (wave < REM ? 1 : 0);
   const int i0 = wave * Q + min(wave, REM);
 
@@ -391,13 +395,72 @@ __global__ void __launch_bounds__(512) gru_h3s16_kernel(H3SBatch batch, int tile
   request_pair(0);
   request_pair(1);
   // NEWER: pairs younger than pair p whose requests may stay in flight (1, or 0 at the last pair)
-  auto pairstep = [&](int p, auto dma, auto newer) __attribute__((always_inline)) {
+  // EXTRA: other vector-memory instructions younger than the pairs' requests that may stay in flight (the L2 touches below)
+  auto pairstep = [&](int p, auto dma, auto newer, auto extra) __attribute__((always_inline)) {
     constexpr bool DMA = decltype(dma)::value;
-    constexpr int NEWER = decltype(newer)::value;
-    if (REM && wave < REM) wait_vmq<NEWER * 2 * (Q + 1)>(); else wait_vmq<NEWER * 2 * Q>();
+    constexpr int NEWER = decltype(newer)::value, EXTRA = decltype(extra)::value;
+    if (REM && wave < REM) wait_vmq<NEWER * 2 * (Q + 1) + EXTRA>(); else wait_vmq<NEWER * 2 * Q + EXTRA>();
     __builtin_amdgcn_s_barrier();
     const unsigned par = (unsigned)(p & 1) * 2u * STAGE;
     const unsigned ab = abase + par, bb = bbase + par;
+    if constexpr (MT == 4) {
+      // four waves of 64 x 96: the W-side fragments stream through two 2-tile buffers (chunk c = the unit tiles of gate c), the next
+      // chunk requested before this chunk's 24 MFMAs; only the last chunk runs behind B' (with the LDS-DMA requests)
+      h16x8q ah[MT], al[MT], bh[2][2], bl[2][2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[i]) : "v"(ab), "n"(i * 16 * RB));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[i]) : "v"(ab), "n"(i * 16 * RB + A_LO));
+      }
+#define TEPOSE_GRU_READ_B(C)                                                                                                   \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[(C) & 1][u]) : "v"(bb), "n"((2 * (C) + u) * 16 * RB));             \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[(C) & 1][u]) : "v"(bb), "n"((2 * (C) + u) * 16 * RB + W_LO));      \
+  }
+      TEPOSE_GRU_READ_B(0)
+      TEPOSE_GRU_READ_B(1)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int X = c & 1;
+        if (c == 0) {
+          asm volatile("s_waitcnt lgkmcnt(4)"
+                       : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]),
+                         "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bl[0][0]), "+v"(bl[0][1])
+                       :
+                       : "memory");
+        } else if (c == 1) {
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[1][0]), "+v"(bh[1][1]), "+v"(bl[1][0]), "+v"(bl[1][1]) : : "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bl[0][0]), "+v"(bl[0][1]) : : "memory");
+          __builtin_amdgcn_s_barrier();                    // B': every wave holds what it needs of pair p -> its two slots are free
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            acc[i][2 * c + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], ah[i], acc[i][2 * c + u], 0, 0, 0);
+            const int n = i * 2 + u;
+#pragma unroll
+            for (; q < (n + 1) * 2 * ND / (MT * 2); ++q)
+              if (DMA && c == 2) dma_part(2 * p + 4 + q / ND, q % ND);
+          }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            acc[i][2 * c + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[X][u], ah[i], acc[i][2 * c + u], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            acc[i][2 * c + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], al[i], acc[i][2 * c + u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 0) { TEPOSE_GRU_READ_B(2) }
+      }
+#undef TEPOSE_GRU_READ_B
+    } else {
     h16x8q ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -434,21 +497,24 @@ __global__ void __launch_bounds__(512) gru_h3s16_kernel(H3SBatch batch, int tile
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+    }
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  int p = 0;
-  for (; p + 2 < NP; ++p) pairstep(p, T_{}, I1{});
-  pairstep(NP - 2, F_{}, I1{});
-  pairstep(NP - 1, F_{}, I0{});
-
-  // ---- cell update: lane (t, g) holds, for row tile i and unit tile u, rows m0 + wm * 32 + i * 16 + t and the hidden units
-  // jb + u * 16 + 4 g .. + 3 of the three gates (W_hh tile j = gate * 2 + u of this wave's 96 rows)
   const GateDir& d = batch.gate[blockIdx.y];
   const int Hp = batch.Hp;
   const int jb = tn * (32 * NWN) + wn * 32;
+  int p = 0;
+  for (; p + 2 < NP; ++p) pairstep(p, T_{}, I1{}, I0{});
+  // (Pulling the cell operands towards L2 two pair steps ahead -- one global_load_dword per 128-byte line, counted in the last two
+  // waits -- was measured: 11.50 against 11.31 ms for the recurrent part of a forward, same baseline.  Not kept.)
+  pairstep(NP - 2, F_{}, I1{}, I0{});
+  pairstep(NP - 1, F_{}, I0{}, I0{});
+
+  // ---- cell update: lane (t, g) holds, for row tile i and unit tile u, rows m0 + wm * 32 + i * 16 + t and the hidden units
+  // jb + u * 16 + 4 g .. + 3 of the three gates (W_hh tile j = gate * 2 + u of this wave's 96 rows)
   const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev | (size_t)d.bhh) & 15) == 0 && (d.ldo & 3) == 0 &&
                    (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
 #pragma unroll
@@ -510,7 +576,9 @@ hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   if (!gru_h3s16_ok(b)) return hipErrorInvalidValue;
   const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
-  hipLaunchKernelGGL(gru_h3s16_kernel<0>, dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
+  if (b.p[0].shape16 == 2)                                 // TEPOSE_MFMA16 bit 4: four waves of 64 x 96
+    hipLaunchKernelGGL((gru_h3s16_kernel<0, 2>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj);
+  else hipLaunchKernelGGL((gru_h3s16_kernel<0, 4>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
   return hipGetLastError();
 }
 
