@@ -164,7 +164,9 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
     phys = physical_cores() or all_cores
     best = (0.0, all_cores)
     sweep = []                                            # every (threads, windows/s) pair tried: SURVEY 8d asks for ALL
-    for nt in sorted({min(n, all_cores) for n in (8, 16, 32, 64, phys, all_cores)}):   # physical cores and 1 (below)
+    # 8 ... the physical core count, and 1 (below).  NOT the logical count: 256 threads on a 128-core / 256-thread EPYC 9575F ran this
+    # 64-window forward at 0.4 windows/s (oversubscribed MKL-DNN GRU): 160 s of a bench run for a point that can only lose
+    for nt in sorted({min(n, phys) for n in (8, 16, 32, 64, phys)}):
         torch.set_num_threads(nt)
         O.tepose_fwd(state, smpl_np, x[:16], L, J_regressor=J, nn_gru=True)  # warm-up
         t0 = time.perf_counter()

@@ -104,5 +104,44 @@ def pmcavg(counter_path, trace_path):
             print('    %-36s %16.1f   per_us %12.1f' % (c, val, val / du))
 
 
+def traffic(fetch_path, write_path, proj_symbol, gru_symbol, out_json):
+    """profiles/rNN_traffic_split.json from the FETCH_SIZE and WRITE_SIZE passes of tools/profile.sh: HBM-side bytes per launch of
+    the dominant kernel (layer-0 projection, grid 131072 = 256 workgroups x 512) and of the fused 3-direction GRU step, FETCH
+    x2-corrected (MI355X_MICROARCH.md, HBM section: the counter is in 32-byte units that report 64-byte requests once on gfx950),
+    WRITE_SIZE as reported, both in KB.  The kernel SYMBOLS go into the file: bench.py refuses it as stale when the running
+    library launches other kernels (tepose_kernel_info)."""
+    import json
+
+    def avg(path, counter, sym, grid=None):
+        vals = defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r['Counter_Name'] == counter and sym.replace(' ', '') in r['Kernel_Name'].replace('tepose::', '').replace(' ', ''):
+                vals[r['Grid_Size']].append(float(r['Counter_Value']))
+        if grid is None:                      # the launch family with the largest grid (the 3-direction step)
+            grid = max(vals, key=lambda g: int(g))
+        v = vals[grid]
+        v = v[1:] if len(v) > 2 else v        # drop the cold first launch
+        return sum(v) / len(v), len(v), grid
+    M, N, K = 131072, 9216, 2133
+    pf, n1, g1 = avg(fetch_path, 'FETCH_SIZE', proj_symbol)
+    pw, _, _ = avg(write_path, 'WRITE_SIZE', proj_symbol)
+    gf, n2, g2 = avg(fetch_path, 'FETCH_SIZE', gru_symbol)
+    gw, _, _ = avg(write_path, 'WRITE_SIZE', gru_symbol)
+    alg = float(M) * K * 4 + float(N) * K * 4 + float(M) * N * 4
+    B, Hp = 8192, 1024
+    galg = 3 * (2.0 * B * Hp * 4 + 3.0 * Hp * Hp * 4 + 3.0 * B * Hp * 4)       # per direction: state in + out, W_hh once, gate pre-activations in
+    d = {'kernel': '%s layer-0 input projection (M=%d,N=%d,K=%d), grid %s, %d steady-state launches' % (proj_symbol, M, N, K, g1, n1),
+         'fetch_size_kb': pf, 'write_size_kb': pw, 'fetch_correction': 2.0,
+         'traffic_bytes_per_launch': (2.0 * pf + pw) * 1024.0, 'algorithmic_bytes_per_launch': alg,
+         'ratio': (2.0 * pf + pw) * 1024.0 / alg,
+         'gru_step': {'kernel': '%s fused GRU step, 3 directions, B=%d, grid %s, %d launches' % (gru_symbol, B, g2, n2),
+                      'fetch_size_kb': gf, 'write_size_kb': gw, 'traffic_bytes_per_launch': (2.0 * gf + gw) * 1024.0,
+                      'algorithmic_bytes_per_launch': galg, 'ratio': (2.0 * gf + gw) * 1024.0 / galg,
+                      'note': 'algorithmic = per direction: previous state in + new state out (fp32-equivalent 4 B/element each), W_hh once, gate pre-activations in'},
+         'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of bench.py --steps 2 --warmup 1 (tools/profile.sh); digest: profiles/summarize.py traffic'}
+    json.dump(d, open(out_json, 'w'), indent=1)
+    print(json.dumps(d, indent=1))
+
+
 if __name__ == '__main__':
-    {'trace': trace, 'pmc': pmc, 'sq': sq, 'pmcavg': pmcavg}[sys.argv[1]](*sys.argv[2:])
+    {'trace': trace, 'pmc': pmc, 'sq': sq, 'pmcavg': pmcavg, 'traffic': traffic}[sys.argv[1]](*sys.argv[2:])

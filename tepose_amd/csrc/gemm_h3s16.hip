@@ -41,10 +41,9 @@ __device__ __forceinline__ void wait_vmq() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ void h3s16_tile_of_block(int bid, int nwg, int tilesM, int tilesN, int& tm, int& tn) {
+__device__ __forceinline__ void h3s16_tile_of_block(int bid, int nwg, int tilesM, int tilesN, int& tm, int& tn, int GM = 4) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  constexpr int GM = 4;
   const int group = lin / (GM * tilesN), rem = lin - group * GM * tilesN;
   const int gm = min(GM, tilesM - group * GM);
   tm = group * GM + rem % gm;
@@ -59,7 +58,7 @@ __device__ __forceinline__ float s16_tanh(float x) {
 }
 
 template <int TAG>
-__global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int tilesM, int tilesN) {
+__global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int tilesM, int tilesN, int GM) {
   constexpr int NWN = 2, NST = 4, MT = 4, NT = 8;         // 4 x 2 waves of 64 x 128 = 4 x 8 MFMA tiles of 16 x 16
   constexpr int HM = 256, HN = 256, HK = 16, RB = HK * 2, RPI = 1024 / RB;
   constexpr int STAGE = (2 * HM + 2 * HN) * RB, TOT = STAGE / 1024, Q = TOT / 8;
@@ -103,7 +102,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int 
   int m0 = 0, n0 = 0;
   auto setup = [&](int tile) {
     int tm, tn;
-    h3s16_tile_of_block(tile, ntiles, tilesM, tilesN, tm, tn);
+    h3s16_tile_of_block(tile, ntiles, tilesM, tilesN, tm, tn, GM);
     m0 = tm * HM; n0 = tn * HN;
     const int l = fresh_lane();
 #pragma unroll
@@ -595,8 +594,11 @@ hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag) {
   if (!gemm_h3s16_ok(a)) return hipErrorInvalidValue;
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   const int nt = tilesM * tilesN;
-  if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
-  else hipLaunchKernelGGL(gemm_h3s_persist16_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN);
+  // row tiles per XCD group of the walk (the 32 workgroups of an XCD take GM x 32 / GM tiles at a time).  Measured on the layer-0
+  // projection, two rounds, same box (TEPOSE_S16_GM): GM 1: 11.95, 2: 11.71, 4: 11.72, 8: 11.59, 16: 12.50 ms -> 8
+  static const int gm = [] { const char* e = getenv("TEPOSE_S16_GM"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 32 ? v : 8; }();
+  if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm);
+  else hipLaunchKernelGGL(gemm_h3s_persist16_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm);
   return hipGetLastError();
 }
 
