@@ -597,6 +597,8 @@ hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag) {
   // row tiles per XCD group of the walk (the 32 workgroups of an XCD take GM x 32 / GM tiles at a time).  Measured on the layer-0
   // projection, two rounds, same box (TEPOSE_S16_GM): GM 1: 11.95, 2: 11.71, 4: 11.72, 8: 11.59, 16: 12.50 ms -> 8
   static const int gm = [] { const char* e = getenv("TEPOSE_S16_GM"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 32 ? v : 8; }();
+  // (Round-4 experiment, removed: a rendezvous of the 32 workgroups of an XCD at every tile start -- one agent-scope atomic + spin -- cut the
+  // beyond-L2 fetches by 10 % (8.28 -> 7.42 GB of FETCH_SIZE) and made the kernel 0.5 % SLOWER under the profiler, 9 % slower without.)
   if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm);
   else hipLaunchKernelGGL(gemm_h3s_persist16_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm);
   return hipGetLastError();

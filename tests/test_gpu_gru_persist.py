@@ -18,7 +18,7 @@ sys.path.insert(0, %r)
 from tepose_amd import synth
 from tepose_amd.testing import build_model
 out = {}
-for L, H, B, T in [(2, 1024, 2305, 3), (1, 320, 2050, 2), (2, 192, 2100, 3)]:
+for L, H, B, T in [(2, 1024, 2305, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (2, 256, 2304, 3), (3, 512, 2049, 2), (2, 1024, 2048, 2)]:
     model, _, _ = build_model(L, H, seed=11, device='cuda', smpl_np=synth.synthetic_smpl(0))
     x = torch.from_numpy(synth.synthetic_windows(B, T, 42)).cuda()
     with torch.no_grad():
@@ -28,7 +28,7 @@ np.savez(sys.argv[1], **out)
 
 
 def _run(persist, path):
-    env = dict(os.environ, TEPOSE_GRU_PERSIST=str(persist))
+    env = dict(os.environ, TEPOSE_GRU_PERSIST=str(persist), TEPOSE_MFMA16='1')      # the 32x32x16 step kernels (the persistent form's twin)
     p = subprocess.run([sys.executable, '-c', SCRIPT, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -41,7 +41,7 @@ def test_persistent_gru_step_is_bit_identical_and_matches_the_oracle(tmp_path):
     from tepose_amd import synth
     a = _run(0, str(tmp_path / 'a.npz'))
     b = _run(1, str(tmp_path / 'b.npz'))
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 3
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 6
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
         _, L, H, B, T = k.split('_')

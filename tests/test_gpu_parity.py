@@ -69,8 +69,10 @@ def test_gemm_rejects_bad_arguments():
                                       (2, 128, 70, 9), (2, 1024, 40, 16), (3, 100, 250, 3), (2, 64, 333, 4), (2, 192, 129, 4),   # 512 <= B*T < 8192, L >= 2: 128 x 288 tiles (ragged last row tile)
                                       (2, 64, 1100, 8), (3, 100, 1030, 8), (2, 64, 4100, 3), (3, 100, 4097, 2), (2, 128, 2048, 2),   # B*T >= 8192: single-accumulator
                                       # layer-0 projection; B >= 2048: scaled-format recurrent path; class defaults: n_layers=1, hidden=2048
-                                      # B >= 2048 and hidden >= 192: the persistent fused GRU step (256-row tiles walked in 4 x 8 / 8 x 4 / 16 x 2 groups;
-                                      # full and ragged row tiles, unit-tile counts 3, 4, 5 (a group with empty slots), 8 and 16)
+                                      # B >= 2048: the fused GRU step of large batches -- by default (round 4) gru_h3s16_kernel<0, 2> (16x16x32 MFMA, four
+                                      # waves of 64 x 96; 128-row tiles, full and ragged; unit-tile counts 3, 4, 5, 8, 16) and the layer >= 1 projections on
+                                      # gemm_h3s_persist16_kernel.  (The OPT-IN 256-row persistent form, TEPOSE_GRU_PERSIST=1, is covered by
+                                      # tests/test_gpu_gru_persist.py only; the 32x32x16 kernels by tests/test_gpu_mfma16.py's TEPOSE_MFMA16=0 baseline.)
                                       (2, 192, 2100, 3), (2, 256, 2304, 3), (1, 320, 2050, 2), (3, 512, 2049, 2), (2, 1024, 2048, 2),
                                       (2, 1024, 2305, 3)])
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
