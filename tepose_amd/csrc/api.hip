@@ -539,7 +539,6 @@ static void read_env_knobs(tepose_model* m) {
   // launch families -- what a committed profile must name to describe THIS binary with THESE knobs (bench.py checks)
   const char* h3sp = getenv("TEPOSE_H3S_PERSIST");
   const bool persist_plain = !(h3sp && atoi(h3sp) == 0);
-  const char* gp = getenv("TEPOSE_GRU_PERSIST");
   m->kinfo = std::string("projection=") +
              (!m->split ? "gemm_f32_kernel"
               : !m->g0_single_acc ? "gemm_h3_kernel"
@@ -549,7 +548,7 @@ static void read_env_knobs(tepose_model* m) {
              (!m->split ? "gru_step_kernel"
               : !m->gru_single_acc ? "gemm_h3_kernel"
               : (m->mfma16 & 4) ? "gru_h3s16_kernel<0, 2>" : (m->mfma16 & 2) ? "gru_h3s16_kernel<0, 4>"
-              : (gp && atoi(gp) != 0) ? "gru_h3s_persist_kernel<0>" : "gemm_h3s_kernel<1, 3, 4, 2, true, 4>");
+              : "gemm_h3s_kernel<1, 3, 4, 2, true, 4>");
 }
 
 namespace {
@@ -715,9 +714,11 @@ int tepose_forward_status(tepose_model* m, void* workspace, void* stream) {
   CK(hipStreamSynchronize((hipStream_t)stream));
   // the sync region is the first carve of every workspace (carve_encoder / carve_regressor): [.. | gru status | .. | reg status]
   unsigned* sy = (unsigned*)workspace;
-  unsigned st[2] = {0u, 0u};
-  CK(hipMemcpy(&st[0], sync_gru_status(m, sy), sizeof(unsigned), hipMemcpyDeviceToHost));
-  CK(hipMemcpy(&st[1], sync_reg_status(m, sy), sizeof(unsigned), hipMemcpyDeviceToHost));
+  // one copy of the span [recurrent status .. regressor status] (129 words: the regressor's arrival counters lie between them)
+  unsigned span[32 + 96 + 1];
+  static_assert(sizeof(span) == (32 + 96 + 1) * sizeof(unsigned), "span");
+  CK(hipMemcpy(span, sync_gru_status(m, sy), sizeof(span), hipMemcpyDeviceToHost));
+  const unsigned st[2] = {span[0], span[32 + 96]};
   if ((st[0] | st[1]) == 0u) return 0;
   // once per faulted forward: a later forward that launches no persistent kernel does not clear the words itself
   CK(hipMemset(sync_gru_status(m, sy), 0, sizeof(unsigned)));

@@ -615,352 +615,9 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist_kernel(H3SArgs a, int ti
   }
 }
 
-// The fused GRU step as a PERSISTENT kernel with 256-row tiles (round 3; OPT-IN: TEPOSE_GRU_PERSIST=1 -- it measured 4 %
-// slower than the one-workgroup-per-tile form above, see the end of this comment).
-//
-// The idea: the 128 x 192 block of 32 x 96 wave tiles above moves 0.83 LDS-DMA bytes and 0.89 KB of fragment reads per MFMA where
-// the 256 x 256 projection kernel moves 0.50 / 0.50, and its cell update ends a workgroup.  Here:
-//  * block = 256 rows x 64 hidden units x 3 gates, 4 x 2 waves of 64 x 96 (two 32-row fragments x the r, z, n tiles of 32
-//    units): 28 KB stages, 0.58 DMA bytes and 0.56 KB of fragment reads per MFMA; one workgroup per CU (112 KB ring + 32 KB
-//    for the LDS turn), 256 persistent workgroups walk the (direction, row tile, unit tile) tiles;
-//  * XCD-aware walk: in every round the 32 workgroups of an XCD (equal blockIdx % 8) take a 4 x 8 group of tiles of one
-//    direction, i.e. 1024 rows of state planes and 1536 rows of W_hh planes serve 32 tiles;
-//  * the finished tile's cell update no longer ends a workgroup: the next tile's first three stages are requested first, the
-//    gate pre-activations / previous state it needs were pulled into L2 six K-tiles earlier (one dword per 128-byte line and
-//    lane, counted in the vmcnt budget of the K-tiles in between), the LDS turn is asm (a C++ LDS access behind LDS-DMA
-//    requests makes hipcc wait for vmcnt(0)), fragment 1's operand loads are issued before fragment 0's stores (so that no
-//    wait covers a store), and the 24 stores of a wave drain under the next tile's first K-tiles (vmcnt allowance as in
-//    gemm_h3s_persist_kernel).  253 VGPRs, no spills.
-// Same fragments, K order and accumulators as the kernel above: bit-identical results (tests/test_gpu_parity.py runs both).
-// Measured (tools/gru_step_bench.py, B = 8192, T = 16, 33 launches per forward, same box, two runs each): 12.18 / 12.23 ms
-// against 11.68 / 11.66 ms for the form above; B = 4096: 6.31 vs 5.95; B = 2048: 3.80 vs 3.12 (1.5 rounds of 256-row tiles).
-// One workgroup per CU keeps all 256 CUs in lock step -- every CU reaches its cell update, its 200 MB burst of state stores
-// and its pipeline refill together -- where two independent workgroups per CU of the form above drift apart and fill each
-// other's gaps; the 30 % saved LDS traffic does not buy that back, because the kernel is limited by power (1.7 GHz), not by
-// an issue port (DESIGN.md section 12 has the ablation table and why most of it cannot be trusted).
-template <int TAG>
-__global__ void __launch_bounds__(512) gru_h3s_persist_kernel(H3SBatch batch, int tilesM, int tilesJ, int GN, int groupsM,
-                                                               int groupsN) {
-  constexpr int WMF = 2, WNT = 3, NWN = 2, NW = 8, NST = 4;
-  constexpr int HM = 256, HN = 192, HK = 16, RB = HK * 2, RPI = 1024 / RB;
-  constexpr int STAGE = (2 * HM + 2 * HN) * RB, TOT = STAGE / 1024, Q = TOT / NW, REM = TOT % NW, NDMA = Q + (REM ? 1 : 0);
-  constexpr int NSTORE = WMF * 4 * 3;                     // per wave and full tile: state + hi plane + lo plane per (fragment, task)
-  constexpr int NTOUCH = 4;                               // L2 touches per lane: gi r / z / n and hprev, one row each
-  static_assert(STAGE % 1024 == 0 && NST * STAGE + NW * 4096 <= 160 * 1024, "ring + turn buffers fit the LDS");
-  static_assert(2 * (Q + 1) + NSTORE <= 63 && 2 * (Q + 1) + NTOUCH <= 63, "vmcnt budget");
-  typedef float f32x4s __attribute__((ext_vector_type(4)));
-  typedef _Float16 h16x4s __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE + NW * 4096];   // ONE object (see gemm_h3s_persist_kernel)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int r = lane & 31, h = lane >> 5;
-  const int nd = Q + (wave < REM ? 1 : 0);
-  const int i0 = wave * Q + min(wave, REM);
-  const int GM = 32 / GN;
-  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int gpd = groupsM * groupsN, ngroups = batch.n * gpd;
-  const int Hp = batch.Hp;
-  const int KT = batch.p[0].Kp / HK;
-
-  // this lane's rows of the stage image [A_hi | A_lo | W_hi | W_lo]
-  bool isA[NDMA], isLo[NDMA];
-  int lrow[NDMA];
-#pragma unroll
-  for (int q = 0; q < NDMA; ++q) {
-    int ri = min(i0 + q, TOT - 1) * RPI + lane / 2;
-    isA[q] = ri < 2 * HM;
-    if (!isA[q]) ri -= 2 * HM;
-    isLo[q] = ri >= (isA[q] ? HM : HN);
-    lrow[q] = isLo[q] ? ri - (isA[q] ? HM : HN) : ri;
-  }
-  const char* gsrc[NDMA];
-  long kst[NDMA];
-  int dir = 0, m0 = 0, tn = 0;
-  // group G of the walk -> this workgroup's tile; false: the slot lies outside the matrix
-  auto decode = [&](int G, int& d_, int& tm_, int& tn_) -> bool {
-    d_ = G / gpd;
-    const int rem = G - d_ * gpd;
-    const int gm = rem / groupsN, gn = rem - gm * groupsN;
-    tm_ = gm * GM + loc % GM;
-    tn_ = gn * GN + loc / GM;
-    return tm_ < tilesM && tn_ < tilesJ;
-  };
-  auto next_valid = [&](int G) -> int {
-    int d_, tm_, tn_;
-    while (G < ngroups && !decode(G, d_, tm_, tn_)) G += 8;
-    return G;
-  };
-  auto setup = [&](int G) {
-    int tm_;
-    (void)decode(G, dir, tm_, tn);
-    m0 = tm_ * HM;
-    const H3SArgs& a = batch.p[dir];
-    const int n0 = tn * HN;
-#pragma unroll
-    for (int q = 0; q < NDMA; ++q) {
-      const char* base = (const char*)(isA[q] ? (isLo[q] ? a.Al : a.Ah) : (isLo[q] ? a.Wl : a.Wh)) + 16 * (lane & 1);
-      const long grow = isA[q] ? min((long)m0 + lrow[q], (long)a.M - 1) : (long)n0 + lrow[q];
-      gsrc[q] = base + grow * RB;
-      const long ks = (isA[q] ? a.a_kst : a.w_kst) * 2;
-      kst[q] = ((long)__builtin_amdgcn_readfirstlane((int)(ks >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ks);
-    }
-  };
-  auto dma_part = [&](int stage, int q) {
-    if (REM == 0 || q < nd) {
-      if (!(TEPOSE_GRU_ABL & 1)) glds16s(gsrc[q], lds + (stage % NST) * STAGE + (i0 + q) * 1024);
-      gsrc[q] += kst[q];
-    }
-  };
-  auto fill_ring = [&]() {
-#pragma unroll
-    for (int p = 0; p < NST - 1; ++p)
-#pragma unroll
-      for (int q = 0; q < NDMA; ++q) dma_part(p, q);
-  };
-  const int sx = 16 * (h ^ ((r >> 3) & 1));
-  int aoff[WMF], boff[WNT];
-#pragma unroll
-  for (int i = 0; i < WMF; ++i) aoff[i] = (wm * 32 * WMF + i * 32 + r) * RB + sx;
-#pragma unroll
-  for (int j = 0; j < WNT; ++j) boff[j] = 2 * HM * RB + (wn * 32 * WNT + j * 32 + r) * RB + sx;
-  constexpr int A_LO = HM * RB, W_LO = HN * RB;
-
-  f32x16 acc[WMF][WNT];
-  // NEWER: stages younger than this K-tile's still in flight when it starts (2 in the steady state; 1, 0 in the tail);
-  // EXTRA: other younger vector-memory instructions that may stay in flight (the previous tile's stores, the L2 touches)
-  auto ktile = [&](int kt, auto dma, auto newer, auto extra) __attribute__((always_inline)) {
-    constexpr bool DMA = decltype(dma)::value;
-    constexpr int NEWER = decltype(newer)::value, EXTRA = decltype(extra)::value;
-    if (REM && wave < REM) wait_vms<NEWER * (Q + 1) + EXTRA>();
-    else wait_vms<NEWER * Q + EXTRA>();
-    __builtin_amdgcn_s_barrier();
-    const char* st = lds + (kt % NST) * STAGE;
-    h16x8 ah[WMF], al[WMF], bh[WNT], bl[WNT];
-#pragma unroll
-    for (int i = 0; i < WMF; ++i) {
-      ah[i] = *(const h16x8*)(st + aoff[i]);
-      al[i] = *(const h16x8*)(st + A_LO + aoff[i]);
-    }
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-      bh[j] = *(const h16x8*)(st + boff[j]);
-      bl[j] = *(const h16x8*)(st + W_LO + boff[j]);
-    }
-    int q = 0;
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        if constexpr ((TEPOSE_GRU_ABL & 16) != 0) acc[i][j][0] += (float)ah[i][0] * (float)bh[j][0] + (float)al[i][0] * (float)bl[j][0];
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        const int t = i * WNT + j;
-#pragma unroll
-        for (; q < (t + 1) * NDMA / (WMF * WNT); ++q)
-          if constexpr (DMA) dma_part(kt + NST - 1, q);
-      }
-    if constexpr ((TEPOSE_GRU_ABL & 16) == 0) {
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  using T_ = std::true_type;
-  using F_ = std::false_type;
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-
-  int G = next_valid(xcd);
-  if (G >= ngroups) return;
-  setup(G);
-  fill_ring();
-  bool pending = false;                                   // NSTORE stores of the previous tile are younger than this tile's first stages
-  // LDS turn, per wave 4 KB behind the ring: write address of (fragment row 4h + ..., column r), read address of this lane's
-  // 4 consecutive units of row (lane >> 3) + 8 t
-  const unsigned turn_w = (unsigned)(size_t)(lds + NST * STAGE + wave * 4096) + (unsigned)(4 * h * 32 + r) * 4u;
-  const unsigned turn_r = (unsigned)(size_t)(lds + NST * STAGE + wave * 4096) + (unsigned)(lane >> 3) * 128u + (unsigned)(lane & 7) * 16u;
-  for (;;) {
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-#pragma unroll
-      for (int j = 0; j < WNT; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const H3SArgs& a = batch.p[dir];
-    const GateDir& d = batch.gate[dir];
-    const int jb = tn * (32 * NWN) + wn * 32;              // first hidden unit of this wave's 32
-    const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev | (size_t)d.bhh) & 15) == 0 && (d.ldo & 3) == 0 &&
-                     (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
-    const bool full = m0 + HM <= a.M && vec;
-    int kt = 0;
-    if (pending) {
-      for (; kt < NST - 1; ++kt) ktile(kt, T_{}, I2{}, std::integral_constant<int, NSTORE>{});
-    }
-    for (; kt < KT - 6; ++kt) ktile(kt, T_{}, I2{}, I0{});
-    ktile(kt, T_{}, I2{}, I0{}); ++kt;                     // K-tile KT - 6
-    // pull the cell operands of this wave's 64 rows x 32 units towards L2: lane = row, one dword of each 128-byte line
-    float touch[NTOUCH];
-    {
-      const long trow = min((long)m0 + wm * 64 + lane, (long)a.M - 1);
-      const float* tp[NTOUCH] = {d.gi + trow * d.ldgi + jb, d.gi + trow * d.ldgi + Hp + jb, d.gi + trow * d.ldgi + 2 * Hp + jb,
-                                 d.hprev + trow * d.ldh + jb};
-#pragma unroll
-      for (int t = 0; t < NTOUCH; ++t) asm volatile("global_load_dword %0, %1, off" : "=v"(touch[t]) : "v"(tp[t]) : "memory");
-    }
-    using NT = std::integral_constant<int, NTOUCH>;
-    ktile(kt, T_{}, I2{}, NT{}); ++kt;                      // KT - 5: its stage is older than the touches
-    ktile(kt, T_{}, I2{}, NT{}); ++kt;                      // KT - 4
-    ktile(kt, F_{}, I2{}, NT{}); ++kt;                      // KT - 3
-    ktile(kt, F_{}, I1{}, I0{}); ++kt;                      // KT - 2: its stage is younger than the touches: they have landed
-    ktile(kt, F_{}, I0{}, I0{});                            // KT - 1
-    wait_vms<0>();
-#pragma unroll
-    for (int t = 0; t < NTOUCH; ++t) asm volatile("" ::"v"(touch[t]));     // the touch registers stay reserved until here
-
-    const int m0s = m0;                                    // the finished tile
-    const int Gn = next_valid(G + 8);
-    const bool ov = full && Gn < ngroups;
-    __syncthreads();                                       // every wave has read the last stages: the ring is free
-    if (Gn < ngroups) {
-      setup(Gn);
-      if (ov) fill_ring();
-    }
-    // ---- cell update of the finished tile (a, d, jb, m0s still describe it)
-    f32x4s br, bz, bn;
-    if (vec) {
-      br = *(const f32x4s*)(d.bhh + jb + (lane & 7) * 4);
-      bz = *(const f32x4s*)(d.bhh + Hp + jb + (lane & 7) * 4);
-      bn = *(const f32x4s*)(d.bhh + 2 * Hp + jb + (lane & 7) * 4);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        br[c] = d.bhh[jb + (lane & 7) * 4 + c]; bz[c] = d.bhh[Hp + jb + (lane & 7) * 4 + c]; bn[c] = d.bhh[2 * Hp + jb + (lane & 7) * 4 + c];
-      }
-    }
-    // order of the vector-memory work (below): the wait for fragment 1's operands may leave the 12 younger stores of fragment 0
-    // in flight, and nothing waits for a store (the asm statements with a memory clobber pin the order)
-    auto loads = [&](int i, f32x4s (&gr)[4], f32x4s (&gz)[4], f32x4s (&gn)[4], f32x4s (&hp)[4]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = m0s + wm * 32 * WMF + i * 32 + ((t * 64 + lane) >> 3), j = jb + (lane & 7) * 4;
-        const int rowc = full ? row : min(row, a.M - 1);
-        const float* gi = d.gi + (long)rowc * d.ldgi + j;
-        const float* hq = d.hprev + (long)rowc * d.ldh + j;
-        if (TEPOSE_GRU_ABL & 2) {
-          const float cc = (float)(row + j) * 1e-6f;
-          gr[t] = f32x4s{cc, cc, cc, cc}; gz[t] = gr[t] * 0.5f; gn[t] = gr[t] * 0.25f; hp[t] = gr[t] * 2.f;
-        } else if (vec) {
-          gr[t] = *(const f32x4s*)gi; gz[t] = *(const f32x4s*)(gi + Hp); gn[t] = *(const f32x4s*)(gi + 2 * Hp);
-          hp[t] = *(const f32x4s*)hq;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) { gr[t][c] = gi[c]; gz[t][c] = gi[Hp + c]; gn[t][c] = gi[2 * Hp + c]; hp[t][c] = hq[c]; }
-        }
-      }
-    };
-    // acc of fragment i -> hg[gate][task]: through the wave's 4 KB of LDS, so that a lane owns 4 consecutive units of a row
-    auto turn = [&](int i, f32x4s (&hg)[3][4]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][g][e] * a.inv_scale;
-          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(turn_w), "v"(v), "n"(((e & 3) + 8 * (e >> 2)) * 128) : "memory");
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hg[g][t]) : "v"(turn_r), "n"(t * 1024) : "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(hg[0][0]), "+v"(hg[0][1]), "+v"(hg[0][2]), "+v"(hg[0][3]), "+v"(hg[1][0]), "+v"(hg[1][1]), "+v"(hg[1][2]),
-                     "+v"(hg[1][3]), "+v"(hg[2][0]), "+v"(hg[2][1]), "+v"(hg[2][2]), "+v"(hg[2][3])
-                   :
-                   : "memory");
-    };
-    auto cell = [&](const f32x4s (&hg)[3][4], const f32x4s (&gr)[4], const f32x4s (&gz)[4], const f32x4s (&gn)[4],
-                    const f32x4s (&hp)[4], f32x4s (&res)[4], h16x4s (&rhi)[4], h16x4s (&rlo)[4]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4s v;
-        _Float16 hh[4], ll[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float rg = gs_sigmoid(gr[t][c] + (hg[0][t][c] + br[c]));
-          const float zg = gs_sigmoid(gz[t][c] + (hg[1][t][c] + bz[c]));
-          const float ng = gs_tanh(gn[t][c] + rg * (hg[2][t][c] + bn[c]));
-          v[c] = (1.f - zg) * ng + zg * hp[t][c];
-          const float sv = v[c] * batch.state_scale;
-          hh[c] = (_Float16)sv;
-          ll[c] = (_Float16)(sv - (float)hh[c]);
-        }
-        res[t] = v;
-        rhi[t] = h16x4s{hh[0], hh[1], hh[2], hh[3]};
-        rlo[t] = h16x4s{ll[0], ll[1], ll[2], ll[3]};
-      }
-    };
-    auto stores = [&](int i, const f32x4s (&res)[4], const h16x4s (&rhi)[4], const h16x4s (&rlo)[4]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = m0s + wm * 32 * WMF + i * 32 + ((t * 64 + lane) >> 3), j = jb + (lane & 7) * 4;
-        if (!full && row >= a.M) continue;
-        if ((TEPOSE_GRU_ABL & 4) && res[t][0] + res[t][1] + (float)rhi[t][0] + (float)rlo[t][1] != 1234.5678f) continue;
-        float* ho = d.hout + (long)row * d.ldo + j;
-        const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
-        if (full) {
-          *(f32x4s*)ho = res[t];
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) ho[c] = res[t][c];
-        }
-        *(h16x4s*)((_Float16*)d.hout_hi + o) = rhi[t];
-        *(h16x4s*)((_Float16*)d.hout_lo + o) = rlo[t];
-      }
-    };
-    static_assert(WMF == 2, "two fragments, written out below");
-    if constexpr ((TEPOSE_GRU_ABL & 64) != 0) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int i = 0; i < WMF; ++i)
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) sacc += acc[i][g][e];
-      if (sacc == 123.456f) d.hout[tid] = sacc + br[0] + bz[0] + bn[0];
-    } else {
-      // turn 0 | loads 0 | turn 1 (under the loads' latency; the accumulators are dead from here) | cell 0 | loads 1 | stores 0 |
-      // cell 1 | stores 1
-      f32x4s hg0[3][4], hg1[3][4];
-      f32x4s gr0[4], gz0[4], gn0[4], hp0[4], res0[4];
-      h16x4s rhi0[4], rlo0[4];
-      turn(0, hg0);
-      loads(0, gr0, gz0, gn0, hp0);
-      turn(1, hg1);
-      cell(hg0, gr0, gz0, gn0, hp0, res0, rhi0, rlo0);
-      // fragment 0's update is complete (its operand registers are free) before fragment 1's loads are issued
-      asm volatile("" : "+v"(res0[0]), "+v"(res0[1]), "+v"(res0[2]), "+v"(res0[3]) : : "memory");
-      f32x4s gr1[4], gz1[4], gn1[4], hp1[4], res1[4];
-      h16x4s rhi1[4], rlo1[4];
-      loads(1, gr1, gz1, gn1, hp1);
-      asm volatile("" ::: "memory");
-      stores(0, res0, rhi0, rlo0);
-      cell(hg1, gr1, gz1, gn1, hp1, res1, rhi1, rlo1);
-      stores(1, res1, rhi1, rlo1);
-    }
-    if (Gn >= ngroups) break;
-    G = Gn;
-    if (!ov) {                                            // partial tile: drain, then fill the ring as a first tile does
-      wait_vms<0>();
-      fill_ring();
-    }
-    pending = ov;
-  }
-}
-
+// (Round 3 had a persistent 256-row form of the fused GRU step here -- gru_h3s_persist_kernel, opt-in, bit-identical, 4 % slower at
+// B = 8192 and up to 22 % slower at B = 2048 because one workgroup per CU keeps all CUs in lock step.  Removed in round 4: the
+// default step is gru_h3s16_kernel<0, 2> of gemm_h3s16.hip.  What was learnt from it is in DESIGN.md section 12b.)
 static bool h3s_persist() {
   static const bool v = [] { const char* e = getenv("TEPOSE_H3S_PERSIST"); return e ? atoi(e) != 0 : true; }();
   return v;
@@ -1006,20 +663,6 @@ hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s) {
   // one block per CU): -1 % at B = 8192, and it keeps winning down to B ~ 2048; 256 rows x 64 units: +2.5 %.
   if (b.p[0].shape16 && gru_h3s16_ok(b)) return launch_gru_h3s16(b, s);
   const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
-  // persistent form with 256-row tiles (round 3): needs >= 12 K-tiles (its peeled tail) and equal shapes in every direction
-  // Opt-in: measured 4 % SLOWER than the form below at B = 8192 (12.2 vs 11.7 ms per forward, same box), 6-22 % slower at
-  // B = 4096 / 2048 (1.5 rounds of 256-row tiles); kept for A/B runs, DESIGN.md section 12
-  static const bool persist = [] { const char* e = getenv("TEPOSE_GRU_PERSIST"); return e ? atoi(e) != 0 : false; }();
-  bool same = b.Hp % 64 == 0 && b.p[0].Kp >= 12 * 16;
-  for (int d = 1; d < b.n; ++d) same = same && b.p[d].M == b.p[0].M && b.p[d].Kp == b.p[0].Kp;
-  if (persist && same) {
-    const int tM = (b.p[0].M + 255) / 256;
-    int GN = 8;
-    while (GN > tj) GN >>= 1;                             // unit tiles per group: the largest of 8, 4, 2, 1 that fits
-    const int GM = 32 / GN, groupsM = (tM + GM - 1) / GM, groupsN = (tj + GN - 1) / GN;
-    hipLaunchKernelGGL(gru_h3s_persist_kernel<0>, dim3(256), dim3(512), 0, s, b, tM, tj, GN, groupsM, groupsN);
-    return hipGetLastError();
-  }
   hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 2, true>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
   return hipGetLastError();
 }
