@@ -186,6 +186,9 @@ int tepose_uses_persistent(const tepose_model* m, int B, int T);
  * kernels launched from now on expect an arrival that never comes), changeable on a live handle -- e.g. between the warm-up
  * and the capture of a hipGraph, so that the give-up happens inside a replay (tests/test_gpu_stream.py).                  */
 int tepose_debug_set_test_fault(tepose_model* m, unsigned bits);
+/* Tests / monitoring: how many waves of the barrier-free GEMM kernels (gemm_h3s16c.hip) ever gave up a bounded poll in this
+ * process (they cannot unless the kernel has a bug: a wave only waits for waves of its own workgroup); 0 = never.         */
+unsigned tepose_debug_kernel_errors(void);
 
 /* ---- sliding-window driver with cached layer-0 projections ---------------
  * Consecutive windows of a clip share T-1 frames, and a frame's layer-0 gate pre-activations

@@ -22,7 +22,7 @@ SYMBOLS = [
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
     'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
-    'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info', 'tepose_debug_set_test_fault',
+    'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info', 'tepose_debug_set_test_fault', 'tepose_debug_kernel_errors',
 ]
 
 _lib = None
@@ -108,6 +108,7 @@ def load():
     lib.tepose_status.argtypes = [c_void_p, c_void_p]
     lib.tepose_forward_status.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.tepose_debug_set_test_fault.argtypes = [c_void_p, c_uint]
+    lib.tepose_debug_kernel_errors.restype = c_uint
     lib.tepose_status_peek.argtypes = [c_void_p]
     lib.tepose_set_persistent.argtypes = [c_void_p, c_int]
     lib.tepose_uses_persistent.argtypes = [c_void_p, c_int, c_int]

@@ -50,11 +50,11 @@ struct tepose_model {
   bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
   bool gru_single_acc = true;                   // large batches: layer >= 1 projections and GRU steps on it too
   std::string kinfo;                            // tepose_kernel_info(): the kernel symbols the knobs select for the dominant launches
-  int mfma16 = 5;                               // TEPOSE_MFMA16 bit mask, kernels on v_mfma_f32_16x16x32_f16 (gemm_h3s16.hip) instead of
-                                                // 32x32x16: 1 = plain scaled-plane products (default since round 4: -3 % on the
-                                                // projections, the chip holds 1.88 instead of 1.66 GHz); 2 = fused GRU step as eight
-                                                // waves of 32 x 96 (neutral: 1.99 vs 1.74 GHz but 0.50 vs 0.57 busy); 4 = fused GRU
-                                                // step as four waves of 64 x 96 with streamed W fragments (default: -4 %)
+  int mfma16 = 13;                              // TEPOSE_MFMA16 bit mask, kernels on v_mfma_f32_16x16x32_f16 instead of 32x32x16: 1 = plain
+                                                // scaled-plane products (gemm_h3s16.hip: -3 % on the projections, the chip holds 1.88 instead
+                                                // of 1.66 GHz); 8 = ... in their barrier-free form (gemm_h3s16c.hip: another -6 %);
+                                                // 2 = fused GRU step as eight waves of 32 x 96 (neutral); 4 = fused GRU step as four
+                                                // waves of 64 x 96 with streamed W fragments (-4 %).  Default 13 = 1 + 4 + 8
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
@@ -524,7 +524,7 @@ static void read_env_knobs(tepose_model* m) {
   e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
   m->gru_single_acc = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_MFMA16");                      // MFMA shape of the scaled-plane kernels (bit 1: plain products, bit 2: GRU step)
-  m->mfma16 = e ? atoi(e) : 5;
+  m->mfma16 = e ? atoi(e) : 13;
   e = getenv("TEPOSE_COLLAPSE_REGRESSOR");          // 0: the regressor's FC loop is always run as a loop
   m->collapse_env = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
@@ -543,6 +543,7 @@ static void read_env_knobs(tepose_model* m) {
              (!m->split ? "gemm_f32_kernel"
               : !m->g0_single_acc ? "gemm_h3_kernel"
               : !persist_plain ? "gemm_h3s_kernel"
+              : (m->mfma16 & 8) ? "gemm_h3s_persist16c_kernel<0>"
               : (m->mfma16 & 1) ? "gemm_h3s_persist16_kernel<0>" : "gemm_h3s_persist_kernel<0>") +
              ";gru_step=" +
              (!m->split ? "gru_step_kernel"
@@ -732,6 +733,8 @@ int tepose_set_persistent(tepose_model* m, int on) {
   __atomic_store_n(&m->persist, on != 0, __ATOMIC_RELAXED);
   return 0;
 }
+
+unsigned tepose_debug_kernel_errors(void) { return h3s16c_read_err(); }
 
 int tepose_debug_set_test_fault(tepose_model* m, unsigned bits) {
   if (!m) return TEPOSE_E_ARG;
@@ -1229,7 +1232,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       const half_t* sh = (const half_t*)(Bl + w_s);
       H3SArgs a{v.hi, v.lo, v.kst, sh, sh + r256 * K, (long)r256 * 16, K, out, (long)H3, Bl + bias,
                 1.f / (kStateScale * w_scale), M, H3};
-      a.shape16 = m->mfma16 & 1;
+      a.shape16 = (m->mfma16 & 8) ? 3 : (m->mfma16 & 1);
       return (int)launch_gemm_h3s(a, s);
     }
     const EncWs::View v = w.view(in);
@@ -1607,7 +1610,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       const half_t* sh = (const half_t*)(Bl + m->wih0_s);
       H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
                 Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0, w.rs};
-      a.shape16 = m->mfma16 & 1;
+      a.shape16 = (m->mfma16 & 8) ? 3 : (m->mfma16 & 1);
       if (g0mid) CK(launch_gemm_h3s_mid(a, s));
       else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {
@@ -2003,7 +2006,7 @@ int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const
   const char* pe = getenv("TEPOSE_H3S");
   if (pe && atoi(pe) && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
     CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, bias,
-                           atoi(pe) == 2));                     // TEPOSE_H3S=2: the 16x16x32 MFMA shape (gemm_h3s16.hip)
+                           atoi(pe) == 2 ? 1 : atoi(pe) == 3 ? 3 : 0));   // TEPOSE_H3S=2: the 16x16x32 MFMA shape (gemm_h3s16.hip); 3: its barrier-free experiment
     return 0;
   }
   CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream));

@@ -628,6 +628,7 @@ hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag) {
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   H3SBatch b{};
   b.p[0] = a; b.n = 1;
+  if (h3s_persist() && a.shape16 == 3 && gemm_h3s16_ok(a)) return launch_gemm_h3s16c(a, s, tag);   // TEPOSE_MFMA16 bit 8 (experiment)
   if (h3s_persist() && a.shape16 && gemm_h3s16_ok(a)) return launch_gemm_h3s16(a, s, tag);
   if (h3s_persist()) {
     const int nt = tilesM * tilesN;

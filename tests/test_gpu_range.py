@@ -164,7 +164,7 @@ def _cancelling_operands(M, N, K, seed):
     return A, W, cols
 
 
-@pytest.mark.parametrize('h3s', ['0', '1', '2'])      # two-accumulator planes; scaled planes on 32x32x16; on 16x16x32
+@pytest.mark.parametrize('h3s', ['0', '1', '2', '3'])      # two-accumulator planes; scaled planes on 32x32x16; on 16x16x32; barrier-free 16x16x32
 def test_cancelling_dot_products_through_the_split_gemm(monkeypatch, h3s):
     from tepose_amd import _lib
     lib = _lib.load()

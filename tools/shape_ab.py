@@ -15,7 +15,7 @@ from tepose_amd.testing import build_model  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-variants = sys.argv[3:] or ['TEPOSE_MFMA16=0', 'TEPOSE_MFMA16=5']
+variants = sys.argv[3:] or ['TEPOSE_MFMA16=0', 'TEPOSE_MFMA16=5', 'TEPOSE_MFMA16=13']
 dev = torch.device('cuda', 0)
 smpl_np = synth.synthetic_smpl(0)
 state = synth.synthetic_state_dict(2, 1024, 0)
