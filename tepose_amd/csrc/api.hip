@@ -548,7 +548,7 @@ static void read_env_knobs(tepose_model* m) {
              ";gru_step=" +
              (!m->split ? "gru_step_kernel"
               : !m->gru_single_acc ? "gemm_h3_kernel"
-              : (m->mfma16 & 4) ? "gru_h3s16_kernel<0, 2>" : (m->mfma16 & 2) ? "gru_h3s16_kernel<0, 4>"
+              : (m->mfma16 & 16) ? "gru_h3s16c_kernel<0>" : (m->mfma16 & 4) ? "gru_h3s16_kernel<0, 2>" : (m->mfma16 & 2) ? "gru_h3s16_kernel<0, 4>"
               : "gemm_h3s_kernel<1, 3, 4, 2, true, 4>");
 }
 
@@ -1261,7 +1261,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           const half_t* sh = (const half_t*)(Bl + dw[d]->whh_s);
           b.p[d] = H3SArgs{vi.hi, vi.lo, vi.kst, sh, sh + r384 * Hp, (long)r384 * 16, Hp, nullptr, 0, nullptr,
                            1.f / (kStateScale * dw[d]->whh_scale), B, H3};
-          b.p[d].shape16 = (m->mfma16 & 4) ? 2 : ((m->mfma16 >> 1) & 1);      // 2: the four-wave form of the 16x16x32 step
+          b.p[d].shape16 = (m->mfma16 & 16) ? 4 : (m->mfma16 & 4) ? 2 : ((m->mfma16 >> 1) & 1);      // 2: the four-wave form of the 16x16x32 step, 4: persistent barrier-free
         }
       }
       if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s, 1);

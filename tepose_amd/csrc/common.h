@@ -307,6 +307,8 @@ bool gemm_h3s16_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag);   // gemm_h3s16.hip
 hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag);  // gemm_h3s16c.hip: experiment, no barriers in the K loop
 unsigned h3s16c_read_err();
+bool gru_h3s16c_ok(const H3SBatch& b);
+hipError_t launch_gru_h3s16c(const H3SBatch& b, hipStream_t s);         // gemm_h3s16c.hip: persistent barrier-free fused GRU step
 bool gru_h3s16_ok(const H3SBatch& b);
 hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s);          // the fused GRU step on 16x16x32 (gemm_h3s16.hip)
 bool gemm_h3s_mid_ok(const H3SArgs& a);

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(2, 1024, 2305, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (3, 512, 2049, 2), (2, 256, 4096, 4)]
 
 
-@pytest.mark.parametrize('knob', ['1', '2', '3', '5', '13'])     # bit 1 plain products, bit 2 GRU step (8 waves), bit 4 GRU step (4 waves of 64 x 96), bit 8 plain products barrier-free (13 = the default)
+@pytest.mark.parametrize('knob', ['1', '2', '3', '5', '13', '25'])     # bit 1 plain products, bit 2 GRU step (8 waves), bit 4 GRU step (4 waves of 64 x 96), bit 8 plain products barrier-free, bit 16 GRU step persistent + barrier-free
 def test_mfma16_kernels_against_the_default_shape_and_the_fp64_oracle(monkeypatch, knob):
     for L, H, B, T in SHAPES:
         smpl_np = synth.synthetic_smpl(0)
