@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int 
 // waves of 64 x 96 -- 20 fragment reads per 72 MFMAs instead of 16 per 36, i.e. 160 + 80 KB of LDS traffic per pair of stages and CU
 // instead of 256 + 80 (the eight-wave form is LDS-bound: 2688 LDS cycles against 2304 MFMA cycles per pair and CU), two waves per SIMD.
 template <int TAG, int NWM>
-__global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(H3SBatch batch, int tilesM, int tilesN) {
+__global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(H3SBatch batch, int tilesM, int tilesN, int GM) {
   constexpr int NWN = 2, NW = NWM * NWN, NST = 4, MT = 8 / NWM, NT = 6;  // wave = MT row tiles x (3 gates x 2 unit tiles) of 16 x 16
   constexpr int HM = 128, HN = 192, HK = 16, RB = HK * 2, RPI = 1024 / RB;
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;            // 20 KB
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
   __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
   const H3SArgs& a = batch.p[blockIdx.y];
   int tm, tn;
-  h3s16_tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn);
+  h3s16_tile_of_block(blockIdx.x, gridDim.x, tilesM, tilesN, tm, tn, GM);
   const int m0 = tm * HM, n0 = tn * HN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
@@ -575,9 +575,11 @@ hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   if (!gru_h3s16_ok(b)) return hipErrorInvalidValue;
   const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
+  // tile rows per XCD group (TEPOSE_GRU_GM): the 64 workgroups resident on an XCD cover GM row tiles x 64 / GM unit tiles of one direction
+  static const int gm = [] { const char* e = getenv("TEPOSE_GRU_GM"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
   if (b.p[0].shape16 == 2)                                 // TEPOSE_MFMA16 bit 4: four waves of 64 x 96
-    hipLaunchKernelGGL((gru_h3s16_kernel<0, 2>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj);
-  else hipLaunchKernelGGL((gru_h3s16_kernel<0, 4>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
+    hipLaunchKernelGGL((gru_h3s16_kernel<0, 2>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj, gm);
+  else hipLaunchKernelGGL((gru_h3s16_kernel<0, 4>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj, gm);
   return hipGetLastError();
 }
 
