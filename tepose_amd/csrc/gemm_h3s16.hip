@@ -516,50 +516,62 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
   // jb + u * 16 + 4 g .. + 3 of the three gates (W_hh tile j = gate * 2 + u of this wave's 96 rows)
   const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev | (size_t)d.bhh) & 15) == 0 && (d.ldo & 3) == 0 &&
                    (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
+  // row tile outermost, the two unit tiles of a row together: lanes g = 0..3 of a row cover 64 bytes per unit tile, and the two unit tiles are the
+  // two halves of ONE 128-byte line of every operand -- requested back to back instead of one whole gate-math pass apart
+  {
+    f32x4q br[2], bz[2], bn[2];
+    int jj[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int j = jb + u * 16 + 4 * g;
-    if (j >= Hp) continue;
-    f32x4q br, bz, bn;
+    for (int u = 0; u < 2; ++u) {
+      jj[u] = min(jb + u * 16 + 4 * g, Hp - 4);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { br[c] = d.bhh[j + c]; bz[c] = d.bhh[Hp + j + c]; bn[c] = d.bhh[2 * Hp + j + c]; }
+      for (int c = 0; c < 4; ++c) { br[u][c] = d.bhh[jj[u] + c]; bz[u][c] = d.bhh[Hp + jj[u] + c]; bn[u][c] = d.bhh[2 * Hp + jj[u] + c]; }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int row = m0 + wm * 16 * MT + i * 16 + t;
       if (row >= a.M) continue;
-      const float* gi = d.gi + (long)row * d.ldgi + j;
-      const float* hq = d.hprev + (long)row * d.ldh + j;
-      f32x4q gr, gz, gn, hp;
-      if (vec) {
-        gr = *(const f32x4q*)gi; gz = *(const f32x4q*)(gi + Hp); gn = *(const f32x4q*)(gi + 2 * Hp);
-        hp = *(const f32x4q*)hq;
-      } else {
+      f32x4q gr[2], gz[2], gn[2], hp[2];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { gr[c] = gi[c]; gz[c] = gi[Hp + c]; gn[c] = gi[2 * Hp + c]; hp[c] = hq[c]; }
-      }
-      f32x4q v;
-      _Float16 hh[4], ll[4];
+      for (int u = 0; u < 2; ++u) {
+        const float* gi = d.gi + (long)row * d.ldgi + jj[u];
+        const float* hq = d.hprev + (long)row * d.ldh + jj[u];
+        if (vec) {
+          gr[u] = *(const f32x4q*)gi; gz[u] = *(const f32x4q*)(gi + Hp); gn[u] = *(const f32x4q*)(gi + 2 * Hp);
+          hp[u] = *(const f32x4q*)hq;
+        } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float hr = acc[i][0 + u][c] * a.inv_scale, hz = acc[i][2 + u][c] * a.inv_scale, hn = acc[i][4 + u][c] * a.inv_scale;
-        const float rg = s16_sigmoid(gr[c] + (hr + br[c]));
-        const float zg = s16_sigmoid(gz[c] + (hz + bz[c]));
-        const float ng = s16_tanh(gn[c] + rg * (hn + bn[c]));
-        v[c] = (1.f - zg) * ng + zg * hp[c];
-        const float sv = v[c] * batch.state_scale;
-        hh[c] = (_Float16)sv;
-        ll[c] = (_Float16)(sv - (float)hh[c]);
+          for (int c = 0; c < 4; ++c) { gr[u][c] = gi[c]; gz[u][c] = gi[Hp + c]; gn[u][c] = gi[2 * Hp + c]; hp[u][c] = hq[c]; }
+        }
       }
-      float* ho = d.hout + (long)row * d.ldo + j;
-      const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
-      if (vec) {
-        *(f32x4q*)ho = v;
-      } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ho[c] = v[c];
+      for (int u = 0; u < 2; ++u) {
+        const int j = jb + u * 16 + 4 * g;
+        if (j >= Hp) continue;
+        f32x4q v;
+        _Float16 hh[4], ll[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float hr = acc[i][0 + u][c] * a.inv_scale, hz = acc[i][2 + u][c] * a.inv_scale, hn = acc[i][4 + u][c] * a.inv_scale;
+          const float rg = s16_sigmoid(gr[u][c] + (hr + br[u][c]));
+          const float zg = s16_sigmoid(gz[u][c] + (hz + bz[u][c]));
+          const float ng = s16_tanh(gn[u][c] + rg * (hn + bn[u][c]));
+          v[c] = (1.f - zg) * ng + zg * hp[u][c];
+          const float sv = v[c] * batch.state_scale;
+          hh[c] = (_Float16)sv;
+          ll[c] = (_Float16)(sv - (float)hh[c]);
+        }
+        float* ho = d.hout + (long)row * d.ldo + j;
+        const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
+        if (vec) {
+          *(f32x4q*)ho = v;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ho[c] = v[c];
+        }
+        *(h16x4q*)((_Float16*)d.hout_hi + o) = h16x4q{hh[0], hh[1], hh[2], hh[3]};
+        *(h16x4q*)((_Float16*)d.hout_lo + o) = h16x4q{ll[0], ll[1], ll[2], ll[3]};
       }
-      *(h16x4q*)((_Float16*)d.hout_hi + o) = h16x4q{hh[0], hh[1], hh[2], hh[3]};
-      *(h16x4q*)((_Float16*)d.hout_lo + o) = h16x4q{ll[0], ll[1], ll[2], ll[3]};
     }
   }
 }
