@@ -823,8 +823,61 @@ __global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int
   }
 }
 
+// The same step for the scaled [K/16][R][16] planes of large batches, laid out for whole cache lines: a wave takes 16 rows x 32 hidden units,
+// lane (t = lane & 15, g = lane >> 4) row t and the units 4 g .. 4 g + 3 of two 16-unit tiles -- 16-byte loads / state stores whose two tiles
+// are the halves of one 128-byte line per row, and 8-byte plane stores that are 512 contiguous bytes per wave instruction (the element-wise
+// kernel above moves 8 / 4 bytes per lane and scatters a wave's plane stores over 16 K-tiles).  Same arithmetic, bit-identical.
+__global__ void __launch_bounds__(256) gru_first16_kernel(GateBatch gb, int M, int Hp) {
+  typedef _Float16 h16x4v __attribute__((ext_vector_type(4)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const GateDir& d = gb.d[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  const int tilesJ = Hp / 128;
+  const int tm = blockIdx.x / tilesJ, tj = blockIdx.x - tm * tilesJ;
+  const long row = (long)tm * 16 + t;
+  if (row >= M) return;
+  f32x4v gr[2], gz[2], gn[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float* gi = d.gi + row * d.ldgi + tj * 128 + wave * 32 + u * 16 + 4 * g;
+    gr[u] = *(const f32x4v*)gi; gz[u] = *(const f32x4v*)(gi + Hp); gn[u] = *(const f32x4v*)(gi + 2 * Hp);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = tj * 128 + wave * 32 + u * 16 + 4 * g;
+    const f32x4v br = *(const f32x4v*)(d.bhh + j), bz = *(const f32x4v*)(d.bhh + Hp + j), bn = *(const f32x4v*)(d.bhh + 2 * Hp + j);
+    f32x4v hv;
+    half_t hh[4], ll[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float rg = g_sigmoid(gr[u][c] + br[c]), zg = g_sigmoid(gz[u][c] + bz[c]);
+      const float ng = g_tanh(gn[u][c] + rg * bn[c]);
+      hv[c] = (1.f - zg) * ng;
+      const float sv = hv[c] * kStateScale;
+      hh[c] = (half_t)sv;
+      ll[c] = (half_t)(sv - (float)hh[c]);
+    }
+    *(f32x4v*)(d.hout + row * d.ldo + j) = hv;
+    const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
+    *(h16x4v*)(d.hout_hi + o) = h16x4v{hh[0], hh[1], hh[2], hh[3]};
+    *(h16x4v*)(d.hout_lo + o) = h16x4v{ll[0], ll[1], ll[2], ll[3]};
+  }
+}
+
 hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s, int scaled16) {
   if (M <= 0 || ndir <= 0) return hipSuccess;
+  if (scaled16 && Hp % 128 == 0) {
+    bool vec = true;
+    for (int i = 0; i < ndir; ++i) {
+      const GateDir& d = gb.d[i];
+      vec = vec && (((size_t)d.gi | (size_t)d.bhh | (size_t)d.hout) & 15) == 0 && (d.ldgi & 3) == 0 && (d.ldo & 3) == 0 &&
+            (((size_t)d.hout_hi | (size_t)d.hout_lo) & 7) == 0 && (d.okst & 3) == 0;
+    }
+    if (vec) {
+      hipLaunchKernelGGL(gru_first16_kernel, dim3((unsigned)(((long)M + 15) / 16 * (Hp / 128)), ndir), dim3(256), 0, s, gb, M, Hp);
+      return hipGetLastError();
+    }
+  }
   const long total = (long)M * Hp / 2;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(gru_first_kernel, dim3(blocks, ndir), dim3(256), 0, s, gb, M, Hp, scaled16);
