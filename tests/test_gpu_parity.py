@@ -71,7 +71,7 @@ def test_gemm_rejects_bad_arguments():
                                       # layer-0 projection; B >= 2048: scaled-format recurrent path; class defaults: n_layers=1, hidden=2048
                                       # B >= 2048: the fused GRU step of large batches -- by default (round 4) gru_h3s16_kernel<0, 2> (16x16x32 MFMA, four
                                       # waves of 64 x 96; 128-row tiles, full and ragged; unit-tile counts 3, 4, 5, 8, 16) and the layer >= 1 projections on
-                                      # gemm_h3s_persist16_kernel.  (The 32x32x16 kernels: tests/test_gpu_mfma16.py's TEPOSE_MFMA16=0 baseline.)
+                                      # gemm_h3s_persist16c_kernel (barrier-free); first steps on gru_first16_kernel where Hp % 128 == 0.  (The 32x32x16 kernels: tests/test_gpu_mfma16.py's TEPOSE_MFMA16=0 baseline.)
                                       (2, 192, 2100, 3), (2, 256, 2304, 3), (1, 320, 2050, 2), (3, 512, 2049, 2), (2, 1024, 2048, 2),
                                       (2, 1024, 2305, 3)])
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
