@@ -176,13 +176,19 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
  *   - tepose_set_persistent(m, 0) (or TEPOSE_PERSISTENT=0 at tepose_create): the step-per-launch HIP kernels at
  *     every batch size -- same results, no residency requirement; the remedy after a TEPOSE_E_TIMEOUT.  The switch is one
  *     atomic flag: it may be flipped while other threads run forwards on the handle (each forward reads it once).
- *   - tepose_uses_persistent(m, B, T): 1 if a forward of B windows may launch a persistent kernel.          */
+ *   - tepose_uses_persistent(m, B, T): 1 if a forward of B windows may launch a persistent kernel.
+ * The large-batch projection kernel (csrc/gemm_h3s16c.hip) has no workgroup barriers; its waves wait on LDS arrival counters with
+ * bounded polls.  No wait there depends on another workgroup, so only a kernel bug or a hardware fault can expire one -- but if one
+ * does, it is reported the same way (NaN in the output, status word of the forward's workspace = 4, the handle's fault word), never
+ * as a plausible result with rc 0.  Large batches are not synchronised by the library: the next entry point on the handle refuses
+ * with TEPOSE_E_TIMEOUT, tepose_forward_status / tepose_status answer after their synchronisation.  tepose_set_persistent does not
+ * affect this kernel (TEPOSE_MFMA16=5 selects the barrier form).                                                */
 int tepose_forward_status(tepose_model* m, void* workspace, void* stream);
 int tepose_status(tepose_model* m, void* stream);
 int tepose_status_peek(const tepose_model* m);
 int tepose_set_persistent(tepose_model* m, int on);
 int tepose_uses_persistent(const tepose_model* m, int B, int T);
-/* Tests only: what TEPOSE_TEST_FAULT sets at tepose_create (bit 0 / 1: the waits of the persistent recurrent / regressor
+/* Tests only: what TEPOSE_TEST_FAULT sets at tepose_create (bit 2: every poll of the barrier-free projection kernel; bit 0 / 1: the waits of the persistent recurrent / regressor
  * kernels launched from now on expect an arrival that never comes), changeable on a live handle -- e.g. between the warm-up
  * and the capture of a hipGraph, so that the give-up happens inside a replay (tests/test_gpu_stream.py).                  */
 int tepose_debug_set_test_fault(tepose_model* m, unsigned bits);

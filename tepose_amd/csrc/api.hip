@@ -517,6 +517,7 @@ int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
 
 // numerics / dispatch knobs, read once per handle at creation (both model kinds)
 static void read_env_knobs(tepose_model* m) {
+  h3s16c_warm();
   const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
   m->split = m->split_env = !(e && atoi(e) != 0);
   e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
@@ -1233,6 +1234,9 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       H3SArgs a{v.hi, v.lo, v.kst, sh, sh + r256 * K, (long)r256 * 16, K, out, (long)H3, Bl + bias,
                 1.f / (kStateScale * w_scale), M, H3};
       a.shape16 = (m->mfma16 & 8) ? 3 : (m->mfma16 & 1);
+      if (w.sync) a.status = sync_gru_status(m, w.sync);
+      a.fault = m->fault;
+      a.inject = (m->test_fault >> 2) & 1u;
       return (int)launch_gemm_h3s(a, s);
     }
     const EncWs::View v = w.view(in);
@@ -1262,6 +1266,9 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           b.p[d] = H3SArgs{vi.hi, vi.lo, vi.kst, sh, sh + r384 * Hp, (long)r384 * 16, Hp, nullptr, 0, nullptr,
                            1.f / (kStateScale * dw[d]->whh_scale), B, H3};
           b.p[d].shape16 = (m->mfma16 & 16) ? 4 : (m->mfma16 & 4) ? 2 : ((m->mfma16 >> 1) & 1);      // 2: the four-wave form of the 16x16x32 step, 4: persistent barrier-free
+          if (w.sync) b.p[d].status = sync_gru_status(m, w.sync);
+          b.p[d].fault = m->fault;
+          b.p[d].inject = (m->test_fault >> 2) & 1u;
         }
       }
       if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s, 1);
@@ -1589,10 +1596,12 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
   const bool g0s = g0big || g0mid;
   // the caller's windows -> planes with one power-of-two scale per row (any finite fp32 magnitude; DESIGN 4b "range")
   // (with zero_sync the kernel also clears the forward's arrival counters / granules: it is the forward's first kernel)
-  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, zero_sync ? (void*)w.sync : nullptr,
-                               zero_sync ? sync_zero_bytes(m, B) : 0));
+  // (the forward's first kernel also clears its sync region -- arrival counters, granules, STATUS words -- so that a give-up of the
+  // layer-0 projection (barrier-free kernel, gemm_h3s16c.hip) is not wiped by a clearing that comes after it)
+  (void)zero_sync;
+  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, (void*)w.sync, w.sync ? sync_zero_bytes(m, B) : 0));
   else CK(launch_pad_input(x, w.xp, BT, s));
-  if (zero_sync && !h3) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
+  if (!h3 && w.sync) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
   {
     tepose_model* mm = const_cast<tepose_model*>(m);
     if (m->prof) {
@@ -1611,6 +1620,9 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
                 Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0, w.rs};
       a.shape16 = (m->mfma16 & 8) ? 3 : (m->mfma16 & 1);
+      if (w.sync) a.status = sync_gru_status(m, w.sync);
+      a.fault = m->fault;
+      a.inject = (m->test_fault >> 2) & 1u;
       if (g0mid) CK(launch_gemm_h3s_mid(a, s));
       else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {
@@ -1662,7 +1674,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
     if (!h3 || is_train || end > first_live) feat_planes = nullptr;
   }
   if (wrote_planes) *wrote_planes = feat_planes != nullptr;
-  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes, zero_sync, xs_out);     // cleared above when asked
+  return encoder_core(m, src, B, T, is_train, feat, w, s, feat_planes, true, xs_out);     // cleared above
 }
 }  // namespace
 

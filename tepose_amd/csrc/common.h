@@ -299,14 +299,20 @@ struct H3SArgs {
   int M, N;
   const float* row_scale;                // optional [M], as H3Args::row_scale (then pA = 1)
   int shape16;                           // 1: v_mfma_f32_16x16x32_f16 instead of 32x32x16 (gemm_h3s16.hip; needs Kp % 32 == 0)
+  // barrier-free kernels (gemm_h3s16c.hip): where a wave whose bounded LDS poll expired reports it -- the forward's status word
+  // (workspace sync region, agent scope) and the handle's host-visible fault word (system scope); nullptr: debug counter + NaN only
+  unsigned* status = nullptr;
+  unsigned* fault = nullptr;
+  unsigned inject = 0;                   // tests: added to every poll target (1 = no poll can ever be met)
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // tag 0: the layer-0 projection (own kernel symbol for profiles)                                // state planes a GRU step writes
 hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
 bool gemm_h3s16_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag);   // gemm_h3s16.hip
-hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag);  // gemm_h3s16c.hip: experiment, no barriers in the K loop
+hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag);  // gemm_h3s16c.hip: no barriers in the K loop (default for the plain products)
 unsigned h3s16c_read_err();
+void h3s16c_warm();                    // allocates the debug error counter (at handle creation: never inside a stream capture)
 bool gru_h3s16c_ok(const H3SBatch& b);
 hipError_t launch_gru_h3s16c(const H3SBatch& b, hipStream_t s);         // gemm_h3s16c.hip: persistent barrier-free fused GRU step
 bool gru_h3s16_ok(const H3SBatch& b);

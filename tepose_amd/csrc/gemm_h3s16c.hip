@@ -105,12 +105,13 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
     if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt0 + 4u * (unsigned)slot), "v"(1u) : "memory");
   };
   bool dead = false;
+  const unsigned INJ = a.inject;
   auto poll = [&](int slot, int target) __attribute__((always_inline)) {
     const unsigned addr = cnt0 + 4u * (unsigned)slot;
     for (int spins = 0;; ++spins) {
       unsigned v;
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-      if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - (unsigned)target) >= 0) break;
+      if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - (unsigned)target - INJ) >= 0) break;
       if (spins > SPIN) { dead = true; break; }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -280,9 +281,11 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
 #undef TEPOSE_C_READ_A
 #undef TEPOSE_C_READ_B
 #undef TEPOSE_C_WAIT_B
-  if (dead && lane == 0) {
+  if (dead && lane == 0) {                                   // never a plausible-looking wrong result with rc 0: NaN + the failure channel
     if (err) atomicAdd(err, 1u);
     a.C[0] = __builtin_nanf("");
+    if (a.status) __hip_atomic_store(a.status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.fault) __hip_atomic_store(a.fault, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -371,12 +374,13 @@ __global__ void __launch_bounds__(512) gru_h3s16c_kernel(H3SBatch batch, int til
     if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt0 + 4u * (unsigned)slot), "v"(1u) : "memory");
   };
   bool dead = false;
+  const unsigned INJ = batch.p[0].inject;
   auto poll = [&](int slot, int target) __attribute__((always_inline)) {
     const unsigned addr = cnt0 + 4u * (unsigned)slot;
     for (int spins = 0;; ++spins) {
       unsigned v;
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-      if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - (unsigned)target) >= 0) break;
+      if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - (unsigned)target - INJ) >= 0) break;
       if (spins > SPIN) { dead = true; break; }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -549,6 +553,8 @@ __global__ void __launch_bounds__(512) gru_h3s16c_kernel(H3SBatch batch, int til
   if (dead && lane == 0) {
     if (err) atomicAdd(err, 1u);
     batch.gate[0].hout[0] = __builtin_nanf("");
+    if (batch.p[0].status) __hip_atomic_store(batch.p[0].status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (batch.p[0].fault) __hip_atomic_store(batch.p[0].fault, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -585,6 +591,8 @@ hipError_t launch_gru_h3s16c(const H3SBatch& b, hipStream_t s) {
   hipLaunchKernelGGL(gru_h3s16c_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, b, tM, tj, GM, h3s16c_err());
   return hipGetLastError();
 }
+
+void h3s16c_warm() { (void)h3s16c_err(); }
 
 unsigned h3s16c_read_err() {
   unsigned v = 0;

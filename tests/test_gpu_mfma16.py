@@ -19,6 +19,8 @@ SHAPES = [(2, 1024, 2305, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (3, 512, 204
 
 @pytest.mark.parametrize('knob', ['1', '2', '3', '5', '13', '25'])     # bit 1 plain products, bit 2 GRU step (8 waves), bit 4 GRU step (4 waves of 64 x 96), bit 8 plain products barrier-free, bit 16 GRU step persistent + barrier-free
 def test_mfma16_kernels_against_the_default_shape_and_the_fp64_oracle(monkeypatch, knob):
+    from tepose_amd import _lib
+    errs0 = int(_lib.load().tepose_debug_kernel_errors())            # process-wide counter (tests/test_gpu_status.py forces give-ups on purpose)
     for L, H, B, T in SHAPES:
         smpl_np = synth.synthetic_smpl(0)
         state = synth.synthetic_state_dict(L, H, 11)
@@ -42,5 +44,4 @@ def test_mfma16_kernels_against_the_default_shape_and_the_fp64_oracle(monkeypatc
         with torch.no_grad():
             ref2 = O.encoder_fwd(enc, torch.from_numpy(synth.synthetic_windows(B, T, 42)[rows]).double(), L).numpy()
         assert np.abs(fb[rows] - ref2).max() < 2e-5, (L, H, B, T)
-    from tepose_amd import _lib
-    assert _lib.load().tepose_debug_kernel_errors() == 0            # no wave of the barrier-free kernels ever gave up a poll
+    assert int(_lib.load().tepose_debug_kernel_errors()) == errs0    # no wave of the barrier-free kernels ever gave up a poll

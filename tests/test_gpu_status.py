@@ -199,3 +199,41 @@ def test_fault_is_attributed_to_the_forward_not_the_handle(smpl_np, monkeypatch)
     assert torch.isfinite(oa['verts']).all()
     eng.set_persistent(True)
     assert eng.uses_persistent(BA) and not eng.degraded
+
+
+def test_barrier_free_projection_give_up_reaches_the_failure_channel(smpl_np, monkeypatch):
+    """csrc/gemm_h3s16c.hip has no workgroup barriers: its waves wait on LDS arrival counters with BOUNDED polls.  A poll that
+    expires (only a kernel bug or a hardware fault can make it: there is no dependence between workgroups) must not end as NaN
+    with rc 0 either: the kernel raises the forward's status word and the handle's fault word (TEPOSE_TEST_FAULT bit 2 adds one
+    to every poll target).  Large batches are never synchronised by the library, so the channel is the lazy one: the NEXT entry
+    point refuses with TEPOSE_E_TIMEOUT, tepose_forward_status on the forward's workspace says so once."""
+    from tepose_amd import _lib
+    model, state = _faulty_model(monkeypatch, smpl_np, 4, mode='lazy')
+    eng, lib = model._engine, model._engine.lib
+    B, T = 600, 16                                                 # 9600 rows: the layer-0 projection runs on the persistent 256 x 256-tile kernel
+    x = torch.from_numpy(synth.synthetic_windows(B, T, 31)).cuda()
+    assert 'persist16c' in eng.kernel_info()['projection']
+    errs0 = int(lib.tepose_debug_kernel_errors())
+    with torch.no_grad():
+        feat = model.encoder(x)                                     # rc 0: nothing has been synchronised yet
+    torch.cuda.synchronize()
+    assert int(lib.tepose_debug_kernel_errors()) > errs0           # the kernel's own counter
+    assert lib.tepose_status_peek(eng.handle) != 0                 # the handle's host-visible fault word is up
+    with pytest.raises(_lib.TeposeTimeout):                        # ... so the next entry point refuses before queueing more work
+        with torch.no_grad():
+            model.encoder(x)
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == _lib.E_TIMEOUT
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0       # once
+    # without the injected fault the same handle is healthy again
+    assert lib.tepose_debug_set_test_fault(eng.handle, 0) == 0
+    eng.check_status()
+    with torch.no_grad():
+        good = model.encoder(x)
+    torch.cuda.synchronize()
+    assert lib.tepose_status_peek(eng.handle) == 0 and torch.isfinite(good).all()
+    from oracle import tepose_ref as O
+    enc, _ = O.split_state_dict(state, torch.float64)
+    with torch.no_grad():
+        ref = O.encoder_fwd(enc, x[:64].cpu().double(), 2)
+    assert (good[:64].cpu().double() - ref).abs().max() < 2e-5
+    del feat
