@@ -80,6 +80,7 @@ struct tepose_model {
   unsigned* fault = nullptr;
   bool persist = true;                          // false: step-per-launch kernels at every batch size (tepose_set_persistent)
   unsigned spin_limit = 1u << 21;               // polls (~1 us each) before a wait gives up
+  int gi_blk = 1;                               // TEPOSE_GI_BLK: large batches keep the layer >= 1 gate pre-activations in the 16 x 16-blocked layout (common.h gi_blk_offset)
   unsigned test_fault = 0;                      // TEPOSE_TEST_FAULT: bit 0 recurrent kernel, bit 1 regressor kernel wait for arrivals that never come
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
@@ -536,6 +537,8 @@ static void read_env_knobs(tepose_model* m) {
   if (e && atol(e) > 0) m->spin_limit = (unsigned)atol(e);
   e = getenv("TEPOSE_TEST_FAULT");                  // tests only: make the persistent kernels' waits unmeetable
   m->test_fault = e ? (unsigned)atoi(e) : 0u;
+  e = getenv("TEPOSE_GI_BLK");
+  m->gi_blk = e ? atoi(e) : 1;
   // the symbols a rocprofv3 kernel trace of a large-batch forward (B >= s_min_b, B * T >= 8192) lists for the two dominant
   // launch families -- what a committed profile must name to describe THIS binary with THESE knobs (bench.py checks)
   const char* h3sp = getenv("TEPOSE_H3S_PERSIST");
@@ -1192,6 +1195,7 @@ struct G0Src {
   int first, ring;                 // ring == 0: no wrap
   const float* last; long last_ld; // newest frame's projections or nullptr
   const float* single; long single_ld;   // L == 1: source of the one consumed rec.l0 forward step
+  long blk = 0;                    // != 0: base is in the blocked layout (common.h gi_blk_offset), floats between 16-row tiles; frames are row_stride * B apart
 };
 
 int prof_mark(tepose_model* mm, hipStream_t s) {     // next event of the GRU-interval list
@@ -1219,6 +1223,10 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   // single-accumulator kernels (gemm_h3s.hip)
   const bool sf = h3 && m->gru_single_acc && B >= m->s_min_b;
   const size_t n128 = (size_t)round_up(H3, 128);
+  // layer >= 1 gate pre-activations in the blocked layout (common.h gi_blk_offset): producer = the barrier-free projection kernel, consumers =
+  // gru_h3s16_kernel / gru_first16_kernel / gru_first_kernel -- only with the default kernel selection (any other knob keeps [rows][3 Hp])
+  const bool gblk = sf && m->gi_blk && (m->mfma16 & 9) == 9 && (m->mfma16 & 6) && !(m->mfma16 & 16) && Hp % 32 == 0 && gemm_h3s_blocked_ok();
+  if (src.blk && !gblk) return (int)hipErrorInvalidValue;   // the caller projected layer 0 into the blocked layout: every consumer here must read it
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t w_s, float w_scale, size_t bias,
                   float* out, int M) -> int {
@@ -1237,6 +1245,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       if (w.sync) a.status = sync_gru_status(m, w.sync);
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
+      a.c_blk_hp = gblk ? Hp : 0;
       return (int)launch_gemm_h3s(a, s);
     }
     const EncWs::View v = w.view(in);
@@ -1255,8 +1264,9 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       for (int d = 0; d < a.ndir; ++d) {
         const EncWs::View vo = w.view16(a.d[d].hout);
         if (!vo.hi) return (int)hipErrorInvalidValue;
-        const GateDir g{a.d[d].gi, a.d[d].ldgi, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh, a.d[d].hout, a.d[d].ldo,
-                        vo.hi, vo.lo, vo.kst};
+        GateDir g{a.d[d].gi, a.d[d].ldgi, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh, a.d[d].hout, a.d[d].ldo,
+                  vo.hi, vo.lo, vo.kst};
+        g.gi_blk = a.d[d].gi_blk;
         b.gate[d] = g;
         gb.d[d] = g;
         if (!a.first) {
@@ -1299,7 +1309,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   auto gi0 = [&](int t, int dir, const float*& p, long& ld) {
     if (src.last && t == T - 1) { p = src.last + (long)dir * H3; ld = src.last_ld; return; }
     const int slot = src.ring ? (src.first + t) % src.ring : t;
-    p = src.base + (long)slot * src.frame_stride + (long)dir * H3;
+    p = src.base + (long)slot * src.frame_stride + (long)dir * H3 * (src.blk ? 16 : 1);
     ld = src.row_stride;
   };
   // small batches: all T steps of a layer in one persistent launch (gru_seq.hip); its arrival counters are zeroed
@@ -1382,8 +1392,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       {  // gru_fwd layer l, frame t = st
         GruDir& d = a.d[nd++];
         d.Whh = Bl + m->fwd[l].whh; d.bhh = Bl + m->fwd[l].bhh;
-        if (l == 0) gi0(st, 0, d.gi, d.ldgi);
-        else { d.gi = gf + goff(st); d.ldgi = ldg; }
+        if (l == 0) { gi0(st, 0, d.gi, d.ldgi); d.gi_blk = src.blk; }
+        else { d.gi = gf + goff(st); d.ldgi = ldg; d.gi_blk = gblk ? (long)H3 * 16 : 0; }
         if (!top) {
           d.hprev = sf + (long)(st - 1) * Bs * Hp; d.ldh = Hp;
           d.hout = sf + (long)st * Bs * Hp; d.ldo = Hp;
@@ -1396,8 +1406,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         GruDir& d = a.d[nd++];
         const int i = T - 1 - st;
         d.Whh = Bl + m->rec_r[l].whh; d.bhh = Bl + m->rec_r[l].bhh;
-        if (l == 0) gi0(st, 1, d.gi, d.ldgi);
-        else { d.gi = grr + goff(i); d.ldgi = ldg; }
+        if (l == 0) { gi0(st, 1, d.gi, d.ldgi); d.gi_blk = src.blk; }
+        else { d.gi = grr + goff(i); d.ldgi = ldg; d.gi_blk = gblk ? (long)H3 * 16 : 0; }
         if (!top) {
           d.hprev = sr + (long)(i + 1) * Bs * 2 * Hp + Hp; d.ldh = 2 * Hp;
           d.hout = sr + (long)i * Bs * 2 * Hp + Hp; d.ldo = 2 * Hp;
@@ -1410,8 +1420,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       if (!top) {  // gru_rec layer l, forward direction: flipped index i = st (frame T-1-st)
         GruDir& d = a.d[nd++];
         d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
-        if (l == 0) gi0(T - 1 - st, 2, d.gi, d.ldgi);
-        else { d.gi = grf + goff(st); d.ldgi = ldg; }
+        if (l == 0) { gi0(T - 1 - st, 2, d.gi, d.ldgi); d.gi_blk = src.blk; }
+        else { d.gi = grf + goff(st); d.ldgi = ldg; d.gi_blk = gblk ? (long)H3 * 16 : 0; }
         d.hprev = sr + (long)(st - 1) * Bs * 2 * Hp; d.ldh = 2 * Hp;
         d.hout = sr + (long)st * Bs * 2 * Hp; d.ldo = 2 * Hp;
       }
@@ -1463,7 +1473,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       GruDir& d = a.d[0];
       d.Whh = Bl + m->rec_f[l].whh; d.bhh = Bl + m->rec_f[l].bhh;
       if (l == 0) { d.gi = src.single; d.ldgi = src.single_ld; }
-      else { d.gi = grf; d.ldgi = H3; }
+      else { d.gi = grf; d.ldgi = H3; d.gi_blk = gblk ? (long)H3 * 16 : 0; }
       d.hprev = w.ytop; d.ldh = 2 * Hp;
       d.hout = w.ytop; d.ldo = 2 * Hp;
       const size_t wp[3] = {m->rec_f[l].whh_p, 0, 0};
@@ -1594,12 +1604,17 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
     g0mid = 2.1 * (double)r_mid <= (double)r_old + 0.15;
   }
   const bool g0s = g0big || g0mid;
+  // large batches on the default kernels: layer-0 gate pre-activations FRAME-major (plane row t * B + b: a GRU step then reads B consecutive
+  // rows) and in the 16 x 16-blocked layout (common.h gi_blk_offset) -- the same condition as encoder_core's `gblk`, plus whole row tiles per frame
+  const bool g0blk = g0big && !g0mid && m->gru_single_acc && B >= m->s_min_b && m->gi_blk && (m->mfma16 & 9) == 9 && (m->mfma16 & 6) &&
+                     !(m->mfma16 & 16) && Hp % 32 == 0 && B % 16 == 0 && gemm_h3s_blocked_ok();
   // the caller's windows -> planes with one power-of-two scale per row (any finite fp32 magnitude; DESIGN 4b "range")
   // (with zero_sync the kernel also clears the forward's arrival counters / granules: it is the forward's first kernel)
   // (the forward's first kernel also clears its sync region -- arrival counters, granules, STATUS words -- so that a give-up of the
   // layer-0 projection (barrier-free kernel, gemm_h3s16c.hip) is not wiped by a clearing that comes after it)
   (void)zero_sync;
-  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, (void*)w.sync, w.sync ? sync_zero_bytes(m, B) : 0));
+  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, (void*)w.sync, w.sync ? sync_zero_bytes(m, B) : 0,
+                               g0blk ? T : 0));
   else CK(launch_pad_input(x, w.xp, BT, s));
   if (!h3 && w.sync) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
   {
@@ -1623,6 +1638,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       if (w.sync) a.status = sync_gru_status(m, w.sync);
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
+      a.c_blk_hp = g0blk ? Hp : 0;
       if (g0mid) CK(launch_gemm_h3s_mid(a, s));
       else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {
@@ -1667,6 +1683,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
   }
 
   G0Src src{w.g0, ld0, (long)T * ld0, 0, 0, nullptr, 0, w.g0c, H3};
+  if (g0blk) { src.frame_stride = (long)B * ld0; src.row_stride = ld0; src.blk = (long)ld0 * 16; }
   if (feat_planes) {
     // live at tail time: the tail product's A planes and the fp32 final states; everything carved before them is dead
     const char* end = (const char*)(feat_planes->lo + (size_t)B * kFeat + 128);

@@ -52,6 +52,7 @@ struct GruDir {
   const float* bhh;              // [3*Hp], natural order g*Hp + j
   const float* gi; long ldgi;    // gi[row*ldgi + g*Hp + j] = x W_ih^T + b_ih
   float* hout; long ldo;
+  long gi_blk = 0;               // != 0: gi is in the 16 x 16-blocked layout (gi_blk_offset below), floats between 16-row tiles
 };
 struct GruArgs {
   GruDir d[3];
@@ -191,7 +192,23 @@ struct GateDir {
   const float* hprev; long ldh;       // fp32 previous state (unused by the first step)
   float* hout; long ldo;              // fp32 new state
   half_t *hout_hi, *hout_lo; long okst;   // its planes: view base (row % 16 == 0), halfs between 32-column groups
+  long gi_blk = 0;                    // as GruDir::gi_blk
 };
+// Blocked layout of the gate pre-activations of large batches (round 4; internal scratch between the barrier-free projection kernel
+// and the fused GRU step / first-step kernels): 16 rows x 16 hidden units of one gate = one 1 KB block, stored in the order of the
+// 16x16x32 MFMA's transposed C fragment (lane = (unit % 16 / 4) * 16 + row % 16 holds 4 consecutive units) -- a wave instruction of the
+// producer's tile store and of the consumer's cell-update load moves ONE contiguous KB instead of 16 rows x 64 bytes.  Inside a
+// 16-row tile the blocks are ordered [unit / 32][unit / 16 & 1][gate]: the six blocks a wave reads per row tile are 6 KB in a row.
+// Offset (floats) of element (row, gate, unit) relative to the view's first row tile; rt_stride = 3 Hp * 16 for a [rows][3 Hp] matrix.
+__host__ __device__ inline long gi_blk_block(int gate, int unit) { return ((long)(unit >> 5) * 6 + ((unit >> 4) & 1) * 3 + gate) * 256; }
+// column `col` of a [rows][ND * 3 Hp] matrix ([dir][gate][unit]): the block's offset inside its row tile (directions are 3 Hp * 16 floats apart)
+__host__ __device__ inline long gi_blk_col_block(int col, int hp) {
+  const int dgi = col / hp, unit = col - dgi * hp, dir = dgi / 3;
+  return (long)dir * 3 * hp * 16 + gi_blk_block(dgi - 3 * dir, unit);
+}
+__host__ __device__ inline long gi_blk_offset(long row, int gate, int unit, long rt_stride) {
+  return (row >> 4) * rt_stride + gi_blk_block(gate, unit) + ((((unit & 15) >> 2) * 16 + (row & 15)) << 2) + (unit & 3);
+}
 struct H3Batch { H3Args p[3]; GateDir gate[3]; int n; int Hp; };
 // up to 3 independent products of the same M, N, Kp in one launch
 hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
@@ -279,7 +296,8 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 // zero / zero_bytes (multiple of 16): the kernel also clears that block -- the forward's arrival counters and granules,
 // when this is the forward's first kernel (saves the memset node).
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
-                             float* row_scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0);
+                             float* row_scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0,
+                             int permT = 0);   // permT = T: source rows [B][T] -> plane rows / row_scale frame-major (t * B + b)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s);
 size_t gemm_h3_ws_bytes(int M, int N, int K);
@@ -304,11 +322,13 @@ struct H3SArgs {
   unsigned* status = nullptr;
   unsigned* fault = nullptr;
   unsigned inject = 0;                   // tests: added to every poll target (1 = no poll can ever be met)
+  int c_blk_hp = 0;                      // != 0 (= Hp): C is a [rows][3 Hp] gate pre-activation matrix, written in the blocked layout (gi_blk_offset)
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // tag 0: the layer-0 projection (own kernel symbol for profiles)                                // state planes a GRU step writes
 hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
 bool gemm_h3s16_ok(const H3SArgs& a);
+bool gemm_h3s_blocked_ok();
 hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag);   // gemm_h3s16.hip
 hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag);  // gemm_h3s16c.hip: no barriers in the K loop (default for the plain products)
 unsigned h3s16c_read_err();

@@ -97,7 +97,7 @@ template <int NP, bool F16>
 __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ src, long ld, long rows, int K, int Kp,
                                                          long R, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                          float* __restrict__ row_scale, uint4* __restrict__ zero,
-                                                         long zero_n) {
+                                                         long zero_n, int permT) {
   typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float buf[8 * kRowsLd];
   // the forward's arrival counters / granules (first kernel of a forward: later kernels see them cleared)
@@ -109,7 +109,9 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     const int lr = 2 * wave + rr;
     const long row = row0 + lr;
     if (row >= rows) continue;                                // wave-uniform
-    const float* x = src + row * ld;
+    // permT = T: the source is [B][T] windows x frames, the planes (and row_scale) are FRAME-major: plane row t * B + b = source row b * T + t
+    const long srow = permT ? (row % (rows / permT)) * permT + row / (rows / permT) : row;
+    const float* x = src + srow * ld;
     float v0[NP], v1[NP];
     float m = 0.f;
     bool bad = false;
@@ -246,8 +248,9 @@ static int split_few_max_rows() {
 }
 
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
-                             float* row_scale, hipStream_t s, void* zero, size_t zero_bytes) {
+                             float* row_scale, hipStream_t s, void* zero, size_t zero_bytes, int permT) {
   if (rows <= 0) return hipSuccess;
+  if (permT && (rows % permT != 0 || rows <= split_few_max_rows())) return hipErrorInvalidValue;
   if (zero_bytes % 16 != 0) return hipErrorInvalidValue;
   if (Kp > 64 * 2 * 17 || Kp > kRowsLd || (Kp & 31)) return hipErrorInvalidValue;        // the [., 2144] input rows
   if (rows <= split_few_max_rows() && Kp <= 4096) {
@@ -262,10 +265,10 @@ hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp
   const dim3 grid((unsigned)((rows + 7) / 8));
   if (fmt16)
     hipLaunchKernelGGL((split_rows_kernel<17, true>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
-                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
+                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), permT);
   else
     hipLaunchKernelGGL((split_rows_kernel<17, false>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
-                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
+                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), permT);
   return hipGetLastError();
 }
 
@@ -800,8 +803,12 @@ __global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int
     float hv[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const float rg = g_sigmoid(gi[c] + d.bhh[j + c]), zg = g_sigmoid(gi[Hp + c] + d.bhh[Hp + j + c]);
-      const float ng = g_tanh(gi[2 * Hp + c] + rg * d.bhh[2 * Hp + j + c]);
+      float xr, xz, xn;
+      if (d.gi_blk) {        // blocked gate pre-activations (common.h gi_blk_offset)
+        xr = d.gi[gi_blk_offset(row, 0, j + c, d.gi_blk)]; xz = d.gi[gi_blk_offset(row, 1, j + c, d.gi_blk)]; xn = d.gi[gi_blk_offset(row, 2, j + c, d.gi_blk)];
+      } else { xr = gi[c]; xz = gi[Hp + c]; xn = gi[2 * Hp + c]; }
+      const float rg = g_sigmoid(xr + d.bhh[j + c]), zg = g_sigmoid(xz + d.bhh[Hp + j + c]);
+      const float ng = g_tanh(xn + rg * d.bhh[2 * Hp + j + c]);
       hv[c] = (1.f - zg) * ng;
     }
     d.hout[row * d.ldo + j] = hv[0];
@@ -839,8 +846,13 @@ __global__ void __launch_bounds__(256) gru_first16_kernel(GateBatch gb, int M, i
   f32x4v gr[2], gz[2], gn[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const float* gi = d.gi + row * d.ldgi + tj * 128 + wave * 32 + u * 16 + 4 * g;
-    gr[u] = *(const f32x4v*)gi; gz[u] = *(const f32x4v*)(gi + Hp); gn[u] = *(const f32x4v*)(gi + 2 * Hp);
+    if (d.gi_blk) {          // blocked gate pre-activations (common.h gi_blk_offset): this wave's 16 x 16 block of a gate is one contiguous KB
+      const float* gq = d.gi + (long)tm * d.gi_blk + gi_blk_block(0, tj * 128 + wave * 32 + u * 16) + lane * 4;
+      gr[u] = *(const f32x4v*)gq; gz[u] = *(const f32x4v*)(gq + 256); gn[u] = *(const f32x4v*)(gq + 512);
+    } else {
+      const float* gi = d.gi + row * d.ldgi + tj * 128 + wave * 32 + u * 16 + 4 * g;
+      gr[u] = *(const f32x4v*)gi; gz[u] = *(const f32x4v*)(gi + Hp); gn[u] = *(const f32x4v*)(gi + 2 * Hp);
+    }
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {

@@ -628,7 +628,8 @@ hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag) {
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   H3SBatch b{};
   b.p[0] = a; b.n = 1;
-  if (h3s_persist() && a.shape16 == 3 && gemm_h3s16_ok(a)) return launch_gemm_h3s16c(a, s, tag);   // TEPOSE_MFMA16 bit 8 (experiment)
+  if (h3s_persist() && a.shape16 == 3 && gemm_h3s16_ok(a)) return launch_gemm_h3s16c(a, s, tag);   // TEPOSE_MFMA16 bit 8: barrier-free (default)
+  if (a.c_blk_hp) return hipErrorInvalidValue;              // only that kernel writes the blocked gate pre-activation layout
   if (h3s_persist() && a.shape16 && gemm_h3s16_ok(a)) return launch_gemm_h3s16(a, s, tag);
   if (h3s_persist()) {
     const int nt = tilesM * tilesN;
@@ -643,6 +644,7 @@ hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag) {
 // Mid-size products (a few hundred to a few thousand rows) whose N is a multiple of 288 -- the stacked layer-0 block, 9 Hp
 // columns: 128 x 288 tiles, 12 waves of 32 x 96 (three per SIMD).  B * T = 1024 rows x 9216 columns are exactly 256 tiles
 // = one round of the chip, where 128 x 128 tiles of the two-accumulator kernel make 576 = 2.25 rounds.
+bool gemm_h3s_blocked_ok() { return h3s_persist(); }     // the blocked gate pre-activation layout needs the persistent 16x16x32 kernels
 bool gemm_h3s_mid_ok(const H3SArgs& a) { return a.N % 288 == 0 && a.Kp % 16 == 0 && a.M > 0; }
 hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s) {
   if (!gemm_h3s_mid_ok(a)) return hipErrorInvalidValue;
@@ -662,8 +664,11 @@ hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s) {
   // block = 128 rows x 64 hidden units x 3 gates (4 x 2 waves of 32 x 96): 100 VGPRs and an 80 KB ring, so two blocks
   // share a CU and cover each other's pipeline fill and store drain.  Measured against 128 x 128 units (148 VGPRs,
   // one block per CU): -1 % at B = 8192, and it keeps winning down to B ~ 2048; 256 rows x 64 units: +2.5 %.
-  if (b.p[0].shape16 == 4 && gru_h3s16c_ok(b)) return launch_gru_h3s16c(b, s);        // TEPOSE_MFMA16 bit 16
+  bool blk = false;
+  for (int d = 0; d < b.n; ++d) blk = blk || b.gate[d].gi_blk != 0;
+  if (b.p[0].shape16 == 4 && gru_h3s16c_ok(b) && !blk) return launch_gru_h3s16c(b, s);        // TEPOSE_MFMA16 bit 16
   if (b.p[0].shape16 && gru_h3s16_ok(b)) return launch_gru_h3s16(b, s);
+  if (blk) return hipErrorInvalidValue;                     // only gru_h3s16_kernel reads the blocked gate pre-activation layout
   const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
   hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 2, true>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
   return hipGetLastError();

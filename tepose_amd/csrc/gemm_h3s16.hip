@@ -19,6 +19,21 @@
 
 #include "common.h"
 
+#ifndef TEPOSE_G16_RT
+#define TEPOSE_G16_RT 1     // row tiles of the cell update whose loads are issued together (A/B builds: 1, 2, 4)
+#endif
+#ifndef TEPOSE_G16_PRIO
+#define TEPOSE_G16_PRIO 0   // A/B builds: bits 0-1 wave priority in the K loop, bits 2-3 in the cell update (0 = never touched)
+#endif
+#ifndef TEPOSE_G16_ABL
+#define TEPOSE_G16_ABL 0    // timing-only ablations of gru_h3s16_kernel (WRONG results; tools/g16_ablate.sh): 1 no LDS-DMA, 2 no cell-update loads, 4 no fp32 state
+#endif                     // store, 8 no plane stores, 16 no MFMA, 64 no cell update at all
+#if TEPOSE_G16_ABL & 16
+#define G16_MFMA(b, a, c) (c)
+#else
+#define G16_MFMA(b, a, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c, 0, 0, 0)
+#endif
+
 #ifndef TEPOSE_S16_STAMPS
 #define TEPOSE_S16_STAMPS 0   // diagnostic builds only (tools/s16_stamps.py): wave 0 of workgroup 0 stamps s_memtime at the phases
 #endif                        // of its pair steps into a buffer of its own; the shipped kernel executes no stamp
@@ -27,6 +42,10 @@ namespace tepose {
 
 #if TEPOSE_S16_STAMPS
 __device__ unsigned long long tepose_s16_stamp_buf[8192];
+__device__ unsigned long long tepose_g16_stamp_buf[16 * 16];     // fused GRU step: wave 0 of 16 sampled workgroups, 16 stamps each (tools/g16_stamps.py)
+#define G16_STAMP(k) do { if (stamp_slot >= 0) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0) tepose_g16_stamp_buf[stamp_slot * 16 + (k)] = tm_; } } while (0)
+#else
+#define G16_STAMP(k) do { } while (0)
 #endif
 
 typedef float f32x4q __attribute__((ext_vector_type(4)));
@@ -367,10 +386,14 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
   auto dma_part = [&](int stage, int q) {
     if (REM == 0 || q < nd) {
       const unsigned dst = (unsigned)(size_t)lds + (unsigned)((stage % NST) * STAGE + (i0 + q) * 1024);
+#if !(TEPOSE_G16_ABL & 1)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                    :
                    : "v"(voff[q]), "s"(sbase[q]), "s"(dst)
                    : "m0", "memory");
+#else
+      asm volatile("" : : "v"(voff[q]), "s"(sbase[q]), "s"(dst) : "memory");
+#endif
       sbase[q] += kst[q];
     }
   };
@@ -391,8 +414,16 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4q{0.f, 0.f, 0.f, 0.f};
+#if TEPOSE_S16_STAMPS
+  const int stamp_slot = (blockIdx.y == 0 && wave == 0 && blockIdx.x % 64 == 5 && blockIdx.x / 64 < 16) ? (int)(blockIdx.x / 64) : -1;
+#endif
+  G16_STAMP(0);
+#if TEPOSE_G16_PRIO
+  __builtin_amdgcn_s_setprio(TEPOSE_G16_PRIO & 3);         // K loop: this wave's MFMAs / fragment reads before the cell-update VALU work of the CU's other workgroup
+#endif
   request_pair(0);
   request_pair(1);
+  G16_STAMP(1);
   // NEWER: pairs younger than pair p whose requests may stay in flight (1, or 0 at the last pair)
   // EXTRA: other vector-memory instructions younger than the pairs' requests that may stay in flight (the L2 touches below)
   auto pairstep = [&](int p, auto dma, auto newer, auto extra) __attribute__((always_inline)) {
@@ -439,7 +470,7 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            acc[i][2 * c + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], ah[i], acc[i][2 * c + u], 0, 0, 0);
+            acc[i][2 * c + u] = G16_MFMA(bh[X][u], ah[i], acc[i][2 * c + u]);
             const int n = i * 2 + u;
 #pragma unroll
             for (; q < (n + 1) * 2 * ND / (MT * 2); ++q)
@@ -449,12 +480,12 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int u = 0; u < 2; ++u)
-            acc[i][2 * c + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[X][u], ah[i], acc[i][2 * c + u], 0, 0, 0);
+            acc[i][2 * c + u] = G16_MFMA(bl[X][u], ah[i], acc[i][2 * c + u]);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int u = 0; u < 2; ++u)
-            acc[i][2 * c + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], al[i], acc[i][2 * c + u], 0, 0, 0);
+            acc[i][2 * c + u] = G16_MFMA(bh[X][u], al[i], acc[i][2 * c + u]);
         __builtin_amdgcn_sched_barrier(0);
         if (c == 0) { TEPOSE_GRU_READ_B(2) }
       }
@@ -512,10 +543,18 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
   pairstep(NP - 2, F_{}, I1{}, I0{});
   pairstep(NP - 1, F_{}, I0{}, I0{});
 
+  G16_STAMP(2);
+#if TEPOSE_G16_PRIO
+  __builtin_amdgcn_s_setprio((TEPOSE_G16_PRIO >> 2) & 3);
+#endif
   // ---- cell update: lane (t, g) holds, for row tile i and unit tile u, rows m0 + wm * 32 + i * 16 + t and the hidden units
   // jb + u * 16 + 4 g .. + 3 of the three gates (W_hh tile j = gate * 2 + u of this wave's 96 rows)
   const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev | (size_t)d.bhh) & 15) == 0 && (d.ldo & 3) == 0 &&
                    (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
+#if TEPOSE_G16_ABL & 64
+  if (acc[0][0][0] == 12345.678f) d.hout[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3] + acc[0][5][0] + acc[3][4][1];
+  if (true) return;
+#endif
   // row tile outermost, the two unit tiles of a row together: lanes g = 0..3 of a row cover 64 bytes per unit tile, and the two unit tiles are the
   // two halves of ONE 128-byte line of every operand -- requested back to back instead of one whole gate-math pass apart
   {
@@ -527,53 +566,114 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
 #pragma unroll
       for (int c = 0; c < 4; ++c) { br[u][c] = d.bhh[jj[u] + c]; bz[u][c] = d.bhh[Hp + jj[u] + c]; bn[u][c] = d.bhh[2 * Hp + jj[u] + c]; }
     }
+    // RT row tiles per round: their 8 RT loads are issued together (one exposed round trip per round; the loads of a wave cannot be issued
+    // before its K loop ends -- vmcnt completes in order, an HBM-latency load ahead of the LDS-DMA requests would stall every pair step)
+    constexpr int RT = TEPOSE_G16_RT < MT ? TEPOSE_G16_RT : MT;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int row = m0 + wm * 16 * MT + i * 16 + t;
-      if (row >= a.M) continue;
-      f32x4q gr[2], gz[2], gn[2], hp[2];
+    for (int i0 = 0; i0 < MT; i0 += RT) {
+      f32x4q gr[RT][2], gz[RT][2], gn[RT][2], hp[RT][2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float* gi = d.gi + (long)row * d.ldgi + jj[u];
-        const float* hq = d.hprev + (long)row * d.ldh + jj[u];
-        if (vec) {
-          gr[u] = *(const f32x4q*)gi; gz[u] = *(const f32x4q*)(gi + Hp); gn[u] = *(const f32x4q*)(gi + 2 * Hp);
-          hp[u] = *(const f32x4q*)hq;
-        } else {
+      for (int ii = 0; ii < RT; ++ii) {
+        const int row = min(m0 + wm * 16 * MT + (i0 + ii) * 16 + t, a.M - 1);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { gr[u][c] = gi[c]; gz[u][c] = gi[Hp + c]; gn[u][c] = gi[2 * Hp + c]; hp[u][c] = hq[c]; }
+        for (int u = 0; u < 2; ++u) {
+          const float* gi = d.gi + (long)row * d.ldgi + jj[u];
+          const float* hq = d.hprev + (long)row * d.ldh + jj[u];
+#if TEPOSE_G16_ABL & 2
+          if (vec) { gr[ii][u] = f32x4q{0.1f, 0.2f, 0.3f, 0.4f}; gz[ii][u] = gr[ii][u]; gn[ii][u] = gr[ii][u]; hp[ii][u] = gr[ii][u]; asm volatile("" : : "v"(gi), "v"(hq)); } else {
+#else
+#if TEPOSE_G16_ABL & 128
+          if (vec) {     // timing only: the same bytes as ONE contiguous 1 KB per wave instruction, 24 KB per wave and row tile... (wrong data)
+            const float* gq = d.gi + ((long)((blockIdx.x * 4 + wave) * MT + (i0 + ii)) * 6 + u * 3) * 256 + lane * 4;
+            gr[ii][u] = *(const f32x4q*)gq; gz[ii][u] = *(const f32x4q*)(gq + 256); gn[ii][u] = *(const f32x4q*)(gq + 512);
+#if TEPOSE_G16_ABL & 256
+            hp[ii][u] = *(const f32x4q*)(d.hprev + ((long)((blockIdx.x * 4 + wave) * MT + (i0 + ii)) * 2 + u) * 256 + lane * 4);
+#else
+            hp[ii][u] = *(const f32x4q*)hq;
+#endif
+          } else {
+#else
+          if (vec && d.gi_blk) {
+            // blocked gate pre-activations (common.h gi_blk_offset): 1 KB per wave instruction, this lane's 16 bytes at lane * 16
+            const int rt = min(m0 + wm * 16 * MT + (i0 + ii) * 16, a.M - 1) >> 4;
+            const float* gq = d.gi + (long)rt * d.gi_blk + gi_blk_block(0, jb + u * 16) + lane * 4;
+            gr[ii][u] = *(const f32x4q*)gq; gz[ii][u] = *(const f32x4q*)(gq + 256); gn[ii][u] = *(const f32x4q*)(gq + 512);
+            hp[ii][u] = *(const f32x4q*)hq;
+          } else if (vec) {
+            gr[ii][u] = *(const f32x4q*)gi; gz[ii][u] = *(const f32x4q*)(gi + Hp); gn[ii][u] = *(const f32x4q*)(gi + 2 * Hp);
+            hp[ii][u] = *(const f32x4q*)hq;
+          } else {
+#endif
+#endif
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (d.gi_blk) {
+                gr[ii][u][c] = d.gi[gi_blk_offset(row, 0, jj[u] + c, d.gi_blk)]; gz[ii][u][c] = d.gi[gi_blk_offset(row, 1, jj[u] + c, d.gi_blk)];
+                gn[ii][u][c] = d.gi[gi_blk_offset(row, 2, jj[u] + c, d.gi_blk)];
+              } else { gr[ii][u][c] = gi[c]; gz[ii][u][c] = gi[Hp + c]; gn[ii][u][c] = gi[2 * Hp + c]; }
+              hp[ii][u][c] = hq[c];
+            }
+          }
         }
       }
+      G16_STAMP(3 + 3 * (i0 / RT));                                // loads issued
+#if TEPOSE_S16_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      G16_STAMP(4 + 3 * (i0 / RT));                                // loads landed
+#endif
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = jb + u * 16 + 4 * g;
-        if (j >= Hp) continue;
-        f32x4q v;
-        _Float16 hh[4], ll[4];
+      for (int ii = 0; ii < RT; ++ii) {
+        const int i = i0 + ii;
+        const int row = m0 + wm * 16 * MT + i * 16 + t;
+        if (row >= a.M) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float hr = acc[i][0 + u][c] * a.inv_scale, hz = acc[i][2 + u][c] * a.inv_scale, hn = acc[i][4 + u][c] * a.inv_scale;
-          const float rg = s16_sigmoid(gr[u][c] + (hr + br[u][c]));
-          const float zg = s16_sigmoid(gz[u][c] + (hz + bz[u][c]));
-          const float ng = s16_tanh(gn[u][c] + rg * (hn + bn[u][c]));
-          v[c] = (1.f - zg) * ng + zg * hp[u][c];
-          const float sv = v[c] * batch.state_scale;
-          hh[c] = (_Float16)sv;
-          ll[c] = (_Float16)(sv - (float)hh[c]);
+        for (int u = 0; u < 2; ++u) {
+          const int j = jb + u * 16 + 4 * g;
+          if (j >= Hp) continue;
+          f32x4q v;
+          _Float16 hh[4], ll[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float hr = acc[i][0 + u][c] * a.inv_scale, hz = acc[i][2 + u][c] * a.inv_scale, hn = acc[i][4 + u][c] * a.inv_scale;
+            const float rg = s16_sigmoid(gr[ii][u][c] + (hr + br[u][c]));
+            const float zg = s16_sigmoid(gz[ii][u][c] + (hz + bz[u][c]));
+            const float ng = s16_tanh(gn[ii][u][c] + rg * (hn + bn[u][c]));
+            v[c] = (1.f - zg) * ng + zg * hp[ii][u][c];
+            const float sv = v[c] * batch.state_scale;
+            hh[c] = (_Float16)sv;
+            ll[c] = (_Float16)(sv - (float)hh[c]);
+          }
+          float* ho = d.hout + (long)row * d.ldo + j;
+          const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
+#if TEPOSE_G16_ABL & 4
+          asm volatile("" : : "v"(v), "v"(ho));
+#else
+          if (vec) {
+#if TEPOSE_G16_ABL & 512
+            *(f32x4q*)(d.hout + ((long)((blockIdx.x * 4 + wave) * MT + i) * 2 + u) * 256 + lane * 4) = v;     // timing only: contiguous 1 KB per instruction
+#else
+            *(f32x4q*)ho = v;
+#endif
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ho[c] = v[c];
+          }
+#endif
+#if TEPOSE_G16_ABL & 8
+          asm volatile("" : : "v"(hh[0]), "v"(hh[1]), "v"(hh[2]), "v"(hh[3]), "v"(ll[0]), "v"(ll[1]), "v"(ll[2]), "v"(ll[3]), "v"(o));
+#else
+          *(h16x4q*)((_Float16*)d.hout_hi + o) = h16x4q{hh[0], hh[1], hh[2], hh[3]};
+          *(h16x4q*)((_Float16*)d.hout_lo + o) = h16x4q{ll[0], ll[1], ll[2], ll[3]};
+#endif
         }
-        float* ho = d.hout + (long)row * d.ldo + j;
-        const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
-        if (vec) {
-          *(f32x4q*)ho = v;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) ho[c] = v[c];
-        }
-        *(h16x4q*)((_Float16*)d.hout_hi + o) = h16x4q{hh[0], hh[1], hh[2], hh[3]};
-        *(h16x4q*)((_Float16*)d.hout_lo + o) = h16x4q{ll[0], ll[1], ll[2], ll[3]};
       }
+      G16_STAMP(5 + 3 * (i0 / RT));                                // math done, stores issued
     }
   }
+#if TEPOSE_S16_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G16_STAMP(15);
+#endif
 }
 
 bool gru_h3s16_ok(const H3SBatch& b) {
@@ -598,6 +698,9 @@ hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s) {
 bool gemm_h3s16_ok(const H3SArgs& a) { return a.Kp % 32 == 0 && a.Kp >= 64; }
 
 #if TEPOSE_S16_STAMPS
+extern "C" int tepose_debug_g16_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tepose_g16_stamp_buf), (size_t)n * 8);
+}
 extern "C" int tepose_debug_s16_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tepose_s16_stamp_buf), (size_t)n * 8);
 }

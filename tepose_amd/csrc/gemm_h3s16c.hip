@@ -241,6 +241,24 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
       }
       float* c0 = a.C + (long)(tm0 + wm * 16 * MT + te) * a.ldc + tn0 + wn * 16 * NT + 4 * ge;
       const float* b0 = a.bias ? a.bias + tn0 + wn * 16 * NT + 4 * ge : nullptr;
+      if (a.c_blk_hp) {
+        // blocked gate pre-activations (common.h gi_blk_offset): every tile store is ONE contiguous KB (lane order = this fragment's)
+        const long rt_stride = (long)a.N * 16;
+        float* cb = a.C + (long)((tm0 + wm * 16 * MT) >> 4) * rt_stride + le * 4;
+        const int col0 = tn0 + wn * 16 * NT;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f32x4c bq = b0 ? *(const f32x4c*)(b0 + j * 16) : f32x4c{0.f, 0.f, 0.f, 0.f};
+          float* cj = cb + gi_blk_col_block(col0 + j * 16, a.c_blk_hp);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            f32x4c v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = acc[i][j][c] * rs[i] + bq[c];
+            *(f32x4c*)(cj + (long)i * rt_stride) = v;
+          }
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const f32x4c bq = b0 ? *(const f32x4c*)(b0 + j * 16) : f32x4c{0.f, 0.f, 0.f, 0.f};
@@ -251,6 +269,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
           for (int c = 0; c < 4; ++c) v[c] = acc[i][j][c] * rs[i] + bq[c];
           *(f32x4c*)(c0 + (long)i * 16 * a.ldc + j * 16) = v;
         }
+      }
       }
     } else {
 #pragma unroll
@@ -263,7 +282,11 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int col = tn0 + wn * 16 * NT + j * 16 + 4 * ge + c;
-            if (col < a.N) a.C[(long)row * a.ldc + col] = acc[i][j][c] * rsv + (a.bias ? a.bias[col] : 0.f);
+            if (col < a.N) {
+              const float v = acc[i][j][c] * rsv + (a.bias ? a.bias[col] : 0.f);
+              if (a.c_blk_hp) a.C[(long)(row >> 4) * a.N * 16 + gi_blk_col_block(col & ~15, a.c_blk_hp) + ((((col & 15) >> 2) * 16 + (row & 15)) << 2) + (col & 3)] = v;
+              else a.C[(long)row * a.ldc + col] = v;
+            }
           }
       }
     }

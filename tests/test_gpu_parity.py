@@ -73,7 +73,10 @@ def test_gemm_rejects_bad_arguments():
                                       # waves of 64 x 96; 128-row tiles, full and ragged; unit-tile counts 3, 4, 5, 8, 16) and the layer >= 1 projections on
                                       # gemm_h3s_persist16c_kernel (barrier-free); first steps on gru_first16_kernel where Hp % 128 == 0.  (The 32x32x16 kernels: tests/test_gpu_mfma16.py's TEPOSE_MFMA16=0 baseline.)
                                       (2, 192, 2100, 3), (2, 256, 2304, 3), (1, 320, 2050, 2), (3, 512, 2049, 2), (2, 1024, 2048, 2),
-                                      (2, 1024, 2305, 3)])
+                                      (2, 1024, 2305, 3),
+                                      # B * T >= 8192 AND B >= 2048 AND B % 16 == 0: layer-0 gate pre-activations frame-major + 16 x 16-blocked (common.h gi_blk_offset),
+                                      # layers >= 1 blocked whenever B >= 2048; a ragged last 128-row tile (2064 = 16 * 128 + 16), three layers
+                                      (2, 128, 2048, 4), (3, 256, 2064, 4), (2, 64, 2320, 5)])
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
     from oracle import tepose_ref as O
     model, state, _ = _model(L, H, 11, smpl_np)
