@@ -1267,6 +1267,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         GateDir g{a.d[d].gi, a.d[d].ldgi, a.d[d].bhh, a.d[d].hprev, a.d[d].ldh, a.d[d].hout, a.d[d].ldo,
                   vo.hi, vo.lo, vo.kst};
         g.gi_blk = a.d[d].gi_blk;
+        g.hprev_b = a.first ? nullptr : a.d[d].hprev_b; g.hp_blk = a.first ? 0 : a.d[d].hp_blk;
+        g.hout_b = a.d[d].hout_b; g.ho_blk = a.d[d].ho_blk;
         b.gate[d] = g;
         gb.d[d] = g;
         if (!a.first) {
@@ -1397,9 +1399,12 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         if (!top) {
           d.hprev = sf + (long)(st - 1) * Bs * Hp; d.ldh = Hp;
           d.hout = sf + (long)st * Bs * Hp; d.ldo = Hp;
+          if (gblk) { d.hprev_b = d.hprev; d.hp_blk = (long)Hp * 16; d.hout_b = d.hout; d.ho_blk = (long)Hp * 16; }
         } else {
           d.hprev = w.pf[(st + 1) & 1]; d.ldh = Hp;
           d.hout = w.pf[st & 1]; d.ldo = Hp;
+          // (the last state is read row-major by the tail; every earlier one only by the next step)
+          if (gblk) { d.hprev_b = d.hprev; d.hp_blk = (long)Hp * 16; if (st < T - 1) { d.hout_b = d.hout; d.ho_blk = (long)Hp * 16; } }
         }
       }
       {  // gru_rec layer l, reverse direction: flipped index i = T-1-st (frame st for layer 0)
@@ -1411,10 +1416,15 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         if (!top) {
           d.hprev = sr + (long)(i + 1) * Bs * 2 * Hp + Hp; d.ldh = 2 * Hp;
           d.hout = sr + (long)i * Bs * 2 * Hp + Hp; d.ldo = 2 * Hp;
+          if (gblk) {      // second half of the [., 2 Hp] slab: its blocks start Hp * 16 floats into every row tile
+            d.hprev_b = sr + (long)(i + 1) * Bs * 2 * Hp + (long)Hp * 16; d.hp_blk = (long)2 * Hp * 16;
+            d.hout_b = sr + (long)i * Bs * 2 * Hp + (long)Hp * 16; d.ho_blk = (long)2 * Hp * 16;
+          }
         } else {
           d.hprev = w.pr[(st + 1) & 1]; d.ldh = Hp;
           if (st == T - 1) { d.hout = w.ytop + Hp; d.ldo = 2 * Hp; }
           else { d.hout = w.pr[st & 1]; d.ldo = Hp; }
+          if (gblk) { d.hprev_b = d.hprev; d.hp_blk = (long)Hp * 16; if (st < T - 1) { d.hout_b = d.hout; d.ho_blk = (long)Hp * 16; } }
         }
       }
       if (!top) {  // gru_rec layer l, forward direction: flipped index i = st (frame T-1-st)
@@ -1424,6 +1434,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         else { d.gi = grf + goff(st); d.ldgi = ldg; d.gi_blk = gblk ? (long)H3 * 16 : 0; }
         d.hprev = sr + (long)(st - 1) * Bs * 2 * Hp; d.ldh = 2 * Hp;
         d.hout = sr + (long)st * Bs * 2 * Hp; d.ldo = 2 * Hp;
+        if (gblk) { d.hprev_b = d.hprev; d.hp_blk = (long)2 * Hp * 16; d.hout_b = d.hout; d.ho_blk = (long)2 * Hp * 16; }
       }
       a.ndir = nd;
       const size_t wp[3] = {m->fwd[l].whh_p, m->rec_r[l].whh_p, m->rec_f[l].whh_p};

@@ -53,6 +53,10 @@ struct GruDir {
   const float* gi; long ldgi;    // gi[row*ldgi + g*Hp + j] = x W_ih^T + b_ih
   float* hout; long ldo;
   long gi_blk = 0;               // != 0: gi is in the 16 x 16-blocked layout (gi_blk_offset below), floats between 16-row tiles
+  // != nullptr: the fp32 previous / new state in the same 16 x 16 blocks (st_blk_offset below; base of the view's first row tile, floats between row tiles);
+  // hprev / hout stay the row-major addresses (they also name the state's planes: EncWs::view16)
+  const float* hprev_b = nullptr; long hp_blk = 0;
+  float* hout_b = nullptr; long ho_blk = 0;
 };
 struct GruArgs {
   GruDir d[3];
@@ -193,7 +197,13 @@ struct GateDir {
   float* hout; long ldo;              // fp32 new state
   half_t *hout_hi, *hout_lo; long okst;   // its planes: view base (row % 16 == 0), halfs between 32-column groups
   long gi_blk = 0;                    // as GruDir::gi_blk
+  const float* hprev_b = nullptr; long hp_blk = 0;    // as GruDir::hprev_b / hout_b
+  float* hout_b = nullptr; long ho_blk = 0;
 };
+// fp32 recurrent state of large batches between two cell steps (its only reader is the next step's cell update): element (row, unit) of a view
+__host__ __device__ inline long st_blk_offset(long row, int unit, long rt_stride) {
+  return (row >> 4) * rt_stride + (long)(unit >> 4) * 256 + ((((unit & 15) >> 2) * 16 + (row & 15)) << 2) + (unit & 3);
+}
 // Blocked layout of the gate pre-activations of large batches (round 4; internal scratch between the barrier-free projection kernel
 // and the fused GRU step / first-step kernels): 16 rows x 16 hidden units of one gate = one 1 KB block, stored in the order of the
 // 16x16x32 MFMA's transposed C fragment (lane = (unit % 16 / 4) * 16 + row % 16 holds 4 consecutive units) -- a wave instruction of the

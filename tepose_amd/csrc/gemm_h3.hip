@@ -811,8 +811,8 @@ __global__ void __launch_bounds__(256) gru_first_kernel(GateBatch gb, int M, int
       const float ng = g_tanh(xn + rg * d.bhh[2 * Hp + j + c]);
       hv[c] = (1.f - zg) * ng;
     }
-    d.hout[row * d.ldo + j] = hv[0];
-    d.hout[row * d.ldo + j + 1] = hv[1];
+    if (d.ho_blk) { d.hout_b[st_blk_offset(row, j, d.ho_blk)] = hv[0]; d.hout_b[st_blk_offset(row, j + 1, d.ho_blk)] = hv[1]; }
+    else { d.hout[row * d.ldo + j] = hv[0]; d.hout[row * d.ldo + j + 1] = hv[1]; }
     half_t h0, l0, h1, l1;
     long o;
     if (scaled16) {       // planes of gemm_h3s.hip: value * kStateScale, [K/16][R][16]
@@ -869,7 +869,8 @@ __global__ void __launch_bounds__(256) gru_first16_kernel(GateBatch gb, int M, i
       hh[c] = (half_t)sv;
       ll[c] = (half_t)(sv - (float)hh[c]);
     }
-    *(f32x4v*)(d.hout + row * d.ldo + j) = hv;
+    if (d.ho_blk) *(f32x4v*)(d.hout_b + (long)tm * d.ho_blk + (j >> 4) * 256 + lane * 4) = hv;       // blocked state (common.h st_blk_offset)
+    else *(f32x4v*)(d.hout + row * d.ldo + j) = hv;
     const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
     *(h16x4v*)(d.hout_hi + o) = h16x4v{hh[0], hh[1], hh[2], hh[3]};
     *(h16x4v*)(d.hout_lo + o) = h16x4v{ll[0], ll[1], ll[2], ll[3]};

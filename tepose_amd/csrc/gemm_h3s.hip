@@ -665,10 +665,10 @@ hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s) {
   // share a CU and cover each other's pipeline fill and store drain.  Measured against 128 x 128 units (148 VGPRs,
   // one block per CU): -1 % at B = 8192, and it keeps winning down to B ~ 2048; 256 rows x 64 units: +2.5 %.
   bool blk = false;
-  for (int d = 0; d < b.n; ++d) blk = blk || b.gate[d].gi_blk != 0;
+  for (int d = 0; d < b.n; ++d) blk = blk || b.gate[d].gi_blk != 0 || b.gate[d].hp_blk != 0 || b.gate[d].ho_blk != 0;
   if (b.p[0].shape16 == 4 && gru_h3s16c_ok(b) && !blk) return launch_gru_h3s16c(b, s);        // TEPOSE_MFMA16 bit 16
   if (b.p[0].shape16 && gru_h3s16_ok(b)) return launch_gru_h3s16(b, s);
-  if (blk) return hipErrorInvalidValue;                     // only gru_h3s16_kernel reads the blocked gate pre-activation layout
+  if (blk) return hipErrorInvalidValue;                     // only gru_h3s16_kernel reads the blocked gate pre-activation / state layouts
   const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
   hipLaunchKernelGGL((gemm_h3s_kernel<1, 3, 4, 2, true>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj);
   return hipGetLastError();

@@ -575,6 +575,7 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
 #pragma unroll
       for (int ii = 0; ii < RT; ++ii) {
         const int row = min(m0 + wm * 16 * MT + (i0 + ii) * 16 + t, a.M - 1);
+        const int rtl = min(m0 + wm * 16 * MT + (i0 + ii) * 16, a.M - 1) >> 4;      // this wave's row tile (clamped like the rows)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const float* gi = d.gi + (long)row * d.ldgi + jj[u];
@@ -589,7 +590,7 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
 #if TEPOSE_G16_ABL & 256
             hp[ii][u] = *(const f32x4q*)(d.hprev + ((long)((blockIdx.x * 4 + wave) * MT + (i0 + ii)) * 2 + u) * 256 + lane * 4);
 #else
-            hp[ii][u] = *(const f32x4q*)hq;
+            hp[ii][u] = d.hp_blk ? *(const f32x4q*)(d.hprev_b + (long)rtl * d.hp_blk + ((jb + u * 16) >> 4) * 256 + lane * 4) : *(const f32x4q*)hq;
 #endif
           } else {
 #else
@@ -598,10 +599,10 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
             const int rt = min(m0 + wm * 16 * MT + (i0 + ii) * 16, a.M - 1) >> 4;
             const float* gq = d.gi + (long)rt * d.gi_blk + gi_blk_block(0, jb + u * 16) + lane * 4;
             gr[ii][u] = *(const f32x4q*)gq; gz[ii][u] = *(const f32x4q*)(gq + 256); gn[ii][u] = *(const f32x4q*)(gq + 512);
-            hp[ii][u] = *(const f32x4q*)hq;
+            hp[ii][u] = d.hp_blk ? *(const f32x4q*)(d.hprev_b + (long)rtl * d.hp_blk + ((jb + u * 16) >> 4) * 256 + lane * 4) : *(const f32x4q*)hq;
           } else if (vec) {
             gr[ii][u] = *(const f32x4q*)gi; gz[ii][u] = *(const f32x4q*)(gi + Hp); gn[ii][u] = *(const f32x4q*)(gi + 2 * Hp);
-            hp[ii][u] = *(const f32x4q*)hq;
+            hp[ii][u] = d.hp_blk ? *(const f32x4q*)(d.hprev_b + (long)rtl * d.hp_blk + ((jb + u * 16) >> 4) * 256 + lane * 4) : *(const f32x4q*)hq;
           } else {
 #endif
 #endif
@@ -611,7 +612,7 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
                 gr[ii][u][c] = d.gi[gi_blk_offset(row, 0, jj[u] + c, d.gi_blk)]; gz[ii][u][c] = d.gi[gi_blk_offset(row, 1, jj[u] + c, d.gi_blk)];
                 gn[ii][u][c] = d.gi[gi_blk_offset(row, 2, jj[u] + c, d.gi_blk)];
               } else { gr[ii][u][c] = gi[c]; gz[ii][u][c] = gi[Hp + c]; gn[ii][u][c] = gi[2 * Hp + c]; }
-              hp[ii][u][c] = hq[c];
+              hp[ii][u][c] = d.hp_blk ? d.hprev_b[st_blk_offset(row, jj[u] + c, d.hp_blk)] : hq[c];
             }
           }
         }
@@ -652,11 +653,15 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
 #if TEPOSE_G16_ABL & 512
             *(f32x4q*)(d.hout + ((long)((blockIdx.x * 4 + wave) * MT + i) * 2 + u) * 256 + lane * 4) = v;     // timing only: contiguous 1 KB per instruction
 #else
-            *(f32x4q*)ho = v;
+            if (d.ho_blk) *(f32x4q*)(d.hout_b + (long)(row >> 4) * d.ho_blk + ((jb + u * 16) >> 4) * 256 + lane * 4) = v;     // blocked state: one contiguous KB per instruction
+            else *(f32x4q*)ho = v;
 #endif
           } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ho[c] = v[c];
+            for (int c = 0; c < 4; ++c) {
+              if (d.ho_blk) d.hout_b[st_blk_offset(row, j + c, d.ho_blk)] = v[c];
+              else ho[c] = v[c];
+            }
           }
 #endif
 #if TEPOSE_G16_ABL & 8
