@@ -74,7 +74,7 @@ struct tepose_model {
   bool split = true;                            // batches of more than split_min_m() rows run their matmuls on the fp16x3 split kernels
   bool split_env = true;                        // what the environment asked for; `split` also needs every packed weight inside
   bool enc_range_ok = true, reg_range_ok = true, smpl_range_ok = true;   // the fp16 range (|w| < 2^15), checked at pack time
-  int s_min_b = 2048;                           // scaled-format recurrent path from this batch size
+  int s_min_b = 640;                            // scaled-format recurrent path from this batch size
   // fault channel of the persistent kernels (gru_seq.hip, reg_seq.hip): one word of pinned host memory that a kernel
   // whose bounded wait expired writes with system scope; sticky until tepose_status() reads it
   unsigned* fault = nullptr;
@@ -530,7 +530,8 @@ static void read_env_knobs(tepose_model* m) {
   e = getenv("TEPOSE_COLLAPSE_REGRESSOR");          // 0: the regressor's FC loop is always run as a loop
   m->collapse_env = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
-  m->s_min_b = e ? atoi(e) : 2048;                  // measured crossover against the two-accumulator recurrent path
+  m->s_min_b = e ? atoi(e) : 640;                   // measured crossover against the two-accumulator recurrent path (round 4, 16x16x32 step + blocked
+                                                    // operands: B = 512 2.38 vs 2.63 ms, 640 3.17 vs 2.94, 1024 4.29 vs 3.90, 1536 6.70 vs 5.91; it was 2048)
   e = getenv("TEPOSE_PERSISTENT");                  // 0: never launch the persistent small-batch kernels (the remedy for GPUs
   m->persist = !(e && atoi(e) == 0);                // that are shared or CU-masked: they need all their workgroups resident)
   e = getenv("TEPOSE_SEQ_SPIN_LIMIT");              // polls before a persistent kernel's wait gives up
