@@ -62,6 +62,8 @@ struct tepose_model {
   // regressor offsets
   size_t w1a = 0, b1 = 0, w1b = 0, w2 = 0, b2 = 0, wdec = 0, bdec = 0, init = 0;
   size_t w1a_p = 0, w1b_p = 0, w2_p = 0, wdec_p = 0, blendW_p = 0;   // blocked hi|lo planes (split path)
+  size_t blendW_s = 0, blend_scale = 0;         // the blend-shape matrix as scaled [K/16][R][16] planes (large batches: barrier-free persistent kernel) + its scale
+  float blend_sc = 1.f;                         // host copy of blob[blend_scale]
   // collapsed regressor: the eval-mode FC loop is affine in (feature, initial state), so with the model's own
   // initial state and n_iter = 3 the final state is  xs = feat Mf^T + k0  and, through the (affine) tail linears,
   // xs = [relu(h_fwd) | relu(y_rec0)] Mt^T + kt.  fp64 algebra at pack time; [256][K] fp32 + planes, bias rows of 160.
@@ -80,6 +82,7 @@ struct tepose_model {
   unsigned* fault = nullptr;
   bool persist = true;                          // false: step-per-launch kernels at every batch size (tepose_set_persistent)
   unsigned spin_limit = 1u << 21;               // polls (~1 us each) before a wait gives up
+  int blend16_min_n = 512;                      // TEPOSE_BLEND16_MIN_N: rows from which the blend-shape product runs on gemm_h3s_persist16c_kernel (0x7fffffff = never)
   int gi_blk = 1;                               // TEPOSE_GI_BLK: large batches keep the layer >= 1 gate pre-activations in the 16 x 16-blocked layout (common.h gi_blk_offset)
   unsigned test_fault = 0;                      // TEPOSE_TEST_FAULT: bit 0 recurrent kernel, bit 1 regressor kernel wait for arrivals that never come
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
@@ -206,6 +209,8 @@ void layout_tail(tepose_model* m, size_t cur) {   // regressor + SMPL sections, 
   m->w2_p = take(cur, 1024 * 1024);
   m->wdec_p = take(cur, 256 * 1024);
   m->blendW_p = take(cur, (size_t)kBlendN * kBlendK);
+  m->blendW_s = take(cur, (size_t)kBlendN * kBlendK);
+  m->blend_scale = take(cur, 16);
   m->mf = take(cur, 256 * (size_t)kFeat);
   m->mf_p = take(cur, 256 * (size_t)kFeat);
   m->k0 = take(cur, kState);
@@ -447,6 +452,8 @@ struct RegWs {
   float *base, *h1, *h2, *xs, *pf, *amat, *posed, *vposed;
   bool split, split_fc;            // split-mode handle with N > 4 rows: blend-shape GEMM / FC stack on the fp16x3 kernels
   Planes featP, xsP, h1P, h2P, pfP;
+  // large batches: the pose features again as scaled [K/16][N][16] planes + per-row scales, for the blend-shape product on the barrier-free kernel
+  bool blend16 = false; half_t *pf16h = nullptr, *pf16l = nullptr; float* pfrs = nullptr;
 };
 
 void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
@@ -466,6 +473,12 @@ void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
   w.amat = c.f((size_t)N * kNJ * 12);
   w.posed = c.f((size_t)N * kNJ * 3);
   w.vposed = c.f((size_t)N * kVertLd);
+  w.blend16 = w.split && N >= m->blend16_min_n && (m->mfma16 & 9) == 9 && gemm_h3s_blocked_ok();
+  if (w.blend16) {
+    w.pf16h = (half_t*)c.f((size_t)N * kBlendK / 2);
+    w.pf16l = (half_t*)c.f((size_t)N * kBlendK / 2);
+    w.pfrs = c.f((size_t)N);
+  }
 }
 
 hipError_t init_state(const float* init160, const float* pose, const float* shape, const float* cam, float* xs, int N,
@@ -506,6 +519,18 @@ int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long
 // v_posed = v_template + shapedirs beta + posedirs^T pose_feature as one GEMM, K = 224
 int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
   const float* Bl = m->blob;
+  if (w.blend16) {
+    // large batches: K = 224 is 7 pairs of K-tiles -- on the one-workgroup-per-tile kernel every tile pays pipeline fill, drain and a 128 KB store burst
+    // (0.40 ms for 677 MB of output); the persistent barrier-free kernel streams the next tile's stages under the finished tile's stores
+    CK(launch_split_rows(w.pf, kBlendK, N, kBlendK, kBlendK, N, 1, w.pf16h, w.pf16l, w.pfrs, s));
+    const half_t* sh = (const half_t*)(Bl + m->blendW_s);
+    H3SArgs a{w.pf16h, w.pf16l, (long)N * 16, sh, sh + (size_t)kBlendN * kBlendK, (long)kBlendN * 16, kBlendK, w.vposed, (long)kVertLd,
+              nullptr, 1.f / m->blend_sc, N, 3 * kNV, w.pfrs};
+    a.shape16 = 3;
+    if (w.sync) a.status = sync_reg_status(m, w.sync);
+    a.fault = m->fault;
+    return (int)launch_gemm_h3s(a, s, 1);
+  }
   if (w.split) {      // the prep kernel wrote the pose-feature planes next to the fp32 rows
     return h3_mm(w.pfP, Bl + m->blendW_p, kBlendN, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV, nullptr, 0, 0.f,
                  nullptr, s);
@@ -538,6 +563,8 @@ static void read_env_knobs(tepose_model* m) {
   if (e && atol(e) > 0) m->spin_limit = (unsigned)atol(e);
   e = getenv("TEPOSE_TEST_FAULT");                  // tests only: make the persistent kernels' waits unmeetable
   m->test_fault = e ? (unsigned)atoi(e) : 0u;
+  e = getenv("TEPOSE_BLEND16_MIN_N");
+  m->blend16_min_n = e ? atoi(e) : 512;
   e = getenv("TEPOSE_GI_BLK");
   m->gi_blk = e ? atoi(e) : 1;
   // the symbols a rocprofv3 kernel trace of a large-batch forward (B >= s_min_b, B * T >= 8192) lists for the two dominant
@@ -799,6 +826,8 @@ int tepose_adopt_blob(tepose_model* m) {
   int max_nnz = kNJ;
   CK(hipMemcpy(&max_nnz, m->blob + m->smpl.lbs_nnz, sizeof(int), hipMemcpyDeviceToHost));   // set-up time only
   m->lbs_sparse = max_nnz <= 4 ? 1 : 0;
+  CK(hipMemcpy(&m->blend_sc, m->blob + m->blend_scale, sizeof(float), hipMemcpyDeviceToHost));
+  if (!(m->blend_sc > 0.f)) m->blend_sc = 1.f;
   if (m->kind == 0 && m->enc_packed) {
     CK(hipMemcpy(&m->w0_scale, m->blob + m->wih0_scale, sizeof(float), hipMemcpyDeviceToHost));
     if (!(m->w0_scale > 0.f)) m->w0_scale = 1.f;
@@ -892,6 +921,7 @@ int tepose_derive_planes(tepose_model* m, void* stream) {
     if (m->reg_collapsed) CK((hipError_t)planes_of(B + m->mf, 256, kFeat, B + m->mf_p, s));
   }
   if (m->smpl_packed) CK((hipError_t)planes_of(B + m->smpl.blendW, kBlendN, kBlendK, B + m->blendW_p, s));
+  if (m->smpl_packed) CK((hipError_t)scaled_planes_of(B + m->smpl.blendW, kBlendN, kBlendK, B + m->blendW_s, kBlendN, B + m->blend_scale, &m->blend_sc, s));
   CK(hipStreamSynchronize(s));
   return 0;
 }
@@ -1126,6 +1156,7 @@ int tepose_pack_smpl(tepose_model* m, const float* v_template, const float* shap
   CK(launch_smpl_consts(v_template, shapedirs, posedirs, J_regressor, B + m->smpl.J0, B + m->smpl.JS,
                         B + m->smpl.blendW, s));
   CK((hipError_t)planes_of(B + m->smpl.blendW, kBlendN, kBlendK, B + m->blendW_p, s));
+  CK((hipError_t)scaled_planes_of(B + m->smpl.blendW, kBlendN, kBlendK, B + m->blendW_s, kBlendN, B + m->blend_scale, &m->blend_sc, s));
   CK((hipError_t)pack(lbs_weights, kNJ, kNV, kNJ, B + m->smpl.lbsW, kNV, kNJ, 0, 0, 0, 1, s));
   CK(launch_lbs_compact(lbs_weights, (int*)(B + m->smpl.lbs_cidx), B + m->smpl.lbs_cval, (int*)(B + m->smpl.lbs_nnz), s));
   int max_nnz = 0;
