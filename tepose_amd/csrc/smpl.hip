@@ -399,10 +399,26 @@ __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__
   for (int k = 0; k < 4; ++k) { jx[k] = ok ? cidx[v * 4 + k] * 12 : 0; wv[k] = ok ? cval[v * 4 + k] : 0.f; }
   const int p0 = blockIdx.y * pg;
   const int p1 = min(p0 + pg, N);
+  // one person ahead: the next person's transforms and posed-vertex coordinates are requested before this person's blend (round 4: a person
+  // used to cost two dependent global round trips -- transforms -> LDS, then the vertex -- with 32 persons per workgroup in sequence)
+  static_assert(kNJ * 12 <= 512, "two loads per thread cover the transforms");
+  float a0 = 0.f, a1 = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+  if (p0 < p1) {
+    a0 = Amat[(long)p0 * kNJ * 12 + threadIdx.x];
+    if (threadIdx.x + 256 < kNJ * 12) a1 = Amat[(long)p0 * kNJ * 12 + 256 + threadIdx.x];
+    if (ok) { const float* vp = vposed + (long)p0 * kVertLd + 3 * v; nx = vp[0]; ny = vp[1]; nz = vp[2]; }
+  }
   for (int p = p0; p < p1; ++p) {
     __syncthreads();
-    for (int i = threadIdx.x; i < kNJ * 12; i += 256) As[i] = Amat[(long)p * kNJ * 12 + i];
+    As[threadIdx.x] = a0;
+    if (threadIdx.x + 256 < kNJ * 12) As[256 + threadIdx.x] = a1;
     __syncthreads();
+    const float x = nx, y = ny, z = nz;
+    if (p + 1 < p1) {
+      a0 = Amat[(long)(p + 1) * kNJ * 12 + threadIdx.x];
+      if (threadIdx.x + 256 < kNJ * 12) a1 = Amat[(long)(p + 1) * kNJ * 12 + 256 + threadIdx.x];
+      if (ok) { const float* vp = vposed + (long)(p + 1) * kVertLd + 3 * v; nx = vp[0]; ny = vp[1]; nz = vp[2]; }
+    }
     float t[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) t[e] = 0.f;
@@ -413,8 +429,6 @@ __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__
       for (int e = 0; e < 4; ++e) { t[e] += wv[k] * r0[e]; t[4 + e] += wv[k] * r1[e]; t[8 + e] += wv[k] * r2[e]; }
     }
     if (ok) {
-      const float* vp = vposed + (long)p * kVertLd + 3 * v;
-      const float x = vp[0], y = vp[1], z = vp[2];
       float* o = verts + ((long)p * kNV + v) * 3;
       o[0] = t[0] * x + t[1] * y + t[2] * z + t[3];
       o[1] = t[4] * x + t[5] * y + t[6] * z + t[7];
