@@ -365,9 +365,6 @@ hipError_t launch_lbs_compact(const float* lbsW, int* cidx, float* cval, int* ma
 // thread = vertex with its <= 4 (joint, weight) pairs in registers; persons looped; the 4 joint
 // transforms are gathered from the LDS copy of A (3 x 16-byte reads per joint).  HBM-bound:
 // 12 B in + 12 B out per (person, vertex).
-#ifndef TEPOSE_SKIN_COAL
-#define TEPOSE_SKIN_COAL 1   // skinning kernel: posed vertices in / vertices out through LDS, fully coalesced (A/B builds: 0 = a thread moves its own vertex)
-#endif
 #ifndef TEPOSE_SKIN_DIAG
 #define TEPOSE_SKIN_DIAG 0   // diagnostic builds only (tools/race_probe_smpl_diag.py): every wave of the skinning
 #endif                       // kernel records when it ran and where (s_memrealtime at entry / exit, HW_ID at entry / exit)
@@ -405,30 +402,6 @@ __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__
   // one person ahead: the next person's transforms and posed-vertex coordinates are requested before this person's blend (round 4: a person
   // used to cost two dependent global round trips -- transforms -> LDS, then the vertex -- with 32 persons per workgroup in sequence)
   static_assert(kNJ * 12 <= 512, "two loads per thread cover the transforms");
-#if TEPOSE_SKIN_COAL && !TEPOSE_SKIN_DIAG
-  // coalesced I/O: a workgroup's 256 vertices are 768 consecutive floats of the person's row, in and out; thread i moves floats i, i + 256, i + 512
-  // (4-byte accesses, 256 contiguous bytes per wave instruction) through LDS instead of its own vertex's 3 floats at a 12-byte stride
-  __shared__ float Vin[768], Vout[768];
-  const int vb3 = blockIdx.x * 768, nval = min(768, 3 * kNV - vb3);
-  float a0 = 0.f, a1 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-  auto fetch = [&](int p) __attribute__((always_inline)) {
-    a0 = Amat[(long)p * kNJ * 12 + threadIdx.x];
-    if (threadIdx.x + 256 < kNJ * 12) a1 = Amat[(long)p * kNJ * 12 + 256 + threadIdx.x];
-    const float* vp = vposed + (long)p * kVertLd + vb3 + threadIdx.x;
-    if ((int)threadIdx.x < nval) n0 = vp[0];
-    if ((int)threadIdx.x + 256 < nval) n1 = vp[256];
-    if ((int)threadIdx.x + 512 < nval) n2 = vp[512];
-  };
-  if (p0 < p1) fetch(p0);
-  for (int p = p0; p < p1; ++p) {
-    __syncthreads();
-    As[threadIdx.x] = a0;
-    if (threadIdx.x + 256 < kNJ * 12) As[256 + threadIdx.x] = a1;
-    Vin[threadIdx.x] = n0; Vin[threadIdx.x + 256] = n1; Vin[threadIdx.x + 512] = n2;
-    __syncthreads();
-    const float x = Vin[3 * threadIdx.x], y = Vin[3 * threadIdx.x + 1], z = Vin[3 * threadIdx.x + 2];
-    if (p + 1 < p1) fetch(p + 1);
-#else
   float a0 = 0.f, a1 = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
   if (p0 < p1) {
     a0 = Amat[(long)p0 * kNJ * 12 + threadIdx.x];
@@ -446,7 +419,6 @@ __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__
       if (threadIdx.x + 256 < kNJ * 12) a1 = Amat[(long)(p + 1) * kNJ * 12 + 256 + threadIdx.x];
       if (ok) { const float* vp = vposed + (long)(p + 1) * kVertLd + 3 * v; nx = vp[0]; ny = vp[1]; nz = vp[2]; }
     }
-#endif
     float t[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) t[e] = 0.f;
@@ -456,26 +428,11 @@ __global__ void __launch_bounds__(256) smpl_skin4_kernel(const int* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) { t[e] += wv[k] * r0[e]; t[4 + e] += wv[k] * r1[e]; t[8 + e] += wv[k] * r2[e]; }
     }
-#if TEPOSE_SKIN_COAL && !TEPOSE_SKIN_DIAG
-    Vout[3 * threadIdx.x] = t[0] * x + t[1] * y + t[2] * z + t[3];
-    Vout[3 * threadIdx.x + 1] = t[4] * x + t[5] * y + t[6] * z + t[7];
-    Vout[3 * threadIdx.x + 2] = t[8] * x + t[9] * y + t[10] * z + t[11];
-    __syncthreads();
-    {
-      float* o = verts + (long)p * kNV * 3 + vb3 + threadIdx.x;
-      if ((int)threadIdx.x < nval) o[0] = Vout[threadIdx.x];
-      if ((int)threadIdx.x + 256 < nval) o[256] = Vout[threadIdx.x + 256];
-      if ((int)threadIdx.x + 512 < nval) o[512] = Vout[threadIdx.x + 512];
-    }
-    if (false) {
-      float* o = nullptr;
-#else
     if (ok) {
       float* o = verts + ((long)p * kNV + v) * 3;
       o[0] = t[0] * x + t[1] * y + t[2] * z + t[3];
       o[1] = t[4] * x + t[5] * y + t[6] * z + t[7];
       o[2] = t[8] * x + t[9] * y + t[10] * z + t[11];
-#endif
 #if TEPOSE_SKIN_DIAG >= 2
       // self-check: the first row of the blended transform again, from a SECOND read of the LDS copy and with scalar FMAs the
       // compiler cannot pack (asm); a lane whose packed accumulators differ records what it saw
