@@ -30,7 +30,7 @@ while time.time() < t_end:
     xd = torch.from_numpy(x).cuda()
     with torch.no_grad():
         f = model.encoder(xd); ft = model.encoder(xd, is_train=True)
-        out = model(xd, J_regressor=J)[0] if B <= 300 else None
+        out = model(xd, J_regressor=J)[0] if (B <= 300 or (H <= 256 and B <= 1300)) else None      # B >= 512: the blend-shape product on the persistent kernel
     enc, _ = O.split_state_dict(state, torch.float64)
     with torch.no_grad():
         rf = O.encoder_fwd(enc, torch.from_numpy(x).double(), L)
@@ -38,8 +38,9 @@ while time.time() < t_end:
     e1 = (f.cpu().double() - rf).abs().max().item(); e2 = (ft.cpu().double() - rft).abs().max().item()
     e3 = 0.0
     if out is not None:
-        ref = O.tepose_fwd(state, smpl_np, x, L, J_regressor=smpl_np['J_regressor_h36m'], dtype=torch.float64)
-        e3 = max((out[k].cpu().double() - ref[k]).abs().max().item() for k in ('verts', 'kp_3d', 'rotmat', 'kp_2d'))
+        sel = np.arange(B) if B <= 300 else np.sort(rng.choice(B, 96, replace=False))       # windows are independent: a random subset of a big batch
+        ref = O.tepose_fwd(state, smpl_np, x[sel], L, J_regressor=smpl_np['J_regressor_h36m'], dtype=torch.float64)
+        e3 = max((out[k][torch.from_numpy(sel).cuda()].cpu().double() - ref[k]).abs().max().item() for k in ('verts', 'kp_3d', 'rotmat', 'kp_2d'))
     worst = max(worst, e1, e2, e3); n += 1
     flag = '' if max(e1, e2) < 2e-5 and e3 < 1e-4 else '   <<<<<< FAIL'
     print('L=%d H=%3d B=%4d T=%d  enc %.1e / %.1e  full %.1e%s' % (L, H, B, T, e1, e2, e3, flag), flush=True)
