@@ -1,5 +1,7 @@
+"""A/B of the blend-shape product of a large batch: gemm_h3_kernel (two-accumulator planes) vs gemm_h3s_persist16c_kernel (scaled planes), whole forwards:
+    python tools/blend_ab.py"""
 import os, sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synthetic_windows_device
 from tepose_amd import synth
 from tepose_amd.testing import build_model
