@@ -19,7 +19,10 @@
 // of it back), layer-0 projection 10.91 ms against 11.65 (same box, two rounds); where the landing is confirmed matters: after Q1
 // 10.91, after Q2 11.18, after Q3 11.56 (drift tolerance beats request lead time); requests in one burst at the top: 11.08.
 // No wave waits for anything but its own workgroup's waves, which are resident by construction, so the polls cannot hang; they are
-// bounded all the same (a wave that gives up writes NaN to C[0] and raises a counter that tepose_debug_kernel_errors() reads).
+// bounded all the same (a wave that gives up writes NaN to C[0], raises a counter that tepose_debug_kernel_errors() reads, and sets the
+// forward's status word / the handle's fault word: H3SArgs::status, ::fault -- the library's failure channel, include/tepose_amd.h).
+// Gate pre-activation outputs (H3SArgs::c_blk_hp) are written in the 16 x 16-blocked layout of common.h gi_blk_offset: the lane order
+// of this kernel's C fragment IS that layout's block order, so every tile store is one contiguous KB.
 #include "common.h"
 
 #ifndef TEPOSE_C_VAR
