@@ -14,6 +14,42 @@ from . import metrics as M
 from .driver import run_clips
 
 
+def mpii3d_valid_map(valid_i, n_pred):
+    """evaluate.py:397-405: indices of the frames whose `valid_i` flag is set, without those past the predictions
+    (the reference trims them from the tail one at a time; the map is ascending, so that is a `< n_pred` filter).
+    Host-side numpy / torch-CPU in, LongTensor out; empty = the clip is skipped ("No valid frames")."""
+    vm = torch.as_tensor(valid_i).reshape(len(valid_i), -1)[:, 0].nonzero()[:, 0]
+    return vm[vm < int(n_pred)]
+
+
+@torch.no_grad()
+def clip_metric_record(model, clip_id, clip, pred_j3d, pred_verts, dataset='3dpw'):
+    """The per-clip metric block of evaluate.py:394-457 on device tensors: joint conversion (`convert_kps` spin ->
+    mpii3d_test / common as index tables), the MPI-INF-3DHP `valid_i` frame filter, pelvis (joint -3 for mpii3d, mean of
+    joints 2, 3 otherwise), MPJPE / PA-MPJPE / acceleration error per frame, MPVPE against SMPL(target theta) for 3DPW.
+    pred_j3d [N, 49 | 14, 3], pred_verts [N, 6890, 3] = bootstrap frames + window predictions of ONE clip.
+    Returns the clip's [8] record (metrics.clip_record) or None when the reference skips the clip."""
+    dev = pred_j3d.device
+    target = torch.as_tensor(clip['joints3D'], dtype=torch.float32, device=dev)[:pred_j3d.shape[0]]   # evaluate.py:302
+    valid_map = None
+    if dataset == 'mpii3d':
+        idx = torch.tensor(M.SPIN_TO_MPII3D_TEST, device=dev)
+        target, pred_j3d = target[:, idx], pred_j3d[:, idx]
+        valid_map = mpii3d_valid_map(clip['valid_i'], pred_j3d.shape[0]).to(dev)
+        if valid_map.numel() == 0:
+            return None
+    elif target.shape[1] == 49:
+        target = target[:, torch.tensor(M.SPIN_TO_COMMON, device=dev)]
+    m = M.joint_metrics(pred_j3d, target, 'mpii3d' if dataset == 'mpii3d' else 'lsp')
+    mpvpe = None
+    if dataset == '3dpw':                                                   # evaluate.py:454-455
+        n = pred_verts.shape[0]
+        tt = torch.cat([torch.zeros(n, 3), torch.as_tensor(clip['pose'], dtype=torch.float32)[:n],
+                        torch.as_tensor(clip['shape'], dtype=torch.float32)[:n]], dim=1).to(dev)
+        mpvpe = M.vertex_metric(pred_verts, M.gt_vertices(model, tt))
+    return M.clip_record(clip_id, m, mpvpe=mpvpe, valid_map=valid_map)
+
+
 @torch.no_grad()
 def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='3dpw', rank=0, world=1):
     """clips: OrderedDict name -> dict(features[N,2048], joints3D[N,J,3], theta_pseu[N,85], pose, shape).
@@ -33,27 +69,11 @@ def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='
     seq = run_clips(model, feats, inits, T, J_regressor=J_regressor, keep=('kp_3d', 'verts'))
     recs = []
     for s, i in enumerate(mine):
-        c = clips[names[i]]
         pred_j3d = torch.cat([boot['kp_3d'][s, :T - 1], seq[s]['kp_3d']], dim=0)
         pred_verts = torch.cat([boot['verts'][s, :T - 1], seq[s]['verts']], dim=0)
-        target = torch.as_tensor(c['joints3D'], dtype=torch.float32, device=dev)
-        valid_map = None
-        if dataset == 'mpii3d':
-            idx = torch.tensor(M.SPIN_TO_MPII3D_TEST, device=dev)
-            target, pred_j3d = target[:, idx], pred_j3d[:, idx]
-            vm = torch.as_tensor(c['valid_i'][:, 0]).nonzero()[:, 0]
-            valid_map = vm[vm < pred_j3d.shape[0]].to(dev)
-            if valid_map.numel() == 0:
-                continue
-        elif target.shape[1] == 49:
-            target = target[:, torch.tensor(M.SPIN_TO_COMMON, device=dev)]
-        m = M.joint_metrics(pred_j3d, target, 'mpii3d' if dataset == 'mpii3d' else 'lsp')
-        mpvpe = None
-        if dataset == '3dpw':
-            tt = torch.cat([torch.zeros(len(c['pose']), 3), torch.as_tensor(c['pose'], dtype=torch.float32),
-                            torch.as_tensor(c['shape'], dtype=torch.float32)], dim=1).to(dev)
-            mpvpe = M.vertex_metric(pred_verts, M.gt_vertices(model, tt))
-        recs.append(M.clip_record(i, m, mpvpe=mpvpe, valid_map=valid_map))
+        rec = clip_metric_record(model, i, clips[names[i]], pred_j3d, pred_verts, dataset)
+        if rec is not None:
+            recs.append(rec)
     out = torch.stack(recs) if recs else torch.zeros(0, 8, dtype=torch.float64, device=dev)
     return out, mine
 

@@ -49,8 +49,11 @@ class _StubSMPL(nn.Module):
         self.t = O.smpl_tensors(SMPL_NP)
 
     def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=False, **kw):
-        assert pose2rot is False
-        R = torch.cat([global_orient, body_pose], dim=1)
+        if pose2rot:      # compute_error_verts (lib/utils/eval_utils.py:155-169): axis-angle in, [N,3] + [N,69]
+            R = O.batch_rodrigues(torch.cat([global_orient, body_pose], dim=1).reshape(-1, 3)).view(-1, 24, 3, 3)
+            global_orient, body_pose = R[:, :1], R[:, 1:]
+        else:
+            R = torch.cat([global_orient, body_pose], dim=1)
         dt = R.dtype
         t = {k: (v.to(dt) if torch.is_tensor(v) else v) for k, v in self.t.items()}
         verts, posed = O.lbs(t, betas, R)
@@ -344,6 +347,181 @@ def metrics_case():
     print('wrote metrics', out['spin_to_common'], out['spin_to_mpii3d_test'])
 
 
+def eval_valid_i(name, lens):
+    """Deterministic `valid_i` columns for a synthetic MPI-INF-3DHP database ([n, 1] per clip, as
+    dataset_data['valid_i'][indexes][valids] in evaluate.py:199): leading, trailing and interior holes, one clip
+    with no valid frame at all (evaluate.py:399-401 skips it) and one with a single valid frame (no accel entry,
+    evaluate.py:441)."""
+    out = []
+    for c, n in enumerate(lens):
+        v = (synth.uniform01('%s/valid_i%d' % (name, c), n) > 0.3).astype(np.float64)
+        if c % 5 == 0:
+            v[:2] = 0; v[-3:] = 0; v[n // 2] = 0         # holes at both ends and inside
+        elif c % 5 == 1:
+            v[0] = 1; v[-1] = 1                          # first and last frame valid: both dropped from accel
+        elif c % 5 == 2:
+            v[:] = 0                                     # no valid frame
+        elif c % 5 == 3:
+            v[:] = 0; v[n // 3] = 1                      # exactly one
+        out.append(v.reshape(n, 1))
+    return out
+
+
+def eval_case(T_mod, name, dataset, L, H, T, lens, seed_w, seed_db, joints=49, invalid_frames=()):
+    """The reference's evaluation flow end to end on a synthetic `*_db.pt` (evaluate.py:169-206 keyed clips, :214-269
+    VIBE bootstrap + autoregressive windows, :394-457 joint conversion / valid_i filter / pelvis / MPJPE / PA-MPJPE /
+    accel / MPVPE, :461 frame-weighted means), written out as the script has it with the reference's own TePose and VIBE
+    classes, convert_kps, batch_compute_similarity_transform_torch, compute_error_accel_eval and compute_error_verts.
+    `dataset` plays the role of the data path's name ('mpii3d' in data_path, target_dataset == '3dpw')."""
+    import lib.models.vibe as V_mod
+    from lib.data_utils._kp_utils import convert_kps
+    from lib.utils.eval_utils import (batch_compute_similarity_transform_torch, compute_error_accel_eval,
+                                      compute_error_verts)
+    from tepose_amd.data import synthetic_eval_db
+    model = T_mod.TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='').eval()
+    sd_np = synth.synthetic_state_dict(L, H, seed_w)
+    sd = model.state_dict()
+    for k in sd:
+        if k in sd_np:
+            sd[k] = torch.from_numpy(sd_np[k])
+    model.load_state_dict(sd, strict=True)
+    model_vibe = V_mod.VIBE(seqlen=T, n_layers=L, hidden_size=H, add_linear=True, bidirectional=False,
+                            use_residual=True, pretrained='').eval()
+    vsd_np = synth.synthetic_vibe_state_dict(L, H, seed_w + 1)
+    vsd = model_vibe.state_dict()
+    for k in vsd_np:
+        vsd[k] = torch.from_numpy(vsd_np[k])
+    model_vibe.load_state_dict(vsd, strict=True)
+    dataset_data, psetheta = synthetic_eval_db(list(lens), seed=seed_db, joints=joints)
+    for f in invalid_frames:                                                 # the db's own `valid` column
+        dataset_data['valid'][f] = 0
+    if dataset == 'mpii3d':
+        dataset_data['valid_i'] = np.concatenate(eval_valid_i(name, lens), axis=0)
+    J_regressor = torch.from_numpy(SMPL_NP['J_regressor_h36m']).float()
+    seqlen = T
+    full_res = {}
+    vid_name_list = dataset_data['vid_name']
+    unique_names = np.unique(vid_name_list)
+    data_keyed = {}
+    psetheta = np.array(psetheta, copy=True)
+    for idx in range(psetheta.shape[0]):
+        psetheta[idx, :] = np.concatenate((np.array([1., 0., 0.]), psetheta[idx, 3:].copy()), axis=0)
+    for u_n in unique_names:
+        indexes = vid_name_list == u_n
+        valids = dataset_data['valid'][indexes].astype(bool)
+        data_keyed[u_n] = {'features': dataset_data['features'][indexes][valids],
+                           'joints3D': dataset_data['joints3D'][indexes][valids],
+                           'vid_name': dataset_data['vid_name'][indexes][valids],
+                           'theta_pseu': psetheta[indexes][valids]}
+        if dataset == 'mpii3d':
+            data_keyed[u_n]['pose'] = np.zeros((len(valids), 72))
+            data_keyed[u_n]['shape'] = np.zeros((len(valids), 10))
+            data_keyed[u_n]['valid_i'] = dataset_data['valid_i'][indexes][valids]
+            J_regressor = None
+        else:
+            data_keyed[u_n]['pose'] = dataset_data['pose'][indexes][valids]
+            data_keyed[u_n]['shape'] = dataset_data['shape'][indexes][valids]
+    per_clip = {}
+    tot_num_pose = 0
+    with torch.no_grad():
+        for ci, seq_name in enumerate(data_keyed.keys()):
+            curr_feat = torch.tensor(data_keyed[seq_name]['features'])
+            theta_input = torch.from_numpy(data_keyed[seq_name]['theta_pseu'][:seqlen - 1, :]).float()
+            vid_names = data_keyed[seq_name]['vid_name']
+            if len(vid_names) < seqlen:
+                continue
+            pred_j3ds, pred_verts = [], []
+            batch = curr_feat[:seqlen].clone().unsqueeze(0)
+            output = model_vibe(batch, J_regressor=J_regressor)[-1]
+            n_kp = output['kp_3d'].shape[-2]
+            pred_j3ds.append(output['kp_3d'][0, :seqlen - 1].view(-1, n_kp, 3).numpy())
+            pred_verts.append(output['verts'][0, :seqlen - 1].view(-1, 6890, 3).numpy())
+            for curr_idx in range(len(vid_names) - seqlen + 1):
+                input_feat = torch.zeros((1, seqlen, 2048 + 85)).float()
+                input_feat[0, :, :2048] = curr_feat[None, curr_idx:curr_idx + seqlen, :].clone()
+                input_feat[0, :seqlen - 1, 2048:] = theta_input.clone()
+                preds = model(input_feat, J_regressor=J_regressor, is_train=False)
+                n_kp = preds[-1]['kp_3d'].shape[-2]
+                pred_j3ds.append(preds[-1]['kp_3d'].view(-1, n_kp, 3).numpy())
+                pred_verts.append(preds[-1]['verts'].view(-1, 6890, 3).numpy())
+                theta_input[:seqlen - 2, :] = theta_input[1:seqlen - 1, :].clone()
+                theta_input[seqlen - 2, :] = preds[-1]['theta'].clone().detach()
+            pred_j3ds = np.vstack(pred_j3ds)
+            raw_pred = pred_j3ds.copy()
+            target_j3ds = data_keyed[seq_name]['joints3D']
+            pred_verts = torch.from_numpy(np.vstack(pred_verts))
+            dummy_cam = np.repeat(np.array([[1., 0., 0.]]), len(target_j3ds), axis=0)
+            target_theta = np.concatenate([dummy_cam, data_keyed[seq_name]['pose'], data_keyed[seq_name]['shape']],
+                                          axis=1).astype(np.float32)
+            target_j3ds, target_theta = target_j3ds[:len(pred_j3ds)], target_theta[:len(pred_j3ds)]
+            if dataset == 'mpii3d':
+                target_j3ds = convert_kps(target_j3ds, src='spin', dst='mpii3d_test')
+                pred_j3ds = convert_kps(pred_j3ds, src='spin', dst='mpii3d_test')
+                valid_map = data_keyed[seq_name]['valid_i'][:, 0].nonzero()[0]
+                if valid_map.size == 0:
+                    continue
+                while True:
+                    if valid_map[-1] >= len(pred_j3ds):
+                        valid_map = valid_map[:-1]
+                    else:
+                        break
+            elif target_j3ds.shape[1] == 49:
+                target_j3ds = convert_kps(target_j3ds, src='spin', dst='common')
+                valid_map = np.arange(len(target_j3ds))
+            else:
+                valid_map = np.arange(len(target_j3ds))
+            pred_j3ds = torch.from_numpy(pred_j3ds).float()
+            target_j3ds = torch.from_numpy(target_j3ds).float()
+            tot_num_pose += len(valid_map)
+            if dataset == 'mpii3d':
+                pred_pelvis = pred_j3ds[:, [-3], :]
+                target_pelvis = target_j3ds[:, [-3], :]
+            else:
+                pred_pelvis = (pred_j3ds[:, [2], :] + pred_j3ds[:, [3], :]) / 2.0
+                target_pelvis = (target_j3ds[:, [2], :] + target_j3ds[:, [3], :]) / 2.0
+            pred_j3ds -= pred_pelvis
+            target_j3ds -= target_pelvis
+            m2mm = 1000
+            mpvpe = compute_error_verts(target_theta=torch.from_numpy(target_theta), pred_verts=pred_verts) * m2mm
+            mpjpe_all = torch.sqrt(((pred_j3ds - target_j3ds) ** 2).sum(dim=-1)).cpu().numpy().mean(axis=-1) * m2mm
+            mpjpe = mpjpe_all[valid_map]
+            S1_hat = batch_compute_similarity_transform_torch(pred_j3ds, target_j3ds)
+            pa_all = torch.sqrt(((S1_hat - target_j3ds) ** 2).sum(dim=-1)).cpu().numpy().mean(axis=-1) * m2mm
+            mpjpe_pa = pa_all[valid_map]
+            accel_all = np.zeros((len(pred_j3ds,)))
+            accel_all[1:-1] = compute_error_accel_eval(joints_pred=pred_j3ds, joints_gt=target_j3ds) * m2mm
+            pose_map = valid_map.copy()
+            accel_map = np.zeros(0, dtype=np.int64)
+            has_accel = 0
+            if len(valid_map) > 1:
+                if valid_map[0] == 0:
+                    valid_map = valid_map[1:]
+                if valid_map[-1] == len(accel_all) - 1:
+                    valid_map = valid_map[:-1]
+                accel_map = valid_map.copy()
+                has_accel = 1
+                full_res.setdefault('accel_err', []).append(accel_all[valid_map])
+            full_res.setdefault('mpjpe', []).append(mpjpe)
+            full_res.setdefault('mpjpe_pa', []).append(mpjpe_pa)
+            if dataset == '3dpw':
+                full_res.setdefault('mpvpe', []).append(mpvpe)
+            per_clip[ci] = {'raw_pred': raw_pred.astype(np.float32), 'mpjpe_all': mpjpe_all, 'pa_all': pa_all,
+                            'accel_all': accel_all, 'pose_map': pose_map.astype(np.int64),
+                            'accel_map': accel_map.astype(np.int64), 'has_accel': has_accel, 'mpvpe': mpvpe}
+    final = {k: float(np.mean(np.concatenate(v))) for k, v in full_res.items()}
+    d = {'meta': np.array([L, H, T, seed_w, seed_db, joints] + list(lens), dtype=np.int64),
+         'invalid_frames': np.array(list(invalid_frames), dtype=np.int64),
+         'tot_num_pose': np.array(tot_num_pose), 'evaluated_clips': np.array(sorted(per_clip), dtype=np.int64),
+         'final_keys': np.array(sorted(final)), 'final_values': np.array([final[k] for k in sorted(final)])}
+    if dataset == 'mpii3d':
+        d['valid_i'] = dataset_data['valid_i']
+    for ci, r in per_clip.items():
+        for k, v in r.items():
+            d['clip%d_%s' % (ci, k)] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **d)
+    print('wrote', name, final, 'poses', tot_num_pose, 'clips', sorted(per_clip))
+
+
 def filter_cases():
     """Reference OneEuroFilter driven as lib/utils/smooth_pose.py:28-58 drives it, and the reference's
     quaternion utilities strung together as evaluate.py:32-59 (smooth_pose_mat) does."""
@@ -432,6 +610,14 @@ def main():
     assert S_mod.H36M_TO_J14 == O.H36M_TO_J14
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if 'eval' in sys.argv[1:] or len(sys.argv) == 1:
+        # BASELINE config 4's three evaluation sets (evaluate.py:394-457 branches)
+        eval_case(T_mod, 'eval_mpii3d_L1H64_T5', 'mpii3d', 1, 64, 5, [13, 9, 8, 11, 12, 4, 10], 21, 31)
+        eval_case(T_mod, 'eval_h36m_L1H64_T5', 'h36m', 1, 64, 5, [9, 3, 12], 22, 32, invalid_frames=(2, 15, 23))
+        eval_case(T_mod, 'eval_h36m14_L1H64_T4', 'h36m', 1, 64, 4, [7, 10], 23, 33, joints=14)
+        eval_case(T_mod, 'eval_3dpw_L2H64_T6', '3dpw', 2, 64, 6, [10, 14, 6], 24, 34, invalid_frames=(0, 11))
+    if len(sys.argv) > 1:
+        return
     run_case(T_mod, 'tepose_L2H1024_B2T6_j14', 2, 1024, 2, 6, True)
     run_case(T_mod, 'tepose_L2H1024_B2T6_j49', 2, 1024, 2, 6, False)
     run_case(T_mod, 'tepose_L2H1024_B2T16_j14', 2, 1024, 2, 16, True)

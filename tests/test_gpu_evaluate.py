@@ -65,3 +65,62 @@ def test_eval_pipeline_matches_oracle_pipeline(tmp_path):
             'accel_err': torch.cat(ac).mean().item(), 'mpvpe': torch.cat(mv).mean().item()}
     for k in want:
         assert abs(got[k] - want[k]) < 0.02, (k, got[k], want[k])         # mm
+
+
+def _fixture_models(fx):
+    from _eval_fixture import vibe_state
+    from tepose_amd.smpl import SMPL
+    from tepose_amd.testing import build_model
+    from tepose_amd.vibe import VIBE
+    smpl_np = synth.synthetic_smpl(0)
+    model, _, _ = build_model(fx['L'], fx['H'], seed=fx['seed_w'], device='cuda', smpl_np=smpl_np, seqlen=fx['T'])
+    vstate, mean = vibe_state(fx['L'], fx['H'], fx['seed_w'] + 1)
+    vibe = VIBE(seqlen=fx['T'], n_layers=fx['L'], hidden_size=fx['H'], add_linear=True, use_residual=True, pretrained='',
+                smpl=SMPL.from_tables(smpl_np), smpl_mean_params=mean)
+    sd = vibe.state_dict()
+    for k, v in vstate.items():
+        sd[k] = torch.from_numpy(v)
+    vibe.load_state_dict(sd)
+    return model, vibe.cuda().eval(), smpl_np
+
+
+@pytest.mark.parametrize('case', ['eval_mpii3d_L1H64_T5', 'eval_h36m_L1H64_T5', 'eval_h36m14_L1H64_T4', 'eval_3dpw_L2H64_T6'])
+def test_dataset_branches_match_the_reference_flow(case):
+    """BASELINE config 4's three evaluation sets end to end (VIBE bootstrap -> windows -> joint conversion -> valid_i filter
+    -> pelvis -> metrics -> records -> frame-weighted means) against tests/golden/eval_*.npz = the reference's own
+    evaluate.py flow run with its TePose / VIBE classes and eval_utils functions: mpii3d with J_regressor=None (49 joints ->
+    mpii3d_test, pelvis = joint -3, valid_i holes, a clip without valid frames, one with a single valid frame), h36m with
+    49- and 14-joint targets and invalid db frames, 3dpw with MPVPE.  0.01 mm on every per-clip sum and the final means."""
+    from _eval_fixture import load
+    from tepose_amd.evaluate import clip_metric_record, evaluate_clips, gather_and_reduce
+    fx = load(case)
+    model, vibe, smpl_np = _fixture_models(fx)
+    J = None if fx['dataset'] == 'mpii3d' else torch.from_numpy(smpl_np['J_regressor_h36m'])
+    recs, mine = evaluate_clips(model, vibe, fx['clips'], fx['T'], J_regressor=J, dataset=fx['dataset'])
+    recs = recs.cpu()
+    assert sorted(int(r[0]) for r in recs) == sorted(fx['per_clip'])            # same clips skipped as the reference
+    assert int(recs[:, 1].sum()) == fx['tot_num_pose']
+    names = list(fx['clips'])
+    for r in recs:
+        g = fx['per_clip'][int(r[0])]
+        n = len(g['pose_map'])
+        assert int(r[1]) == n
+        assert abs(float(r[2]) - float(g['mpjpe_all'][g['pose_map']].sum())) < 1e-2 * n
+        assert abs(float(r[3]) - float(g['pa_all'][g['pose_map']].sum())) < 1e-2 * n
+        assert int(r[4]) == (len(g['accel_map']) if int(g['has_accel']) else 0)
+        assert abs(float(r[5]) - float(g['accel_all'][g['accel_map']].sum())) < 1e-2 * max(1, len(g['accel_map']))
+        if fx['dataset'] == '3dpw':
+            assert int(r[6]) == len(g['mpvpe']) and abs(float(r[7]) - float(g['mpvpe'].sum())) < 1e-2 * len(g['mpvpe'])
+        else:
+            assert int(r[6]) == 0
+    got = gather_and_reduce(recs.cuda())
+    assert set(got) == set(fx['final'])
+    for k, v in fx['final'].items():
+        assert abs(got[k] - v) < 1e-2, (k, got[k], v)
+    # the metric block alone on the reference's own raw predictions (no model in between)
+    for ci, g in fx['per_clip'].items():
+        pv = torch.zeros(len(g['raw_pred']), 6890, 3, device='cuda')
+        r = clip_metric_record(model, ci, fx['clips'][names[ci]], torch.from_numpy(g['raw_pred']).cuda(), pv,
+                               'h36m' if fx['dataset'] == '3dpw' else fx['dataset'])
+        assert abs(float(r[2]) - float(g['mpjpe_all'][g['pose_map']].sum())) < 2e-3 * len(g['pose_map'])
+        assert abs(float(r[3]) - float(g['pa_all'][g['pose_map']].sum())) < 2e-3 * len(g['pose_map'])
