@@ -41,6 +41,35 @@ def load_eval_db(db_path, pseudotheta_path, target_action=''):
                                mpii3d='mpii3d' in str(db_path))
 
 
+def load_base_data(base_dir, gender='neutral'):
+    """The four files of `data/base_data` the evaluation reads (evaluate.py:109,130-135; lib/models/smpl.py:54-56,67;
+    lib/models/spin.py:232-235): `J_regressor_h36m.npy` [17,6890], `smpl_mean_params.npz` (pose[144], shape[10], cam[3]),
+    `SMPL_<GENDER>.pkl` (chumpy-free reader) and `J_regressor_extra.npy` [9,6890].  Returns
+    {'J_regressor_h36m', 'mean_params', 'smpl_tables'} with float32 arrays, the tables in the layout
+    tepose_amd.smpl.SMPL.from_tables takes.  Every missing file is named in one FileNotFoundError."""
+    import os.path as osp
+    from .smpl import load_smpl_pkl
+    files = {'J_regressor_h36m': 'J_regressor_h36m.npy', 'mean_params': 'smpl_mean_params.npz',
+             'smpl': 'SMPL_%s.pkl' % gender.upper(), 'J_regressor_extra': 'J_regressor_extra.npy'}
+    missing = [f for f in files.values() if not osp.isfile(osp.join(str(base_dir), f))]
+    if missing:
+        raise FileNotFoundError('base data directory %r lacks %s (licence-gated downloads, reference README.md:21-25)'
+                                % (str(base_dir), ', '.join(missing)))
+    jh = np.asarray(np.load(osp.join(str(base_dir), files['J_regressor_h36m'])), dtype=np.float32)
+    je = np.asarray(np.load(osp.join(str(base_dir), files['J_regressor_extra'])), dtype=np.float32)
+    mp = np.load(osp.join(str(base_dir), files['mean_params']))
+    mean = {'pose': np.asarray(mp['pose'], dtype=np.float32).reshape(-1), 'shape': np.asarray(mp['shape'], dtype=np.float32).reshape(-1),
+            'cam': np.asarray(mp['cam'], dtype=np.float32).reshape(-1)}
+    if jh.shape != (17, 6890) or je.shape != (9, 6890) or mean['pose'].shape != (144,) or mean['shape'].shape != (10,) \
+            or mean['cam'].shape != (3,):
+        raise ValueError('base data shapes: J_regressor_h36m %s (want 17x6890), J_regressor_extra %s (9x6890), mean pose %s '
+                         '(144) shape %s (10) cam %s (3)' % (jh.shape, je.shape, mean['pose'].shape, mean['shape'].shape,
+                                                              mean['cam'].shape))
+    tables = load_smpl_pkl(osp.join(str(base_dir), files['smpl']))
+    tables['J_regressor_extra'] = je
+    return {'J_regressor_h36m': jh, 'mean_params': mean, 'smpl_tables': tables}
+
+
 def load_generator_state_dict(path, map_location='cpu'):
     """checkpoint['gen_state_dict'] with a DataParallel 'module.' prefix stripped
     (evaluate.py:121-124, lib/utils/utils.py:40-45)."""

@@ -39,3 +39,42 @@ def vibe_state(L, H, seed):
     mean = {'pose': vstate['regressor.init_pose'][0], 'shape': vstate['regressor.init_shape'][0],
             'cam': vstate['regressor.init_cam'][0]}
     return vstate, mean
+
+
+def write_base_data(base_dir, smpl_np, mean):
+    """Fabricate the four `data/base_data` files in the layouts the reference reads (SMPL pickle in the official file
+    layout: posedirs [V,3,207], 300 shape directions, sparse J_regressor, uint32 kintree_table)."""
+    import pickle
+    import scipy.sparse as sp
+    os.makedirs(str(base_dir), exist_ok=True)
+    np.save(os.path.join(str(base_dir), 'J_regressor_h36m.npy'), smpl_np['J_regressor_h36m'])
+    np.save(os.path.join(str(base_dir), 'J_regressor_extra.npy'), smpl_np['J_regressor_extra'])
+    np.savez(os.path.join(str(base_dir), 'smpl_mean_params.npz'), pose=np.asarray(mean['pose'], np.float32),
+             shape=np.asarray(mean['shape'], np.float64), cam=np.asarray(mean['cam'], np.float32))
+    par = np.asarray(smpl_np['parents']).astype(np.int64)
+    kintree = np.stack([np.where(par < 0, 2 ** 32 - 1, par), np.arange(24)]).astype(np.uint32)
+    d = {'v_template': smpl_np['v_template'].astype(np.float64),
+         'shapedirs': np.concatenate([smpl_np['shapedirs'], np.zeros((6890, 3, 290), np.float32)], axis=2),
+         'posedirs': smpl_np['posedirs'].T.reshape(6890, 3, 207).astype(np.float64),
+         'J_regressor': sp.csc_matrix(smpl_np['J_regressor'].astype(np.float64)),
+         'weights': smpl_np['lbs_weights'].astype(np.float64), 'kintree_table': kintree,
+         'f': np.zeros((13776, 3), np.uint32)}
+    with open(os.path.join(str(base_dir), 'SMPL_NEUTRAL.pkl'), 'wb') as f:
+        pickle.dump(d, f, protocol=2)
+
+
+def write_checkpoint(path, state_np, prefix=''):
+    """A checkpoint file as lib/core/trainer.py:393-404 writes it (gen_state_dict + a numpy `performance`)."""
+    import torch
+    torch.save({'epoch': 3, 'gen_state_dict': {prefix + k: torch.from_numpy(np.asarray(v)) for k, v in state_np.items()},
+                'performance': np.float64(51.2)}, str(path))
+
+
+def write_cfg(path, title, layers, hidden, pretrained='', seqlen=6):
+    """An experiment YAML with the key structure of the reference's configs/repr_*.yaml."""
+    with open(str(path), 'w') as f:
+        f.write("TITLE: '%s'\nDEVICE: 'cuda'\nDATASET:\n  SEQLEN: %d\n  VIDLEN: 520\nLOSS:\n  KP_2D_W: 300.0\n"
+                "TRAIN:\n  BATCH_SIZE: 32\n  PRETRAINED: '%s'\n  PRETRAINED_REGRESSOR: 'data/base_data/spin_model_checkpoint.pth.tar'\n"
+                "  DATASETS_3D:\n    - 'ThreeDPW'\n  MOT_DISCR:\n    OPTIM: 'Adam'\n    GCN:\n      num_class: 2\n"
+                "MODEL:\n  TEMPORAL_TYPE: 'gru'\n  TGRU:\n    NUM_LAYERS: %d\n    HIDDEN_SIZE: %d\n"
+                % (title, seqlen, pretrained, layers, hidden))

@@ -124,3 +124,52 @@ def test_dataset_branches_match_the_reference_flow(case):
                                'h36m' if fx['dataset'] == '3dpw' else fx['dataset'])
         assert abs(float(r[2]) - float(g['mpjpe_all'][g['pose_map']].sum())) < 2e-3 * len(g['pose_map'])
         assert abs(float(r[3]) - float(g['pa_all'][g['pose_map']].sum())) < 2e-3 * len(g['pose_map'])
+
+
+@pytest.mark.parametrize('case,world', [('eval_mpii3d_L1H64_T5', 1), ('eval_h36m_L1H64_T5', 2)])
+def test_the_eval_tool_on_files_alone_reproduces_the_reference_flow(tmp_path, case, world):
+    """tools/evaluate_clips.py in real-data mode: database + pseudo-theta (joblib), base data (J_regressor_h36m.npy,
+    smpl_mean_params.npz, SMPL_NEUTRAL.pkl, J_regressor_extra.npy), experiment YAML and the two checkpoints all read from
+    files -- the JSON line's metrics equal the reference flow's (tests/golden/eval_*.npz) to 0.01 mm; world 2 = two ranks
+    sharing cuda:0 over gloo (clip sharding + weight broadcast + record gather)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import joblib
+    from _eval_fixture import load, vibe_state, write_base_data, write_cfg, write_checkpoint
+    from tepose_amd.data import synthetic_eval_db
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = load(case)
+    import numpy as np
+    g = np.load(os.path.join(root, 'tests', 'golden', case + '.npz'))
+    lens = [int(v) for v in g['meta'][6:]]
+    db, pse = synthetic_eval_db(lens, seed=int(g['meta'][4]), joints=fx['joints'])
+    for f in g['invalid_frames']:
+        db['valid'][int(f)] = 0
+    stem = 'mpii3d_val_scale12' if fx['dataset'] == 'mpii3d' else 'h36m_test_25fps_nosmpl'
+    if fx['dataset'] == 'mpii3d':
+        db['valid_i'] = g['valid_i']
+    joblib.dump(db, tmp_path / (stem + '_db.pt'))
+    joblib.dump(pse, tmp_path / (stem + '_pseudotheta.pt'))
+    smpl_np = synth.synthetic_smpl(0)
+    state = synth.synthetic_state_dict(fx['L'], fx['H'], fx['seed_w'])
+    vstate, _ = vibe_state(fx['L'], fx['H'], fx['seed_w'] + 1)
+    mean = {'pose': state['regressor.init_pose'][0], 'shape': state['regressor.init_shape'][0], 'cam': state['regressor.init_cam'][0]}
+    write_base_data(tmp_path / 'base', smpl_np, mean)
+    write_checkpoint(tmp_path / 'tepose.pth.tar', state)
+    write_checkpoint(tmp_path / 'vibe.pth.tar', vstate)
+    write_cfg(tmp_path / 'c.yaml', 'repr_wpw_h36m_mpii3d_model', fx['L'], fx['H'], pretrained=str(tmp_path / 'tepose.pth.tar'))
+    cmd = [sys.executable, 'tools/evaluate_clips.py', '--cfg', str(tmp_path / 'c.yaml'), '--dataset', fx['dataset'],
+           '--db-dir', str(tmp_path), '--base-data', str(tmp_path / 'base'), '--vibe-ckpt', str(tmp_path / 'vibe.pth.tar'),
+           '--vibe-layers', str(fx['L']), '--vibe-hidden', str(fx['H']), '--seqlen', str(fx['T'])]
+    if world > 1:
+        cmd += ['--gpus', str(world), '--backend', 'gloo', '--share-device0']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['data'] == 'real' and line['tables'] == 'files' and line['n_gpus'] == world
+    assert set(line['metrics_mm']) == set(fx['final'])
+    for k, v in fx['final'].items():
+        assert abs(line['metrics_mm'][k] - v) < 1e-2, (k, line['metrics_mm'][k], v)
