@@ -225,6 +225,89 @@ def cpu_baseline(state, smpl_np, L, T, budget_s=15.0, gpu_models=None, device=No
     return res
 
 
+
+def eval_driver_block(model, state, smpl_np, device, L, H, cpu_budget_s=8.0, with_cpu=True):
+    """The real evaluation product on the driver's clock (reference flow evaluate.py:209-462): 37 synthetic
+    clips of 300-1800 frames (3DPW-test-sized), seqlen 6 (evaluate.py:141), the published architecture -- VIBE bootstrap over the
+    first T frames of every clip -> `run_clips` (all clips in lock-step, layer-0 projection cache) -> joint conversion, pelvis
+    alignment, MPJPE / PA-MPJPE / accel / MPVPE on the device -> one record per clip -> frame-weighted means.  Timed end to end
+    (host clock, synchronised), once with the projection cache (default) and once with TEPOSE_DRIVER_CACHE=0; beside it the
+    reference's per-clip CPU loop (evaluate.py:247-269: one window at a time) through oracle.run_clip on a bounded prefix of
+    one clip.  Outside the headline timed region; informational."""
+    from tepose_amd import synth
+    from tepose_amd.data import split_db_into_clips, synthetic_eval_db
+    from tepose_amd.evaluate import evaluate_clips, gather_and_reduce
+    from tepose_amd.smpl import SMPL
+    from tepose_amd.vibe import VIBE
+    T, n_clips = 6, 37
+    lens = (300 + 1500 * synth.uniform01('evalclips', n_clips)).astype(int)
+    db, pse = synthetic_eval_db(list(lens), seed=0)
+    clips = split_db_into_clips(db, pse)
+    vstate = synth.synthetic_vibe_state_dict(L, H, 1)
+    mean_v = {'pose': vstate['regressor.init_pose'][0], 'shape': vstate['regressor.init_shape'][0], 'cam': vstate['regressor.init_cam'][0]}
+    vibe = VIBE(seqlen=T, n_layers=L, hidden_size=H, add_linear=True, use_residual=True, pretrained='',
+                smpl=SMPL.from_tables(smpl_np), smpl_mean_params=mean_v)
+    sd = vibe.state_dict()
+    for k, v in vstate.items():
+        sd[k] = torch.from_numpy(v)
+    vibe.load_state_dict(sd)
+    vibe = vibe.to(device).eval()
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    frames, steps = int(lens.sum()), int(lens.max()) - T + 1
+    out = {'clips': n_clips, 'frames': frames, 'seqlen': T, 'lock_steps': steps,
+           'flow': 'VIBE bootstrap -> run_clips (lock-step windows, theta feedback) -> device metrics -> per-clip records -> means'}
+    old = os.environ.get('TEPOSE_DRIVER_CACHE')
+    try:
+        for key, env in (('projection_cache', None), ('no_cache', '0')):
+            if env is None:
+                os.environ.pop('TEPOSE_DRIVER_CACHE', None)
+            else:
+                os.environ['TEPOSE_DRIVER_CACHE'] = env
+            best = None
+            for rep in range(3):                      # first pass warms allocations / packs the bootstrap model
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset='3dpw')
+                res = gather_and_reduce(recs)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                if rep and (best is None or dt < best):
+                    best = dt
+            out[key] = {'seconds': best, 'frames_per_s': frames / best, 'ms_per_lock_step': best / steps * 1e3,
+                        'metrics_mm_on_random_weights': res}
+            del recs
+            torch.cuda.empty_cache()
+    finally:
+        if old is None:
+            os.environ.pop('TEPOSE_DRIVER_CACHE', None)
+        else:
+            os.environ['TEPOSE_DRIVER_CACHE'] = old
+    if with_cpu:
+        # the reference's loop for ONE clip on the host cores: B = 1 windows, strictly serial (best thread count of 1 / 4 / 8)
+        from oracle import tepose_ref as O
+        name0 = next(iter(clips))
+        c0 = clips[name0]
+        best = None
+        for nt in (1, 4, 8):
+            torch.set_num_threads(nt)
+            O.run_clip(state, smpl_np, c0['features'][:T + 1], c0['theta_pseu'][:T - 1], T, L, J_regressor=smpl_np['J_regressor_h36m'])
+            t0 = time.perf_counter()
+            nwin = 0
+            while time.perf_counter() - t0 < cpu_budget_s / 3:
+                O.run_clip(state, smpl_np, c0['features'][:T + 7], c0['theta_pseu'][:T - 1], T, L, J_regressor=smpl_np['J_regressor_h36m'])
+                nwin += 8
+            ms = (time.perf_counter() - t0) / nwin * 1e3
+            if best is None or ms < best[0]:
+                best = (ms, nt)
+        windows = int(sum(max(int(n) - T + 1, 0) for n in lens))
+        out['reference_cpu_loop'] = {'ms_per_window': best[0], 'threads': best[1], 'kind': 'port (oracle.run_clip: evaluate.py:247-269, one window at a time)',
+                                     'sample': '8-window prefixes of one clip for %.1f s per thread count' % (cpu_budget_s / 3),
+                                     'projected_seconds_for_this_database': windows * best[0] / 1e3,
+                                     'frames_per_s': 1e3 / best[0]}
+        out['speedup_vs_reference_cpu_loop'] = out['reference_cpu_loop']['projected_seconds_for_this_database'] / out['projection_cache']['seconds']
+    return out
+
+
 def self_launch(n):
     """One process per GPU through torch.distributed.run on 127.0.0.1 (the driver's own launch line), as children
     of this GPU-free process.  Returns the launcher's exit code."""
@@ -263,6 +346,10 @@ def main():
     ap.add_argument('--force-dist', action='store_true',
                     help='run the process-group path at world size 1 too: init_process_group (nccl = RCCL), blob broadcast, '
                          'all_reduce, gather -- so that the collectives of the N-GPU run execute on a 1-GPU box')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='no GPU work: every rank joins the process group, runs the bench\'s collective sequence (barrier, all_reduce MAX, '
+                         'gather of per-rank records) on host tensors and rank 0 prints a JSON line -- keeps the N-rank launch path testable '
+                         'on a machine without GPUs (use with --backend gloo)')
     args = ap.parse_args()
     # the host driver of this pool only supports dmabuf IPC (RCCL and cross-process tensor sharing fail without it); the runtime
     # reads the variable when HIP initialises, so it has to be in the environment before the first torch.cuda call
@@ -281,6 +368,35 @@ def main():
                          'bench.py start its own ranks)' % (args.gpus, world))
     if args.share_device0:
         local = 0
+    if args.rendezvous_only:
+        # the collective skeleton of the timed region, on host tensors: same calls, same order, no device
+        import torch.distributed as dist
+        if args.backend == 'nccl':
+            raise SystemExit('--rendezvous-only runs without GPUs: use --backend gloo')
+        if world > 1 or args.force_dist:
+            if 'MASTER_ADDR' not in os.environ:
+                import socket
+                sk = socket.socket()
+                sk.bind(('127.0.0.1', 0))
+                os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+                sk.close()
+            dist.init_process_group(args.backend)
+            dist.barrier()
+            t_all = torch.tensor([1.0 + rank], dtype=torch.float64)
+            dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+            rec = torch.tensor([float(rank), 1.0 + rank, float(args.batch * args.steps), 1.0, float(local)], dtype=torch.float64)
+            gathered = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
+            dist.gather(rec, gathered, dst=0)
+            dist.barrier()
+            if rank == 0:
+                print(json.dumps({'rendezvous_only': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                                  'max_over_ranks': float(t_all.item()), 'per_rank': [[float(v) for v in g.tolist()] for g in gathered],
+                                  'dist_backend': dist.get_backend(), 'cuda_initialised': bool(torch.cuda.is_initialized())}))
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({'rendezvous_only': True, 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'per_rank': [[0.0]],
+                              'cuda_initialised': bool(torch.cuda.is_initialized())}))
+        return
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
@@ -559,12 +675,30 @@ def main():
                                   'results_to_host': list(keep),
                                   'how': 'StreamSession.push: one hipGraph replay + one event wait per frame, pinned host rows'}
                     del ses
+            # the published checkpoints' window (DATASET.SEQLEN 6, configs/repr_*.yaml) at the headline batch: 0.600 GFLOP per window
+            xe = synthetic_windows_device(B, 6, 78, device)
+            with torch.no_grad():
+                for _ in range(2):
+                    model(xe, J_regressor=J)
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                for _ in range(5):
+                    model(xe, J_regressor=J)
+                torch.cuda.synchronize()
+            ms6 = (time.perf_counter() - te) / 5 * 1e3
+            tf6 = B * gflop_per_window(6) / (ms6 * 1e-3) / 1e3
+            extra['b%d_T6_published_window' % B] = {'ms_per_forward': ms6, 'windows_per_s': B / ms6 * 1e3, 'algorithmic_tflops': tf6,
+                                                     'frac_of_split_mfma_peak': tf6 / (PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS),
+                                                     'gflop_per_window': gflop_per_window(6)}
+            del xe
             extra['note'] = ('BASELINE.json configs 1 / 2 / 5 (synthetic stand-ins: random-init weights, synthetic features; the '
                              'licence-gated 3DPW data and repr_wpw_3dpw checkpoint are absent, so MPJPE vs that checkpoint is '
                              'UNMEASURED); the recurrent layers and the regressor loop run as persistent kernels '
                              '(csrc/gru_seq.hip, csrc/reg_seq.hip)')
             res['other_shapes'] = extra
             _t('other shapes done')
+            res['eval_driver'] = eval_driver_block(model, state, smpl_np, device, L, H, with_cpu=not args.no_cpu_baseline)
+            _t('eval driver done')
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(state, smpl_np, L, T, gpu_models=gpu_models, device=device)
             _t('cpu baseline done')

@@ -61,6 +61,7 @@ class Engine:
         self.device = None
         self._sig_enc = self._sig_reg = self._sig_smpl = None
         self._ws = None
+        self._ws_private = None        # a caller-owned workspace (use_workspace): StreamSession's captured graphs
         self._ws_need = {}
         self.packed_generation = 0     # bumped by every (re)pack: the workspace size can depend on what was packed
         self._jreg_cache = {}
@@ -294,10 +295,30 @@ class Engine:
             need = self._ws_need[k] = int(self.lib.tepose_workspace_bytes(self.handle, int(B), int(T)))
             if len(self._ws_need) > 64:
                 self._ws_need = {k: need}
+        if self._ws_private is not None:
+            if self._ws_private.numel() < need or self._ws_private.device != device:
+                raise RuntimeError('the caller-owned workspace (%d bytes on %s) is too small for B = %d, T = %d (%d bytes on %s)'
+                                   % (self._ws_private.numel(), self._ws_private.device, B, T, need, device))
+            return self._ws_private
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
+
+    def workspace_bytes(self, B, T):
+        return int(self.lib.tepose_workspace_bytes(self.handle, int(B), int(T)))
+
+    @contextlib.contextmanager
+    def use_workspace(self, ws):
+        """Every forward queued inside the block uses the caller's tensor `ws` instead of the engine's shared, growable
+        workspace.  For callers whose kernels outlive the call -- a captured hipGraph bakes the workspace ADDRESS into its
+        kernel arguments, and the shared workspace is freed and re-allocated whenever a later call needs more bytes or the
+        blob is re-packed (replays into freed memory)."""
+        old, self._ws_private = self._ws_private, ws
+        try:
+            yield self
+        finally:
+            self._ws_private = old
 
     def encoder_fwd(self, x, is_train):
         B, T = x.shape[:2]

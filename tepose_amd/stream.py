@@ -40,6 +40,14 @@ class StreamSession:
         if T < 2 or tuple(feature_init.shape) != (T - 1, 2048) or tuple(theta_init.shape) != (T - 1, 85):
             raise ValueError('feature_init / theta_init must be [seqlen-1, 2048] / [seqlen-1, 85] with seqlen >= 2')
         self.stream = torch.cuda.Stream(device=dev)
+        eng = model._engine
+        with torch.no_grad():
+            eng.pack_model(model, dev)          # the workspace size depends on what is packed
+        # A workspace of the session's own: the captured graph bakes its address into every kernel argument (the status words
+        # that push() reads live in it too), and the engine's shared workspace moves whenever another call on the model needs
+        # more bytes or the weights are re-packed.  Two sessions on one model do not share scratch either.
+        self.ws = torch.empty(eng.workspace_bytes(1, T), dtype=torch.uint8, device=dev)
+        self._captured_for = None
         # the window as the model sees it (slot T-1 = the newest frame) and a scratch copy for the one-frame shift
         self.win = torch.zeros(1, T, 2133, device=dev)
         self.win[0, 1:, :2048] = feature_init.to(dev, torch.float32)      # after the first push's shift they sit in slots 0 .. T-2
@@ -52,7 +60,9 @@ class StreamSession:
         self.use_graph = bool(graph)
         self.done = torch.cuda.Event()
         self.frames = 0
-        with torch.no_grad(), torch.cuda.stream(self.stream):
+        # the buffers above were filled on the caller's stream; the session's stream is non-blocking (no implicit ordering)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(self.stream), eng.use_workspace(self.ws):
             # warm-up (its window is restored afterwards): packs the blob, sizes the workspace, creates the pinned result rows
             for attempt in (0, 1):
                 with model._engine.lazy_status():
@@ -87,10 +97,18 @@ class StreamSession:
                 self.out_host[k] = torch.empty(out[k][0].shape, dtype=torch.float32).pin_memory()
             self.out_host[k].copy_(out[k][0], non_blocking=True)
 
+    def _signature(self):
+        eng = self.model._engine
+        return (eng.packed_generation, eng.blob.data_ptr() if eng.blob is not None else 0, self.ws.data_ptr())
+
     def _capture(self):
+        """Queue-free capture of one step with the session's own workspace; remembers which packed blob it was captured
+        against (a re-pack or an adopted blob invalidates the graph: push() re-captures)."""
+        eng = self.model._engine
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        with eng.use_workspace(self.ws), torch.cuda.graph(self.graph, stream=self.stream):
             self._step()
+        self._captured_for = self._signature()
 
     @torch.no_grad()
     def push(self, feature):
@@ -100,8 +118,16 @@ class StreamSession:
         if torch.is_tensor(feature) and feature.is_cuda:
             feature = feature.cpu()
         self.feat_host.copy_(torch.as_tensor(feature, dtype=torch.float32).reshape(2048))
-        for attempt in (0, 1):
+        if self.graph is not None and self._signature() != self._captured_for:
+            # the blob the graph was captured against was re-packed (another caller's forward after a weight change: kernel
+            # selection may differ, e.g. the fp16-range fallback) or replaced (adopt_blob, device move): capture again
+            need = eng.workspace_bytes(1, self.T)
+            if self.ws.numel() < need:
+                self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
             with torch.cuda.stream(self.stream):
+                self._capture()
+        for attempt in (0, 1):
+            with torch.cuda.stream(self.stream), eng.use_workspace(self.ws):
                 if self.graph is not None:
                     self.graph.replay()
                 else:

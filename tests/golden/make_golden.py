@@ -104,7 +104,10 @@ def install_stubs():
         if s.endswith('J_regressor_extra.npy'):
             return SMPL_NP['J_regressor_extra']
         if s.endswith('smpl_mean_params.npz'):
-            return MEAN
+            # a fresh copy per load, as a real np.load gives: Regressor.__init__ wraps the arrays with torch.from_numpy, so two
+            # models built from ONE dict would share their init_pose / init_shape / init_cam buffers (load_state_dict of the second
+            # would overwrite the first's)
+            return {k: np.array(v, copy=True) for k, v in MEAN.items()}
         return _np_load(p, *a, **k)
 
     np.load = fake_load

@@ -37,3 +37,43 @@ def test_newest_traffic_profile_matches_the_default_kernels():
 def test_physical_core_count_is_sane():
     n = bench.physical_cores()
     assert n is None or 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_n_rank_launch_path_runs_on_a_machine_without_gpus():
+    """`python bench.py --gpus 2 --backend gloo --rendezvous-only`: the GPU-free parent starts the stock launcher line (the driver's
+    own: torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...), the ranks join the group and run the
+    bench's collective sequence (barrier, all_reduce MAX, gather) on host tensors -- no HIP call anywhere (VERDICT r4 item 9:
+    keep the N-GPU path warm without faking a curve)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    env.pop('WORLD_SIZE', None)
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--backend', 'gloo', '--share-device0',
+                        '--rendezvous-only'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['rendezvous_only'] and line['n_gpus'] == 2 and line['steps'] == 3 and line['dist_backend'] == 'gloo'
+    assert line['max_over_ranks'] == 2.0                                     # MAX over ranks of (1 + rank)
+    assert sorted(r[0] for r in line['per_rank']) == [0.0, 1.0] and not line['cuda_initialised']
+    # a WORLD_SIZE that contradicts --gpus is refused, not silently run as something else
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--rendezvous-only', '--backend', 'gloo'], cwd=ROOT,
+                       env=dict(env, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and 'WORLD_SIZE=4' in (p.stderr + p.stdout)
+
+
+def test_self_launch_builds_the_drivers_command_line(monkeypatch):
+    import subprocess
+    import sys
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '5', '--warmup', '2'])
+    assert bench.self_launch(8) == 0
+    cmd = seen['cmd']
+    assert cmd[1:6] == ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8']
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    assert cmd[-6:] == ['--gpus', '8', '--steps', '5', '--warmup', '2'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

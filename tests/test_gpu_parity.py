@@ -139,9 +139,9 @@ def test_full_forward_vs_reference_golden(case, smpl_np):
     assert o['rotmat'].shape == (B, 24, 3, 3) and o['kp_3d'].shape[1] == (14 if use_j else 49)
     assert np.abs(o['rotmat'] - g['rotmat']).max() < TOL
     assert np.abs(o['verts'][:, ::53] - g['verts_sub']).max() < TOL
-    assert np.abs(o['verts'].sum(1) - g['verts_sum']).max() < 2e-2
+    assert np.abs(o['verts'].sum(1) - g['verts_sum']).max() < 5e-3       # sum of 6890 coordinates, each within ~1e-6
     assert np.abs(o['kp_3d'] - g['kp_3d']).max() < TOL
-    assert np.abs(o['kp_2d'] - g['kp_2d']).max() < 5e-4
+    assert np.abs(o['kp_2d'] - g['kp_2d']).max() < TOL                   # the north star's 1e-4 (measured ~1e-7)
     _check_theta(o['theta'], g['theta'].astype(np.float64), g['rotmat'])
     for v in out[0].values():
         assert v.is_contiguous() and v.dtype == torch.float32 and v.is_cuda

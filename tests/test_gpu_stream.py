@@ -125,3 +125,49 @@ def test_a_give_up_during_session_setup_is_repaired_too(smpl_np, monkeypatch):
         ses = StreamSession(bad, 6, torch.from_numpy(w[:5, :2048].copy()), torch.from_numpy(w[:5, 2048:].copy()), keep=('theta',))
     assert bad._engine.degraded
     assert torch.isfinite(ses.push(torch.from_numpy(w[5, :2048].copy()))['theta']).all()
+
+
+def test_the_session_owns_its_workspace_and_survives_other_callers_on_the_model(smpl_np):
+    """the captured graph used to bake in the address of the engine's shared workspace, which a later, larger
+    call on the same model frees and re-allocates (and which two sessions shared).  Now each session has a workspace of its
+    own: between pushes the model runs a much larger batch (the shared workspace grows: other address), a second session on
+    the SAME model interleaves its pushes, and a weight re-pack triggers a re-capture -- every frame still equals the
+    clip-at-once driver bit for bit.  The session's buffers are initialised on a busy caller stream (ordering fix)."""
+    from tepose_amd.driver import run_clips
+    from tepose_amd.stream import StreamSession
+    from tepose_amd.testing import build_model
+    L, H, T, N = 2, 256, 6, 16
+    model, _, _ = build_model(L, H, seed=31, device='cuda', smpl_np=smpl_np)
+    wa, wb = synth.synthetic_windows(1, N, 91)[0], synth.synthetic_windows(1, N, 92)[0]
+    fa, fb = torch.from_numpy(wa[:, :2048].copy()), torch.from_numpy(wb[:, :2048].copy())
+    tha, thb = torch.from_numpy(wa[:T - 1, 2048:].copy()), torch.from_numpy(wb[:T - 1, 2048:].copy())
+    ref_a = run_clips(model, [fa], [tha], T, keep=('theta', 'verts'))[0]
+    ref_b = run_clips(model, [fb], [thb], T, keep=('theta', 'verts'))[0]
+    # a busy default stream while the sessions are built from DEVICE tensors (the init copies must be ordered before capture)
+    junk = torch.randn(4096, 4096, device='cuda')
+    for _ in range(20):
+        junk = junk @ junk.t() * 1e-4
+    sa = StreamSession(model, T, fa[:T - 1].cuda(), tha.cuda(), keep=('theta', 'verts'))
+    sb = StreamSession(model, T, fb[:T - 1].cuda(), thb.cuda(), keep=('theta', 'verts'))
+    assert sa.ws.data_ptr() != sb.ws.data_ptr()
+    eng = model._engine
+    big = torch.from_numpy(synth.synthetic_windows(96, T, 93)).cuda()
+    for j in range(N - T + 1):
+        ra = {k: v.clone() for k, v in sa.push(fa[T - 1 + j]).items()}
+        if j == 2:
+            shared_before = eng._ws.data_ptr() if eng._ws is not None else 0
+            with torch.no_grad():
+                model(big)                                       # the shared workspace grows: freed + re-allocated
+            assert eng._ws is not None and eng._ws.numel() >= eng.workspace_bytes(96, T)
+            del shared_before
+        if j == 4:
+            gen = eng.packed_generation
+            with torch.no_grad():
+                model.encoder.linear_fwd.bias.add_(0.0)          # an in-place touch bumps the parameter version: re-pack
+                model(big[:1])
+            assert eng.packed_generation > gen
+        rb = sb.push(fb[T - 1 + j])
+        for k in ('theta', 'verts'):
+            assert torch.equal(ra[k], ref_a[k][j].cpu()), (k, j)
+            assert torch.equal(rb[k], ref_b[k][j].cpu()), (k, j)
+    assert sa._captured_for[0] == eng.packed_generation        # both graphs were re-captured against the re-packed blob
