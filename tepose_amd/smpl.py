@@ -100,6 +100,11 @@ class _VertexJointSelector(nn.Module):
             [332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
              2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133], dtype=torch.long))
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # smplx-owned constant: a checkpoint may or may not carry it (the author's smplx version decides); the table above is
+        # what the hot path uses either way -- never "missing", never a shape error (evaluate.py:124 loads strictly)
+        state_dict.pop(prefix + 'extra_joints_idxs', None)
+
 
 class SMPL(nn.Module):
     """SMPL(model_path, batch_size=1, create_transl=False, gender='neutral', ...) as the callers

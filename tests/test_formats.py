@@ -118,3 +118,23 @@ def test_padded_validation_batch_follows_the_dataset_layout():
     assert np.array_equal(b['theta'][2, :6, 3:75].numpy(), db['pose'][26:32].astype(np.float16).astype(np.float32))
     assert not b['theta'][2, 6:].any() and b['index'].view(-1).tolist() == [0.0, 1.0, 2.0]
     assert padded_validation_batch(db, pse, seqlen=20) is None
+
+
+def test_strict_checkpoint_load_with_and_without_smplx_owned_keys():
+    """evaluate.py:124 loads the generator strictly.  A reference checkpoint carries whatever the author's smplx version registered under
+    `regressor.smpl.*` (faces_tensor, vertex_joint_selector.extra_joints_idxs, ...); a checkpoint written from this repo's modules, or by
+    an smplx that registers other buffers, does not -- both must load with strict=True and neither may change the hot path's tables."""
+    from tepose_amd.smpl import SMPL
+    from tepose_amd.tepose import TePose
+    m = TePose(seqlen=5, n_layers=1, hidden_size=64, pretrained='', smpl=SMPL.from_tables(synth.synthetic_smpl(0)),
+               smpl_mean_params=synth.synthetic_mean_params(0))
+    sd = {k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(1, 64, 2).items()}
+    r = m.load_state_dict(dict(sd), strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    idx = m.regressor.smpl.vertex_joint_selector.extra_joints_idxs.clone()
+    sd['regressor.smpl.vertex_joint_selector.extra_joints_idxs'] = torch.zeros(21, dtype=torch.long)
+    sd['regressor.smpl.faces_tensor'] = torch.zeros(13776, 3, dtype=torch.long)
+    sd['regressor.smpl.some_future_smplx_buffer'] = torch.zeros(3)
+    r = m.load_state_dict(dict(sd), strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    assert torch.equal(m.regressor.smpl.vertex_joint_selector.extra_joints_idxs, idx)
