@@ -20,8 +20,11 @@ struct DirW {                     // one GRU layer/direction inside the blob (fl
   size_t whh = 0, bhh = 0;
   size_t wih_p = 0, whh_p = 0;    // blocked hi|lo fp16 planes of the same matrices (whh: gate-tiled rows), float offsets
   size_t wih_s = 0, whh_s = 0;    // the same as scaled [K/16][R][16] planes (gemm_h3s.hip; rows padded to 256 / 384)
-  size_t scales = 0;              // blob slot: [0] = W_ih scale, [1] = W_hh scale
+  size_t scales = 0;              // blob slot: [0] = W_ih scale, [1] = W_hh scale, [2] = scale of the concatenated [W_ih | W_hh] planes
   float wih_scale = 1.f, whh_scale = 1.f;   // host copies
+  size_t wcat_s = 0;              // layers >= 1: scaled planes of [W_ih | W_hh] ([K/16][384-padded gate-tiled rows][16], one scale; gru_fuse16.hip)
+  size_t bias4 = 0;               // layers >= 1: [4][Hp] = b_ir + b_hr | b_iz + b_hz | b_in | b_hn
+  float wcat_scale = 1.f;
 };
 
 struct SmplOff {
@@ -83,6 +86,7 @@ struct tepose_model {
   bool persist = true;                          // false: step-per-launch kernels at every batch size (tepose_set_persistent)
   unsigned spin_limit = 1u << 21;               // polls (~1 us each) before a wait gives up
   int blend16_min_n = 512;                      // TEPOSE_BLEND16_MIN_N: rows from which the blend-shape product runs on gemm_h3s_persist16c_kernel (0x7fffffff = never)
+  int fuse_l1 = 1;                              // TEPOSE_FUSE_L1: large batches run the cell steps of layers >= 1 with the layer's input projection fused into the K loop (gru_fuse16.hip)
   int gi_blk = 1;                               // TEPOSE_GI_BLK: large batches keep the layer >= 1 gate pre-activations in the 16 x 16-blocked layout (common.h gi_blk_offset)
   unsigned test_fault = 0;                      // TEPOSE_TEST_FAULT: bit 0 recurrent kernel, bit 1 regressor kernel wait for arrivals that never come
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
@@ -180,6 +184,13 @@ void layout(tepose_model* m) {
   m->wlf_p = take(cur, (size_t)kFeat * Hp);
   m->wlr_p = take(cur, (size_t)kFeat * 2 * Hp);
   m->wlfr_p = take(cur, (size_t)kFeat * 3 * Hp);
+  for (size_t l = 1; l < L; ++l) {      // fused input projection + recurrent step (gru_fuse16.hip): planes of [W_ih | W_hh], combined biases
+    const size_t r384 = round_up(3 * (int)Hp, 384);
+    m->fwd[l].wcat_s = take(cur, r384 * 2 * Hp);
+    m->rec_f[l].wcat_s = take(cur, r384 * 3 * Hp);
+    m->rec_r[l].wcat_s = take(cur, r384 * 3 * Hp);
+    for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) d->bias4 = take(cur, 4 * Hp);
+  }
   layout_tail(m, cur);
 }
 
@@ -311,6 +322,38 @@ int scaled_planes_of(const float* packed, int rows, int Kp, float* dst_planes, i
   if ((e = launch_split_planes16(packed, Kp, rows, Kp, Kp, (long)R, p, hi, hi + (size_t)R * Kp, s)) != hipSuccess)
     return (int)e;
   return (int)hipStreamSynchronize(s);    // *scale_host is read by the async copy above
+}
+
+// layers >= 1: scaled planes of the concatenated [W_ih | W_hh] with ONE scale (largest |w| of both * p in [2^13, 2^14)), rows in the gate-interleaved
+// tile order padded to 384 -- W_ih's packed fp32 copy is in the natural [gate][unit] row order (launch_split_planes16's tiled_hp mapping reorders it),
+// W_hh's is tiled already -- plus the combined bias rows.  Pack time only.
+int cat_planes_of(tepose_model* m, DirW* d, int Kin, hipStream_t s) {
+  float* B = m->blob;
+  const int Hp = m->Hp, r384 = round_up(3 * Hp, 384);
+  float* sc = B + d->scales + 2;
+  CK(launch_absmax(B + d->wih, (size_t)3 * Hp * Kin, sc, s));
+  CK(launch_absmax(B + d->whh, (size_t)3 * Hp * Hp, sc + 1, s));
+  float wm[2] = {0.f, 0.f};
+  CK(hipMemcpyAsync(wm, sc, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  const float wmax = wm[0] > wm[1] ? wm[0] : wm[1];
+  float p = 1.f;
+  if (wmax > 0.f && wmax < 3e38f) {
+    int ex = 0;
+    (void)frexpf(wmax, &ex);
+    p = ldexpf(1.f, 14 - ex);
+  }
+  d->wcat_scale = p;
+  CK(hipMemcpyAsync(sc, &d->wcat_scale, sizeof(float), hipMemcpyHostToDevice, s));
+  const size_t K = (size_t)Kin + Hp;
+  CK(launch_fill(B + d->wcat_s, (size_t)r384 * K, 0.f, s));
+  half_t* hi = (half_t*)(B + d->wcat_s);
+  half_t* lo = hi + (size_t)r384 * K;
+  CK(launch_split_planes16(B + d->wih, Kin, 3 * Hp, Kin, Kin, (long)r384, p, hi, lo, s, Hp));
+  const size_t off = (size_t)(Kin / 16) * r384 * 16;
+  CK(launch_split_planes16(B + d->whh, Hp, 3 * Hp, Hp, Hp, (long)r384, p, hi + off, lo + off, s));
+  CK(launch_bias_cat(B + d->bih, B + d->bhh, B + d->bias4, Hp, s));
+  return (int)hipStreamSynchronize(s);    // d->wcat_scale is read by the async copy above
 }
 
 struct Carver {
@@ -567,6 +610,8 @@ static void read_env_knobs(tepose_model* m) {
   m->blend16_min_n = e ? atoi(e) : 512;
   e = getenv("TEPOSE_GI_BLK");
   m->gi_blk = e ? atoi(e) : 1;
+  e = getenv("TEPOSE_FUSE_L1");
+  m->fuse_l1 = e ? atoi(e) : 1;
   // the symbols a rocprofv3 kernel trace of a large-batch forward (B >= s_min_b, B * T >= 8192) lists for the two dominant
   // launch families -- what a committed profile must name to describe THIS binary with THESE knobs (bench.py checks)
   const char* h3sp = getenv("TEPOSE_H3S_PERSIST");
@@ -899,6 +944,7 @@ int tepose_derive_planes(tepose_model* m, void* stream) {
         CK((hipError_t)planes_rows(d->whh, 3 * Hp, Hp, d->whh_p, n128));
         CK((hipError_t)scaled_planes_of(B + d->whh, 3 * Hp, Hp, B + d->whh_s, round_up(3 * Hp, 384), B + d->scales + 1,
                                         &d->whh_scale, s));
+        if (l > 0) CK((hipError_t)cat_planes_of(m, d, Kp, s));
       }
     }
     CK((hipError_t)planes_of(B + m->wlf, kFeat, Hp, B + m->wlf_p, s));
@@ -1072,6 +1118,7 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
       }
       CK((hipError_t)scaled_planes_of(B + d.d->whh, 3 * Hp, Hp, B + d.d->whh_s, round_up(3 * Hp, 384),
                                       B + d.d->scales + 1, &d.d->whh_scale, s));
+      if (l > 0) CK((hipError_t)cat_planes_of(m, d.d, d.split ? 2 * Hp : Hp, s));
     }
   }
   const float* const* t = w + 12 * L;
@@ -1259,6 +1306,9 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   // gru_h3s16_kernel / gru_first16_kernel / gru_first_kernel -- only with the default kernel selection (any other knob keeps [rows][3 Hp])
   const bool gblk = sf && m->gi_blk && (m->mfma16 & 9) == 9 && (m->mfma16 & 6) && !(m->mfma16 & 16) && Hp % 32 == 0 && gemm_h3s_blocked_ok();
   if (src.blk && !gblk) return (int)hipErrorInvalidValue;   // the caller projected layer 0 into the blocked layout: every consumer here must read it
+  // layers >= 1 of large batches: the cell steps run over [x_t | h_{t-1}] against the planes of [W_ih | W_hh] (gru_fuse16.hip) -- no gate pre-activations in
+  // memory, no projection launches except one slab per direction for the first step (h = 0: element-wise kernel)
+  const bool fuse = sf && m->fuse_l1 && L >= 2 && T >= 2 && B % 128 == 0 && (m->mfma16 & 4) && !(m->mfma16 & 16);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t w_s, float w_scale, size_t bias,
                   float* out, int M) -> int {
@@ -1309,7 +1359,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           const half_t* sh = (const half_t*)(Bl + dw[d]->whh_s);
           b.p[d] = H3SArgs{vi.hi, vi.lo, vi.kst, sh, sh + r384 * Hp, (long)r384 * 16, Hp, nullptr, 0, nullptr,
                            1.f / (kStateScale * dw[d]->whh_scale), B, H3};
-          b.p[d].shape16 = (m->mfma16 & 16) ? 4 : (m->mfma16 & 4) ? 2 : ((m->mfma16 >> 1) & 1);      // 2: the four-wave form of the 16x16x32 step, 4: persistent barrier-free
+          b.p[d].shape16 = (m->mfma16 & 16) ? 4 : (m->mfma16 & 64) ? 6 : (m->mfma16 & 32) ? 5 : (m->mfma16 & 4) ? 2 : ((m->mfma16 >> 1) & 1);      // 2: the four-wave form of the 16x16x32 step, 4: persistent barrier-free, 5: four waves + cell operands by LDS-DMA
           if (w.sync) b.p[d].status = sync_gru_status(m, w.sync);
           b.p[d].fault = m->fault;
           b.p[d].inject = (m->test_fault >> 2) & 1u;
@@ -1402,6 +1452,14 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         }
         if (big.n) CK(launch_gemm_h3(big, s));
         if (sk.n) CK(launch_skinny_gemm_h3_batch(sk, s));
+      } else if (fuse) {
+        // only the slab each direction's FIRST step reads: fwd / rec forward frame 0 (flipped index 0), rec reverse flipped index T - 1
+        const int M1 = (int)Bs;
+        CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].wih_s, m->fwd[l].wih_scale, m->fwd[l].bih, w.gf, M1));
+        CK((hipError_t)proj(inr + (long)(T - 1) * Bs * 2 * Hp, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].wih_s, m->rec_r[l].wih_scale,
+                            m->rec_r[l].bih, w.grr, M1));
+        CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].wih_s, m->rec_f[l].wih_scale, m->rec_f[l].bih, w.grf,
+                            top ? B : M1));
       } else {
       CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].wih_s, m->fwd[l].wih_scale, m->fwd[l].bih,
                           w.gf, MT));
@@ -1414,7 +1472,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       ldg = H3;
     }
     // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
-    auto goff = [&](int q) -> long { return (long)q * Bs * H3; };
+    const bool fused_layer = fuse && l >= 1;
+    auto goff = [&](int q) -> long { return fused_layer ? 0 : (long)q * Bs * H3; };   // (a fused layer holds one slab of gate pre-activations per direction: its first step's)
 
     if (m->prof) { int rc = prof_mark(mm, s); if (rc) return rc; }
     const bool use_seq = seq && gru_seq_ok(top ? 2 : 3, B, Hp, T);
@@ -1508,6 +1567,32 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         }
         continue;
       }
+      if (fused_layer && st > 0) {
+        // x_t of this step per direction: the previous layer's state slab (fwd: frame st; rec reverse: flipped index T - 1 - st; rec forward: flipped index st)
+        const float* xin[3] = {w.sf[(l - 1) & 1] + (long)st * Bs * Hp, w.sr[(l - 1) & 1] + (long)(T - 1 - st) * Bs * 2 * Hp,
+                               w.sr[(l - 1) & 1] + (long)st * Bs * 2 * Hp};
+        const int kx[3] = {Hp, 2 * Hp, 2 * Hp};
+        FuseBatch fb{};
+        const size_t r384 = (size_t)round_up(H3, 384);
+        for (int k = 0; k < nd; ++k) {
+          const EncWs::View vx = w.view16(xin[k]), vh = w.view16(a.d[k].hprev), vo = w.view16(a.d[k].hout);
+          if (!vx.hi || !vh.hi || !vo.hi) return (int)hipErrorInvalidValue;
+          FuseDir& f = fb.d[k];
+          f.Xh = vx.hi; f.Xl = vx.lo; f.x_kst = vx.kst;
+          f.Hh = vh.hi; f.Hl = vh.lo; f.h_kst = vh.kst;
+          const half_t* sh = (const half_t*)(Bl + dw[k]->wcat_s);
+          f.Wh = sh; f.Wl = sh + r384 * (size_t)(kx[k] + Hp); f.w_kst = (long)r384 * 16;
+          f.Kx = kx[k];
+          f.inv_scale = 1.f / (kStateScale * dw[k]->wcat_scale);
+          f.bias4 = Bl + dw[k]->bias4;
+          const bool fp32_out = top && st == T - 1;                 // the tail reads the top layer's last states as fp32 rows; every other state lives in its planes
+          f.hout = fp32_out ? a.d[k].hout : nullptr; f.ldo = a.d[k].ldo;
+          f.hout_hi = vo.hi; f.hout_lo = vo.lo; f.okst = vo.kst;
+        }
+        fb.n = nd; fb.M = B; fb.Hp = Hp; fb.state_scale = kStateScale;
+        CK(launch_gru_fuse16(fb, s));
+        continue;
+      }
       CK((hipError_t)step(a, wp, dw));
     }
     if (top && !use_seq) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
@@ -1528,6 +1613,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       if (rc) return rc;
       // consumed cell steps of this layer: fwd T + rec_reverse T + rec forward (T, or 1 on the top layer)
       mm->prof_gru_flops += 2.0 * B * 3.0 * m->H * m->H * (2.0 * T + (top ? 1 : T));
+      // a fused layer's step launches also run the layer's input projection (fwd: K = H, the two rec directions: K = 2 H), T - 1 steps each
+      if (fused_layer) mm->prof_gru_flops += 2.0 * B * 3.0 * m->H * m->H * (T - 1.0) * (1.0 + 2.0 + (top ? 0.0 : 2.0));
     }
   }
   // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------

@@ -350,7 +350,24 @@ hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s);          // the f
 bool gemm_h3s_mid_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s);   // 128 x 288 tiles, N % 288 == 0
 hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
-                                 void* lo, hipStream_t s);
+                                 void* lo, hipStream_t s, int tiled_hp = 0);   // tiled_hp = Hp: destination row q (gate-interleaved tile order,
+                                 // q = jt * 192 + wn * 96 + gate * 32 + i) takes source row gate * Hp + jt * 64 + wn * 32 + i
+// gru_fuse16.hip (round 5): one cell step of a layer >= 1 with the layer's input projection fused into the K loop -- [x_t | h_{t-1}] against the
+// planes of [W_ih | W_hh]; no gate pre-activations in memory.  One direction of one step:
+struct FuseDir {
+  const half_t *Xh, *Xl; long x_kst;     // this step's input rows (the previous layer's state slab) as scaled planes: view base, halfs between K-tiles
+  const half_t *Hh, *Hl; long h_kst;     // previous state planes of this direction
+  const half_t *Wh, *Wl; long w_kst;     // planes of [W_ih | W_hh]: rows in the gate-interleaved tile order padded to 384, K-tiles [0, Kx / 16) = W_ih
+  int Kx;                                // input width (Hp or 2 Hp), multiple of 32
+  float inv_scale;                       // 1 / (kStateScale * scale of the concatenated weight planes)
+  const float* bias4;                    // [4][Hp]: b_ir + b_hr | b_iz + b_hz | b_in | b_hn
+  float* hout; long ldo;                 // fp32 new state (row-major) where somebody reads it, else nullptr: the planes are the state
+  half_t *hout_hi, *hout_lo; long okst;  // planes of the new state: view base, halfs between 16-column groups
+};
+struct FuseBatch { FuseDir d[3]; int n, M, Hp; float state_scale; };
+bool gru_fuse16_ok(const FuseBatch& b);
+hipError_t launch_gru_fuse16(const FuseBatch& b, hipStream_t s);
+hipError_t launch_bias_cat(const float* bih, const float* bhh, float* out, int Hp, hipStream_t s);
 hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);
 size_t gemm_h3s_ws_bytes(int M, int N, int K);
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,

@@ -45,7 +45,7 @@ __device__ __forceinline__ void wait_vms() {
 // consecutive K-tiles of the same rows, so a block's reads stay contiguous; 4 units in flight per wave.
 __global__ void __launch_bounds__(256) split_planes16_kernel(const float* __restrict__ src, long ld, long rows, int K,
                                                              int Kp, long R, float p, _Float16* __restrict__ hi,
-                                                             _Float16* __restrict__ lo) {
+                                                             _Float16* __restrict__ lo, int tiled_hp) {
   typedef _Float16 h16x2s __attribute__((ext_vector_type(2)));
   const int KT = Kp / 16;
   const long units = ((rows + 7) / 8) * KT;
@@ -62,8 +62,10 @@ __global__ void __launch_bounds__(256) split_planes16_kernel(const float* __rest
       const long row = 8 * grp + (lane >> 3);
       const int k = kt * 16 + 2 * (lane & 7);
       const bool ok = u < units && row < rows;
-      v0[i] = (ok && k < K) ? src[row * ld + k] : 0.f;
-      v1[i] = (ok && k + 1 < K) ? src[row * ld + k + 1] : 0.f;
+      // tiled_hp: destination row q = jt * 192 + wn * 96 + gate * 32 + i of the gate-interleaved tile order reads the natural row gate * Hp + jt * 64 + wn * 32 + i
+      const long srow = tiled_hp ? (long)((row % 96) / 32) * tiled_hp + (row / 192) * 64 + ((row % 192) / 96) * 32 + row % 32 : row;
+      v0[i] = (ok && k < K) ? src[srow * ld + k] : 0.f;
+      v1[i] = (ok && k + 1 < K) ? src[srow * ld + k + 1] : 0.f;
       o[i] = ok ? plane16_index(row, k, R) : -1;
     }
 #pragma unroll
@@ -78,13 +80,14 @@ __global__ void __launch_bounds__(256) split_planes16_kernel(const float* __rest
 }
 
 hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
-                                 void* lo, hipStream_t s) {
+                                 void* lo, hipStream_t s, int tiled_hp) {
   if (rows <= 0) return hipSuccess;
+  if (tiled_hp && (tiled_hp % 64 != 0 || rows != 3 * (long)tiled_hp)) return hipErrorInvalidValue;
   const long units = ((rows + 7) / 8) * (Kp / 16);
   const long want = (units + 15) / 16;
   const int blocks = (int)(want < 16384 ? want : 16384);
   hipLaunchKernelGGL(split_planes16_kernel, dim3(blocks), dim3(256), 0, s, src, ld, rows, K, Kp, R, p, (_Float16*)hi,
-                     (_Float16*)lo);
+                     (_Float16*)lo, tiled_hp);
   return hipGetLastError();
 }
 

@@ -346,8 +346,16 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16_kernel(H3SArgs a, int 
 // NWM = 4: eight waves of 32 rows x 96 columns (122 VGPRs, four waves per SIMD with two workgroups per CU).  NWM = 2 (round 4): FOUR
 // waves of 64 x 96 -- 20 fragment reads per 72 MFMAs instead of 16 per 36, i.e. 160 + 80 KB of LDS traffic per pair of stages and CU
 // instead of 256 + 80 (the eight-wave form is LDS-bound: 2688 LDS cycles against 2304 MFMA cycles per pair and CU), two waves per SIMD.
-template <int TAG, int NWM>
+// GIDMA (round 5; opt-in A/B: TEPOSE_MFMA16 bit 32): the cell update's gate pre-activations / previous state travel through the SAME
+// in-order LDS-DMA request stream as the K panels (into ring slots the last pair steps have freed) and are read from LDS; the launcher selects this
+// instantiation only for full tiles on the blocked layouts (no run-time path choice inside: with both paths in one kernel hipcc threaded the other
+// path's loads in front of the LDS reads and answered them with vmcnt(0)).  Bit-identical results.
+// HPL (with GIDMA; opt-in A/B: TEPOSE_MFMA16 bit 64): the previous state of the cell update is rebuilt from the hi / lo PLANES the K loop
+// streams anyway (22 significant bits: exactly the value the matrix product consumed) instead of a separate fp32 copy, and the fp32 copy of a state that only
+// the next step reads (blocked layout) is no longer written: 8 of 24 bytes per element less beyond L2.  NOT bit-identical to the fp32-state form.
+template <int TAG, int NWM, bool GIDMA = false, bool HPL = false>
 __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(H3SBatch batch, int tilesM, int tilesN, int GM) {
+  static_assert(!HPL || GIDMA, "the plane-fed previous state rides on the LDS-DMA-fed cell update");
   constexpr int NWN = 2, NW = NWM * NWN, NST = 4, MT = 8 / NWM, NT = 6;  // wave = MT row tiles x (3 gates x 2 unit tiles) of 16 x 16
   constexpr int HM = 128, HN = 192, HK = 16, RB = HK * 2, RPI = 1024 / RB;
   constexpr int STAGE = (2 * HM + 2 * HN) * RB;            // 20 KB
@@ -540,8 +548,54 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
   for (; p + 2 < NP; ++p) pairstep(p, T_{}, I1{}, I0{});
   // (Pulling the cell operands towards L2 two pair steps ahead -- one global_load_dword per 128-byte line, counted in the last two
   // waits -- was measured: 11.50 against 11.31 ms for the recurrent part of a forward, same baseline.  Not kept.)
-  pairstep(NP - 2, F_{}, I1{}, I0{});
-  pairstep(NP - 1, F_{}, I0{}, I0{});
+  // GIDMA: cell operands through the LDS-DMA stream: a wave's operands of one 16-row tile are 8 contiguous KB-blocks (6 of gate pre-activations: (u, gate),
+  // 2 of fp32 previous state) = 8 requests into a wave-private 8 KB of the ring slots whose pair every wave has read (behind that pair's B').
+  // Row tile 0 is requested behind pair NP - 2, row tile 1 behind pair NP - 1 (~1.5 pair steps before the K loop ends); later row tiles reuse the
+  // two buffers.  Full tiles on the blocked layouts only (the launcher checks): the vmcnt waits of the update count the stores of every row tile.
+  using I6 = std::integral_constant<int, 6>;
+  using I8 = std::integral_constant<int, 8>;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // HPL: lanes >= 32 fetch from the lo plane (the launcher checks that the planes are less than 4 GB apart)
+  const unsigned hpl_off = (unsigned)(lane & 31) * 16u + (lane >= 32 ? (unsigned)((const char*)a.Al - (const char*)a.Ah) : 0u);
+  const unsigned gslot[2] = {(unsigned)(size_t)lds + (unsigned)(((NP - 2) & 1) * 2 * STAGE) + (unsigned)wave * 8192u,
+                             (unsigned)(size_t)lds + (unsigned)(((NP - 1) & 1) * 2 * STAGE) + (unsigned)wave * 8192u};
+  auto issue_rt = [&](int i, unsigned slot) __attribute__((always_inline)) {
+    const int rt = (m0 + wm * 16 * MT + i * 16) >> 4;
+    const char* gb = (const char*)(d.gi + (long)rt * d.gi_blk + (long)(jb >> 5) * 1536);
+    const char* hb = HPL ? nullptr : (const char*)(d.hprev_b + (long)rt * d.hp_blk + (long)(jb >> 4) * 256);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned dst = slot + (unsigned)k * 1024u;
+      if (HPL && k >= 6) {
+        // rows rt * 16 .. + 15 of the K-tile (jb + u * 16) / 16 of the state planes: 512 contiguous bytes of the hi plane (lanes 0..31) and of the lo plane (lanes 32..63)
+        const char* src = (const char*)(a.Ah + (long)((jb >> 4) + (k - 6)) * a.a_kst + (long)rt * 256);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(hpl_off), "s"(src), "s"(dst) : "m0", "memory");
+      } else {
+        const char* src = k < 6 ? gb + k * 1024 : hb + (k - 6) * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "m0", "memory");
+      }
+    }
+  };
+  f32x4q pre_b[6];
+  if constexpr (GIDMA) {
+    static_assert(!GIDMA || (MT == 4 && TEPOSE_G16_RT == 1), "four waves, one row tile per round");
+    // the recurrent biases of this lane's 2 x 4 units (r, z, n): six 16-byte loads issued HERE as asm, in front of the cell operands' requests --
+    // compiler-visible loads at the start of the cell update would be answered with vmcnt(0) at their first use (hipcc does not see the asm
+    // requests), draining every row tile in flight.  They are older than row tile 0's requests, so the wait of pair NP - 1 covers them.
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float* bp = d.bhh + (long)(k % 3) * Hp + jb + (k / 3) * 16 + 4 * g;            // k = u * 3 + gate
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre_b[k]) : "v"(bp) : "memory");
+    }
+    pairstep(NP - 2, F_{}, I1{}, I6{});                    // (the six bias loads are younger than pair NP - 1's requests)
+    issue_rt(0, gslot[0]);
+    pairstep(NP - 1, F_{}, I0{}, I8{});                    // pair NP - 1 AND the bias loads have landed; the 8 younger requests (row tile 0) may still be in flight
+    issue_rt(1, gslot[1]);
+    asm volatile("" : "+v"(pre_b[0]), "+v"(pre_b[1]), "+v"(pre_b[2]), "+v"(pre_b[3]), "+v"(pre_b[4]), "+v"(pre_b[5]));   // defined from here on (no use may move above the wait)
+  } else {
+    pairstep(NP - 2, F_{}, I1{}, I0{});
+    pairstep(NP - 1, F_{}, I0{}, I0{});
+  }
 
   G16_STAMP(2);
 #if TEPOSE_G16_PRIO
@@ -557,12 +611,16 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
 #endif
   // row tile outermost, the two unit tiles of a row together: lanes g = 0..3 of a row cover 64 bytes per unit tile, and the two unit tiles are the
   // two halves of ONE 128-byte line of every operand -- requested back to back instead of one whole gate-math pass apart
-  {
+  // (a generic lambda: the LDS-DMA-fed form (TEPOSE_G16_GIDMA) is its own instantiation, chosen by ONE branch -- a flag tested per row tile let hipcc
+  // issue the other path's loads first and put vmcnt(0) in front of the LDS reads)
+  auto cell_update = [&](auto lds_tag) __attribute__((always_inline)) {
+    constexpr bool FROM_LDS = decltype(lds_tag)::value;
     f32x4q br[2], bz[2], bn[2];
     int jj[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       jj[u] = min(jb + u * 16 + 4 * g, Hp - 4);
+      if constexpr (FROM_LDS) { br[u] = pre_b[u * 3]; bz[u] = pre_b[u * 3 + 1]; bn[u] = pre_b[u * 3 + 2]; continue; }
 #pragma unroll
       for (int c = 0; c < 4; ++c) { br[u][c] = d.bhh[jj[u] + c]; bz[u][c] = d.bhh[Hp + jj[u] + c]; bn[u][c] = d.bhh[2 * Hp + jj[u] + c]; }
     }
@@ -572,8 +630,50 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
 #pragma unroll
     for (int i0 = 0; i0 < MT; i0 += RT) {
       f32x4q gr[RT][2], gz[RT][2], gn[RT][2], hp[RT][2];
+      if constexpr (FROM_LDS) {
+        // vector-memory operations of this wave in issue order: rt0 rt1 | rt2 st0 | rt3 st1 | st2 | st3   (rt = 8 requests, st = 6 stores)
+        if (HPL && d.ho_blk) {      // (st = 4: the fp32 copy of a state that only the next step reads is not written)
+          if (i0 == 0) wait_vmq<8>(); else if (i0 == 1) wait_vmq<12>(); else if (i0 == 2) wait_vmq<16>(); else wait_vmq<8>();
+        } else {
+          if (i0 == 0) wait_vmq<8>(); else if (i0 == 1) wait_vmq<14>(); else if (i0 == 2) wait_vmq<20>(); else wait_vmq<12>();
+        }
+        const unsigned sl = gslot[i0 & 1] + lane16;
+        asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(gr[0][0]) : "v"(sl));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(gz[0][0]) : "v"(sl));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(gn[0][0]) : "v"(sl));
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(gr[0][1]) : "v"(sl));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(gz[0][1]) : "v"(sl));
+        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(gn[0][1]) : "v"(sl));
+        if constexpr (HPL) {
+          // this lane's 4 units of row t: 8 bytes of the hi block and 8 of the lo block (plane16_index: 32 bytes per row, the two 16-byte slots swizzled by row bit 3)
+          typedef _Float16 h16x4r __attribute__((ext_vector_type(4)));
+          const unsigned sp = gslot[i0 & 1] + (unsigned)t * 32u + (unsigned)((((g >> 1) ^ (t >> 3)) & 1) * 16 + (g & 1) * 8);
+          h16x4r qh[2], ql[2];
+          asm volatile("ds_read_b64 %0, %1 offset:6144" : "=v"(qh[0]) : "v"(sp));
+          asm volatile("ds_read_b64 %0, %1 offset:6656" : "=v"(ql[0]) : "v"(sp));
+          asm volatile("ds_read_b64 %0, %1 offset:7168" : "=v"(qh[1]) : "v"(sp));
+          asm volatile("ds_read_b64 %0, %1 offset:7680" : "=v"(ql[1]) : "v"(sp));
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(gr[0][0]), "+v"(gz[0][0]), "+v"(gn[0][0]), "+v"(gr[0][1]), "+v"(gz[0][1]), "+v"(gn[0][1]), "+v"(qh[0]), "+v"(ql[0]), "+v"(qh[1]), "+v"(ql[1])
+                       :
+                       : "memory");
+          const float inv_ss = 1.f / batch.state_scale;
 #pragma unroll
-      for (int ii = 0; ii < RT; ++ii) {
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hp[0][u][c] = ((float)qh[u][c] + (float)ql[u][c]) * inv_ss;     // exact: 11 + 11 bits, power-of-two scale
+        } else {
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(hp[0][0]) : "v"(sl));
+        asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(hp[0][1]) : "v"(sl));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(gr[0][0]), "+v"(gz[0][0]), "+v"(gn[0][0]), "+v"(gr[0][1]), "+v"(gz[0][1]), "+v"(gn[0][1]), "+v"(hp[0][0]), "+v"(hp[0][1])
+                     :
+                     : "memory");
+        }
+        if (i0 + 2 < MT) issue_rt(i0 + 2, gslot[i0 & 1]);  // this buffer has been read: the row tile after next goes into it
+      }
+#pragma unroll
+      for (int ii = 0; ii < (FROM_LDS ? 0 : RT); ++ii) {
         const int row = min(m0 + wm * 16 * MT + (i0 + ii) * 16 + t, a.M - 1);
         const int rtl = min(m0 + wm * 16 * MT + (i0 + ii) * 16, a.M - 1) >> 4;      // this wave's row tile (clamped like the rows)
 #pragma unroll
@@ -653,7 +753,7 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
 #if TEPOSE_G16_ABL & 512
             *(f32x4q*)(d.hout + ((long)((blockIdx.x * 4 + wave) * MT + i) * 2 + u) * 256 + lane * 4) = v;     // timing only: contiguous 1 KB per instruction
 #else
-            if (d.ho_blk) *(f32x4q*)(d.hout_b + (long)(row >> 4) * d.ho_blk + ((jb + u * 16) >> 4) * 256 + lane * 4) = v;     // blocked state: one contiguous KB per instruction
+            if (d.ho_blk) { if constexpr (!HPL) *(f32x4q*)(d.hout_b + (long)(row >> 4) * d.ho_blk + ((jb + u * 16) >> 4) * 256 + lane * 4) = v; }     // blocked state: one contiguous KB per instruction
             else *(f32x4q*)ho = v;
 #endif
           } else {
@@ -674,7 +774,9 @@ __global__ void __launch_bounds__(128 * NWM, NWM == 2 ? 2 : 1) gru_h3s16_kernel(
       }
       G16_STAMP(5 + 3 * (i0 / RT));                                // math done, stores issued
     }
-  }
+  };
+  cell_update(std::integral_constant<bool, GIDMA>{});
+  (void)hpl_off;
 #if TEPOSE_S16_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G16_STAMP(15);
@@ -694,7 +796,30 @@ hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s) {
   const int tm = (b.p[0].M + 127) / 128, tj = (b.Hp + 63) / 64;
   // tile rows per XCD group (TEPOSE_GRU_GM): the 64 workgroups resident on an XCD cover GM row tiles x 64 / GM unit tiles of one direction
   static const int gm = [] { const char* e = getenv("TEPOSE_GRU_GM"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
-  if (b.p[0].shape16 == 2)                                 // TEPOSE_MFMA16 bit 4: four waves of 64 x 96
+  if (b.p[0].shape16 == 5 || b.p[0].shape16 == 6) {        // TEPOSE_MFMA16 bit 32 / 64 (A/B): cell operands through the LDS-DMA stream, where every tile qualifies
+    bool ok = b.p[0].M % 128 == 0 && b.Hp % 64 == 0;
+    for (int d = 0; d < b.n; ++d) {
+      const GateDir& g = b.gate[d];
+      ok = ok && g.gi_blk != 0 && g.hp_blk != 0 && g.hprev_b != nullptr &&
+           (((size_t)g.hout | (size_t)g.gi | (size_t)g.hprev | (size_t)g.hprev_b | (size_t)g.bhh) & 15) == 0 && (g.ldo & 3) == 0 && (g.ldgi & 3) == 0 && (g.ldh & 3) == 0;
+    }
+    if (ok && b.p[0].shape16 == 6) {
+      for (int d = 0; d < b.n; ++d) {
+        const long dist = (const char*)b.p[d].Al - (const char*)b.p[d].Ah;
+        ok = ok && dist > 0 && dist < (1l << 31);
+      }
+      if (ok) {
+        hipLaunchKernelGGL((gru_h3s16_kernel<0, 2, true, true>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj, gm);
+        return hipGetLastError();
+      }
+      // (falling back is consistent: the predicate depends on the batch size, the hidden size and the layouts only, so EVERY step launch of a forward
+      // takes the same decision -- the plain kernel below reads and writes the fp32 state copies)
+    } else if (ok) {
+      hipLaunchKernelGGL((gru_h3s16_kernel<0, 2, true>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj, gm);
+      return hipGetLastError();
+    }
+  }
+  if (b.p[0].shape16 == 2 || b.p[0].shape16 == 5 || b.p[0].shape16 == 6)          // TEPOSE_MFMA16 bit 4: four waves of 64 x 96
     hipLaunchKernelGGL((gru_h3s16_kernel<0, 2>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj, gm);
   else hipLaunchKernelGGL((gru_h3s16_kernel<0, 4>), dim3(tm * tj, b.n), dim3(512), 0, s, b, tm, tj, gm);
   return hipGetLastError();

@@ -76,7 +76,12 @@ def test_gemm_rejects_bad_arguments():
                                       (2, 1024, 2305, 3),
                                       # B * T >= 8192 AND B >= 640 AND B % 16 == 0: layer-0 gate pre-activations frame-major + 16 x 16-blocked (common.h gi_blk_offset),
                                       # layers >= 1 blocked whenever B >= 640; a ragged last 128-row tile (2064 = 16 * 128 + 16), three layers
-                                      (2, 128, 2048, 4), (3, 256, 2064, 4), (2, 64, 2320, 5)])
+                                      (2, 128, 2048, 4), (3, 256, 2064, 4), (2, 64, 2320, 5),
+                                      # B >= 640 AND B % 128 == 0, L >= 2 (round 5): the cell steps of layers >= 1 with the layer's input projection fused
+                                      # into the K loop (gru_fuse16_kernel: [x_t | h] against [W_ih | W_hh], no gate pre-activations in memory); two- and
+                                      # three-direction launches (3 layers: the middle layer runs all T steps of the rec forward direction too), Kx = Hp and 2 Hp,
+                                      # unit-tile counts 1 ... 16, T from 2 (one fused step) to 7
+                                      (2, 256, 1024, 6), (3, 128, 1280, 5), (2, 1024, 640, 4), (2, 64, 768, 7), (3, 192, 896, 3), (4, 64, 640, 3)])
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
     from oracle import tepose_ref as O
     model, state, _ = _model(L, H, 11, smpl_np)

@@ -23,9 +23,13 @@ __global__ void __launch_bounds__(256) touch_kernel(const char* base, long per_w
         const unsigned long long qa = (unsigned long long)q;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)qa), hi = __builtin_amdgcn_readfirstlane((unsigned)(qa >> 32));
         const unsigned long long qs = ((unsigned long long)hi << 32) | lo;
-        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v[u]) : "s"(qs) : "memory");
+        asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(v[u]) : "s"(qs) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // SMEM returns asynchronously: every destination must stay allocated until the wait (an asm output that looks dead is handed to
+      // another value at once -- the first version of this file faulted on a base pointer overwritten by a late s_load_dwordx16)
+#pragma unroll
+      for (int u = 0; u < U; ++u) asm volatile("" : "+s"(v[u]));
 #pragma unroll
       for (int u = 0; u < U; ++u) acc += v[u];
     } else if (MODE == 1) {
@@ -40,11 +44,13 @@ __global__ void __launch_bounds__(256) touch_kernel(const char* base, long per_w
         const unsigned long long qa = (unsigned long long)q;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)qa), hi = __builtin_amdgcn_readfirstlane((unsigned)(qa >> 32));
         const unsigned long long qs = ((unsigned long long)hi << 32) | lo;
-        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v[u]) : "s"(qs) : "memory");
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(v[u]) : "s"(qs) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc += v[u][0];
+      for (int u = 0; u < U; ++u) asm volatile("" : "+s"(v[u]));
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += v[u][0] + v[u][15];
     }
   }
   if (acc == 0x12345678u) sink[0] = acc;
