@@ -95,7 +95,10 @@ __global__ void __launch_bounds__(256, 2) gru_fuse16_kernel(FuseBatch batch, int
       hb[q] = sbase[q] + (long)SX * kst[q];
       hk[q] = kst[q];
     }
-    const int grow = isA ? m0 + lrow0 + lane / 2 : n0 + lrow0 + lane / 2;
+#ifndef TEPOSE_FZ_ABL
+#define TEPOSE_FZ_ABL 0    // timing-only (WRONG results): 1 every workgroup streams the A rows of row tile 0 (L2-hot), 2 the W rows of unit tile 0, 4 no cell update
+#endif
+    const int grow = isA ? ((TEPOSE_FZ_ABL & 1) ? 0 : m0) + lrow0 + lane / 2 : ((TEPOSE_FZ_ABL & 2) ? 0 : n0) + lrow0 + lane / 2;
     voff[q] = (unsigned)grow * RB + 16u * (lane & 1);
   }
   auto dma_part = [&](int stage, int q) __attribute__((always_inline)) {
@@ -223,6 +226,10 @@ __global__ void __launch_bounds__(256, 2) gru_fuse16_kernel(FuseBatch batch, int
   pairstep(NP - 1, F_{}, I0{}, I9{});                      // pair NP - 1 has landed; the 9 younger requests may still be in flight
   wait_vmf<0>();                                           // (they were issued one and a half pair steps ago and are L2 hits)
 
+#if TEPOSE_FZ_ABL & 4
+  if (acc[0][0][0] == 12345.678f) d.hout_hi[0] = (_Float16)(acc[1][1][1] + acc[2][2][2] + acc[3][3][3] + acc[0][5][0] + acc[3][4][1] + ni[0][0][0] + ni[3][1][2]);
+  if (true) return;
+#endif
   // ---- cell update: lane (t, g) holds, for row tile i and unit tile u, row m0 + wm * 64 + i * 16 + t and the hidden units jb + u * 16 + 4 g .. + 3
   const float inv = d.inv_scale, inv_ss = 1.f / batch.state_scale;
 #pragma unroll
