@@ -69,6 +69,13 @@ void tepose_destroy(tepose_model* m);
  * (profiles/rNN_traffic_*.json) describes the running binary only if it names the same symbols; bench.py marks it stale
  * otherwise.  The string lives as long as the handle.                                                                    */
 const char* tepose_kernel_info(const tepose_model* m);
+/* The whole kernel selection of an eval forward of B windows x T frames on this handle, family by family ("input=...;projection=...;gi0_layout=...;
+ * gru_step=...;gru_first=...;projection_l1=...;gi1_layout=...;tail_regressor=...;smpl=..."), as the launch code itself decides it (csrc/api.hip
+ * select_kernels: the ONE place where batch classes are told apart).  A pure host function of the handle's knobs (environment at creation: TEPOSE_EXACT_FP32,
+ * TEPOSE_LARGE_BATCH_KERNELS=scaled|twoacc, TEPOSE_GRU_STATE=planes|fp32, TEPOSE_S_MIN_B, ...), L, hidden, B, T -- no device needed (the persistent
+ * small-batch kernels plan with the device's CU count, or TEPOSE_ASSUME_CUS where none is visible).  The string belongs to the calling thread and is
+ * valid until its next call.                                                                                                  */
+const char* tepose_select_kernels(const tepose_model* m, int B, int T);
 
 /* Bytes of the single device blob that holds every packed constant of the model
  * (encoder + regressor + SMPL tables).  The caller allocates it; it is what gets

@@ -20,11 +20,8 @@ struct DirW {                     // one GRU layer/direction inside the blob (fl
   size_t whh = 0, bhh = 0;
   size_t wih_p = 0, whh_p = 0;    // blocked hi|lo fp16 planes of the same matrices (whh: gate-tiled rows), float offsets
   size_t wih_s = 0, whh_s = 0;    // the same as scaled [K/16][R][16] planes (gemm_h3s.hip; rows padded to 256 / 384)
-  size_t scales = 0;              // blob slot: [0] = W_ih scale, [1] = W_hh scale, [2] = scale of the concatenated [W_ih | W_hh] planes
+  size_t scales = 0;              // blob slot: [0] = W_ih scale, [1] = W_hh scale
   float wih_scale = 1.f, whh_scale = 1.f;   // host copies
-  size_t wcat_s = 0;              // layers >= 1: scaled planes of [W_ih | W_hh] ([K/16][384-padded gate-tiled rows][16], one scale; gru_fuse16.hip)
-  size_t bias4 = 0;               // layers >= 1: [4][Hp] = b_ir + b_hr | b_iz + b_hz | b_in | b_hn
-  float wcat_scale = 1.f;
 };
 
 struct SmplOff {
@@ -50,14 +47,13 @@ struct tepose_model {
   size_t wih0_p = 0;                            // its hi|lo planes
   size_t wih0_s = 0, wih0_scale = 0;            // the same block as scaled [K/16][R][16] planes (gemm_h3s.hip) + its scale
   float w0_scale = 1.f;                         // host copy of blob[wih0_scale]
-  bool g0_single_acc = true;                    // large batches: layer-0 projection on the single-accumulator kernel
-  bool gru_single_acc = true;                   // large batches: layer >= 1 projections and GRU steps on it too
-  std::string kinfo;                            // tepose_kernel_info(): the kernel symbols the knobs select for the dominant launches
-  int mfma16 = 13;                              // TEPOSE_MFMA16 bit mask, kernels on v_mfma_f32_16x16x32_f16 instead of 32x32x16: 1 = plain
-                                                // scaled-plane products (gemm_h3s16.hip: -3 % on the projections, the chip holds 1.88 instead
-                                                // of 1.66 GHz); 8 = ... in their barrier-free form (gemm_h3s16c.hip: another -6 %);
-                                                // 2 = fused GRU step as eight waves of 32 x 96 (neutral); 4 = fused GRU step as four
-                                                // waves of 64 x 96 with streamed W fragments (-4 %).  Default 13 = 1 + 4 + 8
+  // kernel-family knobs (named options, read once per handle; defaults = the measured best):
+  bool large_scaled = true;                     // TEPOSE_LARGE_BATCH_KERNELS=scaled|twoacc: large batches (layer-0 projection from B * T >= 8192 / mid tiles from 512 rows,
+                                                // recurrent path from s_min_b windows) on the scaled-plane single-accumulator kernels (gemm_h3s16c.hip, gru_step16.hip,
+                                                // gemm_h3s.hip) -- or, `twoacc`, on the two-accumulator family of gemm_h3.hip at every batch size
+  bool state_planes = true;                     // TEPOSE_GRU_STATE=planes|fp32: the large-batch step kernel rebuilds h_{t-1} from the state planes and takes its cell
+                                                // operands through the LDS-DMA stream (gru_step16_kernel<true>) -- or, `fp32`, keeps a separate fp32 state copy (<false>)
+  std::string kinfo;                            // tepose_kernel_info(): the kernel symbols the knobs select for the dominant launches of cfg-C
   std::vector<DirW> fwd, rec_f, rec_r;          // per layer
   size_t wlf = 0, blf = 0, wlr = 0, blr = 0;
   size_t wlf_p = 0, wlr_p = 0;                  // blocked hi|lo planes of the tail linears
@@ -86,7 +82,6 @@ struct tepose_model {
   bool persist = true;                          // false: step-per-launch kernels at every batch size (tepose_set_persistent)
   unsigned spin_limit = 1u << 21;               // polls (~1 us each) before a wait gives up
   int blend16_min_n = 512;                      // TEPOSE_BLEND16_MIN_N: rows from which the blend-shape product runs on gemm_h3s_persist16c_kernel (0x7fffffff = never)
-  int fuse_l1 = 1;                              // TEPOSE_FUSE_L1: large batches run the cell steps of layers >= 1 with the layer's input projection fused into the K loop (gru_fuse16.hip)
   int gi_blk = 1;                               // TEPOSE_GI_BLK: large batches keep the layer >= 1 gate pre-activations in the 16 x 16-blocked layout (common.h gi_blk_offset)
   unsigned test_fault = 0;                      // TEPOSE_TEST_FAULT: bit 0 recurrent kernel, bit 1 regressor kernel wait for arrivals that never come
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
@@ -184,13 +179,6 @@ void layout(tepose_model* m) {
   m->wlf_p = take(cur, (size_t)kFeat * Hp);
   m->wlr_p = take(cur, (size_t)kFeat * 2 * Hp);
   m->wlfr_p = take(cur, (size_t)kFeat * 3 * Hp);
-  for (size_t l = 1; l < L; ++l) {      // fused input projection + recurrent step (gru_fuse16.hip): planes of [W_ih | W_hh], combined biases
-    const size_t r384 = round_up(3 * (int)Hp, 384);
-    m->fwd[l].wcat_s = take(cur, r384 * 2 * Hp);
-    m->rec_f[l].wcat_s = take(cur, r384 * 3 * Hp);
-    m->rec_r[l].wcat_s = take(cur, r384 * 3 * Hp);
-    for (DirW* d : {&m->fwd[l], &m->rec_f[l], &m->rec_r[l]}) d->bias4 = take(cur, 4 * Hp);
-  }
   layout_tail(m, cur);
 }
 
@@ -322,38 +310,6 @@ int scaled_planes_of(const float* packed, int rows, int Kp, float* dst_planes, i
   if ((e = launch_split_planes16(packed, Kp, rows, Kp, Kp, (long)R, p, hi, hi + (size_t)R * Kp, s)) != hipSuccess)
     return (int)e;
   return (int)hipStreamSynchronize(s);    // *scale_host is read by the async copy above
-}
-
-// layers >= 1: scaled planes of the concatenated [W_ih | W_hh] with ONE scale (largest |w| of both * p in [2^13, 2^14)), rows in the gate-interleaved
-// tile order padded to 384 -- W_ih's packed fp32 copy is in the natural [gate][unit] row order (launch_split_planes16's tiled_hp mapping reorders it),
-// W_hh's is tiled already -- plus the combined bias rows.  Pack time only.
-int cat_planes_of(tepose_model* m, DirW* d, int Kin, hipStream_t s) {
-  float* B = m->blob;
-  const int Hp = m->Hp, r384 = round_up(3 * Hp, 384);
-  float* sc = B + d->scales + 2;
-  CK(launch_absmax(B + d->wih, (size_t)3 * Hp * Kin, sc, s));
-  CK(launch_absmax(B + d->whh, (size_t)3 * Hp * Hp, sc + 1, s));
-  float wm[2] = {0.f, 0.f};
-  CK(hipMemcpyAsync(wm, sc, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
-  CK(hipStreamSynchronize(s));
-  const float wmax = wm[0] > wm[1] ? wm[0] : wm[1];
-  float p = 1.f;
-  if (wmax > 0.f && wmax < 3e38f) {
-    int ex = 0;
-    (void)frexpf(wmax, &ex);
-    p = ldexpf(1.f, 14 - ex);
-  }
-  d->wcat_scale = p;
-  CK(hipMemcpyAsync(sc, &d->wcat_scale, sizeof(float), hipMemcpyHostToDevice, s));
-  const size_t K = (size_t)Kin + Hp;
-  CK(launch_fill(B + d->wcat_s, (size_t)r384 * K, 0.f, s));
-  half_t* hi = (half_t*)(B + d->wcat_s);
-  half_t* lo = hi + (size_t)r384 * K;
-  CK(launch_split_planes16(B + d->wih, Kin, 3 * Hp, Kin, Kin, (long)r384, p, hi, lo, s, Hp));
-  const size_t off = (size_t)(Kin / 16) * r384 * 16;
-  CK(launch_split_planes16(B + d->whh, Hp, 3 * Hp, Hp, Hp, (long)r384, p, hi + off, lo + off, s));
-  CK(launch_bias_cat(B + d->bih, B + d->bhh, B + d->bias4, Hp, s));
-  return (int)hipStreamSynchronize(s);    // d->wcat_scale is read by the async copy above
 }
 
 struct Carver {
@@ -499,8 +455,12 @@ struct RegWs {
   bool blend16 = false; half_t *pf16h = nullptr, *pf16l = nullptr; float* pfrs = nullptr;
 };
 
+// regressor / SMPL side of the kernel selection (select_kernels below computes the same two predicates for its description)
+inline bool reg_split_for(const tepose_model* m, int N) { return m->split && N > split_min_m(); }
+inline bool blend16_for(const tepose_model* m, int N) { return reg_split_for(m, N) && m->large_scaled && N >= m->blend16_min_n; }
+
 void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
-  w.split = m->split && N > split_min_m();
+  w.split = reg_split_for(m, N);
   w.split_fc = w.split;            // h3_mm picks the width-first kernel for <= 768 rows, 256-row tiles above
   w.sync = (unsigned*)c.f(sync_words(m));
   w.featP = carve_planes(c, N, kFeat, w.split_fc);
@@ -516,7 +476,7 @@ void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
   w.amat = c.f((size_t)N * kNJ * 12);
   w.posed = c.f((size_t)N * kNJ * 3);
   w.vposed = c.f((size_t)N * kVertLd);
-  w.blend16 = w.split && N >= m->blend16_min_n && (m->mfma16 & 9) == 9 && gemm_h3s_blocked_ok();
+  w.blend16 = blend16_for(m, N);
   if (w.blend16) {
     w.pf16h = (half_t*)c.f((size_t)N * kBlendK / 2);
     w.pf16l = (half_t*)c.f((size_t)N * kBlendK / 2);
@@ -569,7 +529,6 @@ int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
     const half_t* sh = (const half_t*)(Bl + m->blendW_s);
     H3SArgs a{w.pf16h, w.pf16l, (long)N * 16, sh, sh + (size_t)kBlendN * kBlendK, (long)kBlendN * 16, kBlendK, w.vposed, (long)kVertLd,
               nullptr, 1.f / m->blend_sc, N, 3 * kNV, w.pfrs};
-    a.shape16 = 3;
     if (w.sync) a.status = sync_reg_status(m, w.sync);
     a.fault = m->fault;
     return (int)launch_gemm_h3s(a, s, 1);
@@ -584,17 +543,121 @@ int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
 
 }  // namespace
 
+// ---- fault channel of the persistent kernels: the two tests every entry point and the kernel selection use
+static inline bool fault_pending(const tepose_model* m) {
+  return m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) != 0u;
+}
+static inline bool persist_on(const tepose_model* m) {
+  return __atomic_load_n(&m->persist, __ATOMIC_RELAXED) && m->fault != nullptr;   // (tepose_set_persistent may run on another thread)
+}
+
+namespace {
+
+// ---- kernel selection: EVERY batch-class decision of a forward in one place ------------------------------------------------------------
+// (the predicates used to be spread over encoder_fwd_impl / encoder_core / carve_regressor as conjunctions of knob bits.)
+// Pure host function of (handle knobs, L, Hp, B, T): no device call, so tests/test_dispatch.py pins every class boundary on a machine without a GPU
+// (tepose_select_kernels).  The launch code below consumes these fields; nothing else decides a kernel family.
+struct KernelPlan {
+  bool h3 = false;            // split-precision kernels (split-mode handle, B > TEPOSE_SPLIT_MIN_M); else the exact-fp32 kernels of gemm.hip / skinny.hip
+  bool scaled = false;        // large batch: recurrent-state planes in the scaled format, layer >= 1 projections and cell steps on the scaled-plane kernels
+  bool gblk = false;          // ... with the layer >= 1 gate pre-activations and the fp32 states between steps in the 16 x 16-blocked layout
+  bool planes_state = false;  // ... and the step kernel's PLANES instantiation (every tile full: B % 128 == 0)
+  bool g0big = false, g0mid = false, g0blk = false, g0skinny = false;     // layer-0 projection class
+  bool seq2 = false, seq3 = false;   // the persistent recurrent kernel serves 2- / 3-direction layers of this (B, T)
+  bool step_skinny = false;   // (not scaled, not seq) width-first step kernel
+  bool reg_split = false, reg_seq = false, blend16 = false;   // regressor / SMPL side at N = B persons (1 - 4 persons: smpl_small_kernel, decided by smpl_small_ok at launch)
+};
+
+KernelPlan select_kernels(const tepose_model* m, int B, int T, bool assume_ready = false) {
+  KernelPlan k;
+  const int L = m->L, Hp = m->Hp;
+  const long BT = (long)B * T;
+  k.h3 = m->split && B > split_min_m();
+  k.scaled = k.h3 && m->large_scaled && B >= m->s_min_b;
+  k.gblk = k.scaled && m->gi_blk && Hp % 32 == 0;
+  k.planes_state = k.gblk && m->state_planes && B % 128 == 0;
+  // layer-0 projection
+  k.g0big = k.h3 && m->large_scaled && L >= 2 && BT >= 8192;
+  static const int g0mid_min = [] { const char* e = getenv("TEPOSE_G0_MID_MIN_ROWS"); return e ? atoi(e) : 512; }();
+  k.g0mid = k.h3 && m->large_scaled && L >= 2 && !k.g0big && BT >= g0mid_min && BT > 128 && (9 * Hp) % 288 == 0;
+  if (k.g0mid) {   // whichever tile shape needs less time in whole rounds of the 256 CUs (a 128 x 288 tile takes ~2.1x a 128 x 128 one)
+    const long rt = (BT + 127) / 128;
+    const long r_mid = (rt * (9 * Hp / 288) + 255) / 256, r_old = (rt * ((9 * Hp + 127) / 128) + 255) / 256;
+    k.g0mid = 2.1 * (double)r_mid <= (double)r_old + 0.15;
+  }
+  // frame-major + blocked layer-0 gate pre-activations: the same condition as gblk, plus whole row tiles per frame
+  k.g0blk = k.g0big && k.gblk && B % 16 == 0;
+  static const int g0_skinny_max = [] { const char* e = getenv("TEPOSE_G0_SKINNY_MAX_M"); return e ? atoi(e) : 128; }();
+  k.g0skinny = k.h3 && !k.g0big && !k.g0mid && BT <= g0_skinny_max;
+  // recurrent part of small batches
+  const bool persist = assume_ready ? m->persist : persist_on(m);
+  const bool seq_ok = k.h3 && !k.scaled && persist;
+  k.seq3 = seq_ok && gru_seq_ok(3, B, Hp, T);
+  k.seq2 = seq_ok && gru_seq_ok(2, B, Hp, T);
+  k.step_skinny = k.h3 && !k.scaled && B <= skinny_h3_max_m();
+  // regressor / SMPL
+  k.reg_split = reg_split_for(m, B);
+  k.reg_seq = k.reg_split && B <= reg_seq_max_n() && persist;
+  k.blend16 = blend16_for(m, B);
+  return k;
+}
+
+// the kernel symbols (as a rocprofv3 trace names them) a default eval forward of B windows x T frames launches, family by family
+std::string describe_plan(const tepose_model* m, int B, int T) {
+  const KernelPlan k = select_kernels(m, B, T, true);
+  const int L = m->L;
+  const long BT = (long)B * T;
+  std::string s = "input=";
+  s += !k.h3 ? "pad_input_kernel" : BT <= 64 ? "split_rows_few_kernel" : "split_rows_kernel";
+  s += ";projection=";
+  s += !k.h3 ? (BT <= skinny_max_m() ? "skinny_gemm_kernel" : "gemm_f32_kernel")
+       : k.g0big ? "gemm_h3s_persist16c_kernel<0>" : k.g0mid ? "gemm_h3s_kernel<1, 3, 4, 3, 4>" : k.g0skinny ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel";
+  s += std::string(";gi0_layout=") + (k.g0blk ? "frame_major_blocked" : "row_major");
+  const bool seq_l0 = L == 1 ? k.seq2 : k.seq3;
+  s += ";gru_step=";
+  s += !k.h3 ? (B <= skinny_max_m() ? "skinny_gru_kernel" : "gru_step_kernel")
+       : k.scaled ? (k.planes_state ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>")
+       : seq_l0 ? (B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024 ? "gru_seq_kernel(granules)" : "gru_seq_kernel")
+       : k.step_skinny ? "skinny_gru_h3_kernel" : "gemm_h3_kernel<GRU>";
+  s += ";gru_first=";
+  s += !k.h3 ? "gru_step_kernel" : (seq_l0 ? "(in gru_seq_kernel)" : (k.scaled && m->Hp % 128 == 0 ? "gru_first16_kernel" : "gru_first_kernel"));
+  if (L >= 2) {
+    s += ";projection_l1=";
+    s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= skinny_max_m() ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
+    s += std::string(";gi1_layout=") + (k.gblk ? "blocked" : "row_major");
+  }
+  s += ";tail_regressor=";
+  s += !k.reg_split ? "gemm_f32_kernel x (2 + 1 + 9)" : (m->tail_collapsed || !m->enc_packed) && m->collapse_env ? "collapsed: one product (skinny_gemm_h3_kernel / gemm_h3_kernel)"
+       : k.reg_seq ? "reg_seq_kernel" : "gemm_h3_kernel loop";
+  s += ";smpl=";
+  s += B <= 4 ? "smpl_small_kernel" : k.blend16 ? "smpl_prep_kernel+gemm_h3s_persist16c_kernel<1>+smpl_skin4_kernel" : k.reg_split ? "smpl_prep_kernel+gemm_h3_kernel+smpl_skin4_kernel"
+       : "smpl_prep_kernel+gemm_f32_kernel+smpl_skin4_kernel";
+  return s;
+}
+
+void refresh_kernel_info(tepose_model* m) {
+  // the symbols a rocprofv3 kernel trace of cfg-C (B = 8192, T = 16) lists for the two dominant launch families -- what a committed profile must
+  // name to describe THIS binary with THESE knobs (bench.py checks)
+  const std::string d = describe_plan(m, 8192, 16);
+  auto field = [&](const char* key) {
+    const std::string kk = std::string(key) + "=";
+    const size_t i = d.find(kk);
+    if (i == std::string::npos) return std::string("?");
+    const size_t j = d.find(';', i);
+    return d.substr(i + kk.size(), j == std::string::npos ? std::string::npos : j - i - kk.size());
+  };
+  m->kinfo = "projection=" + field("projection") + ";gru_step=" + field("gru_step");
+}
+}  // namespace
+
 // numerics / dispatch knobs, read once per handle at creation (both model kinds)
 static void read_env_knobs(tepose_model* m) {
-  h3s16c_warm();
   const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
   m->split = m->split_env = !(e && atoi(e) != 0);
-  e = getenv("TEPOSE_G0_SINGLE_ACC");               // 0: layer-0 projection on the two-accumulator kernel (A/B)
-  m->g0_single_acc = !(e && atoi(e) == 0);
-  e = getenv("TEPOSE_GRU_SINGLE_ACC");              // 0: recurrent path of large batches on the two-accumulator kernels
-  m->gru_single_acc = !(e && atoi(e) == 0);
-  e = getenv("TEPOSE_MFMA16");                      // MFMA shape of the scaled-plane kernels (bit 1: plain products, bit 2: GRU step)
-  m->mfma16 = e ? atoi(e) : 13;
+  e = getenv("TEPOSE_LARGE_BATCH_KERNELS");         // scaled (default) | twoacc
+  m->large_scaled = !(e && std::string(e) == "twoacc");
+  e = getenv("TEPOSE_GRU_STATE");                   // planes (default) | fp32
+  m->state_planes = !(e && std::string(e) == "fp32");
   e = getenv("TEPOSE_COLLAPSE_REGRESSOR");          // 0: the regressor's FC loop is always run as a loop
   m->collapse_env = !(e && atoi(e) == 0);
   e = getenv("TEPOSE_S_MIN_B");                     // batch threshold of the scaled-format recurrent path
@@ -610,23 +673,7 @@ static void read_env_knobs(tepose_model* m) {
   m->blend16_min_n = e ? atoi(e) : 512;
   e = getenv("TEPOSE_GI_BLK");
   m->gi_blk = e ? atoi(e) : 1;
-  e = getenv("TEPOSE_FUSE_L1");
-  m->fuse_l1 = e ? atoi(e) : 1;
-  // the symbols a rocprofv3 kernel trace of a large-batch forward (B >= s_min_b, B * T >= 8192) lists for the two dominant
-  // launch families -- what a committed profile must name to describe THIS binary with THESE knobs (bench.py checks)
-  const char* h3sp = getenv("TEPOSE_H3S_PERSIST");
-  const bool persist_plain = !(h3sp && atoi(h3sp) == 0);
-  m->kinfo = std::string("projection=") +
-             (!m->split ? "gemm_f32_kernel"
-              : !m->g0_single_acc ? "gemm_h3_kernel"
-              : !persist_plain ? "gemm_h3s_kernel"
-              : (m->mfma16 & 8) ? "gemm_h3s_persist16c_kernel<0>"
-              : (m->mfma16 & 1) ? "gemm_h3s_persist16_kernel<0>" : "gemm_h3s_persist_kernel<0>") +
-             ";gru_step=" +
-             (!m->split ? "gru_step_kernel"
-              : !m->gru_single_acc ? "gemm_h3_kernel"
-              : (m->mfma16 & 16) ? "gru_h3s16c_kernel<0>" : (m->mfma16 & 4) ? "gru_h3s16_kernel<0, 2>" : (m->mfma16 & 2) ? "gru_h3s16_kernel<0, 4>"
-              : "gemm_h3s_kernel<1, 3, 4, 2, true, 4>");
+  refresh_kernel_info(m);
 }
 
 namespace {
@@ -719,6 +766,13 @@ const char* tepose_build_info(void) {
 
 const char* tepose_kernel_info(const tepose_model* m) { return m ? m->kinfo.c_str() : ""; }
 
+const char* tepose_select_kernels(const tepose_model* m, int B, int T) {
+  static thread_local std::string buf;
+  if (!m || B < 1 || T < 1) return "";
+  buf = describe_plan(m, B, T);
+  return buf.c_str();
+}
+
 const char* tepose_error_string(int code) {
   switch (code) {
     case 0: return "ok";
@@ -759,6 +813,7 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
   if (!m || !blob) return TEPOSE_E_ARG;
   if (bytes < m->blob_floats * sizeof(float)) return TEPOSE_E_WORKSPACE;
   m->blob = (float*)blob;
+  h3s16c_warm();                                 // the blob's device is current (callers run under it): its debug counter of the barrier-free kernels
   if (!m->fault) {                               // first blob = first moment a device is certain to exist
     unsigned* f = nullptr;
     if (hipHostMalloc((void**)&f, 64, hipHostMallocDefault) == hipSuccess && f) { *f = 0u; m->fault = f; }
@@ -768,12 +823,6 @@ int tepose_set_blob(tepose_model* m, void* blob, size_t bytes) {
 }
 
 // ---- fault channel of the persistent kernels ------------------------------------------------------------------
-static inline bool fault_pending(const tepose_model* m) {
-  return m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) != 0u;
-}
-static inline bool persist_on(const tepose_model* m) {
-  return __atomic_load_n(&m->persist, __ATOMIC_RELAXED) && m->fault != nullptr;   // (tepose_set_persistent may run on another thread)
-}
 
 int tepose_status_peek(const tepose_model* m) {
   if (!m) return TEPOSE_E_ARG;
@@ -944,7 +993,6 @@ int tepose_derive_planes(tepose_model* m, void* stream) {
         CK((hipError_t)planes_rows(d->whh, 3 * Hp, Hp, d->whh_p, n128));
         CK((hipError_t)scaled_planes_of(B + d->whh, 3 * Hp, Hp, B + d->whh_s, round_up(3 * Hp, 384), B + d->scales + 1,
                                         &d->whh_scale, s));
-        if (l > 0) CK((hipError_t)cat_planes_of(m, d, Kp, s));
       }
     }
     CK((hipError_t)planes_of(B + m->wlf, kFeat, Hp, B + m->wlf_p, s));
@@ -1118,7 +1166,6 @@ int tepose_pack_encoder(tepose_model* m, const float* const* w, int n_w, void* s
       }
       CK((hipError_t)scaled_planes_of(B + d.d->whh, 3 * Hp, Hp, B + d.d->whh_s, round_up(3 * Hp, 384),
                                       B + d.d->scales + 1, &d.d->whh_scale, s));
-      if (l > 0) CK((hipError_t)cat_planes_of(m, d.d, d.split ? 2 * Hp : Hp, s));
     }
   }
   const float* const* t = w + 12 * L;
@@ -1296,19 +1343,16 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   const float* Bl = m->blob;
   const long BT = (long)B * T;
   const int H3 = 3 * Hp;
-  const bool h3 = m->split && B > split_min_m();
+  const KernelPlan plan = select_kernels(m, B, T);     // every batch-class decision (see select_kernels)
+  const bool h3 = plan.h3;
   const long Bs = (long)w.Bs;          // rows per time slab of the layer >= 1 buffers
-  // large batches: recurrent-state planes in the scaled format, layer >= 1 projections and GRU steps on the
-  // single-accumulator kernels (gemm_h3s.hip)
-  const bool sf = h3 && m->gru_single_acc && B >= m->s_min_b;
+  // large batches: recurrent-state planes in the scaled format, layer >= 1 projections and GRU steps on the scaled-plane kernels
+  const bool sf = plan.scaled;
   const size_t n128 = (size_t)round_up(H3, 128);
   // layer >= 1 gate pre-activations in the blocked layout (common.h gi_blk_offset): producer = the barrier-free projection kernel, consumers =
-  // gru_h3s16_kernel / gru_first16_kernel / gru_first_kernel -- only with the default kernel selection (any other knob keeps [rows][3 Hp])
-  const bool gblk = sf && m->gi_blk && (m->mfma16 & 9) == 9 && (m->mfma16 & 6) && !(m->mfma16 & 16) && Hp % 32 == 0 && gemm_h3s_blocked_ok();
+  // gru_step16_kernel / gru_first16_kernel / gru_first_kernel
+  const bool gblk = plan.gblk;
   if (src.blk && !gblk) return (int)hipErrorInvalidValue;   // the caller projected layer 0 into the blocked layout: every consumer here must read it
-  // layers >= 1 of large batches: the cell steps run over [x_t | h_{t-1}] against the planes of [W_ih | W_hh] (gru_fuse16.hip) -- no gate pre-activations in
-  // memory, no projection launches except one slab per direction for the first step (h = 0: element-wise kernel)
-  const bool fuse = sf && m->fuse_l1 && L >= 2 && T >= 2 && B % 128 == 0 && (m->mfma16 & 4) && !(m->mfma16 & 16);
   // input projection of a layer >= 1: fp32 kernel, or split kernel on the hi/lo mirrors of the input states
   auto proj = [&](const float* in, int K, size_t w_f32, size_t w_planes, size_t w_s, float w_scale, size_t bias,
                   float* out, int M) -> int {
@@ -1323,7 +1367,6 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       const half_t* sh = (const half_t*)(Bl + w_s);
       H3SArgs a{v.hi, v.lo, v.kst, sh, sh + r256 * K, (long)r256 * 16, K, out, (long)H3, Bl + bias,
                 1.f / (kStateScale * w_scale), M, H3};
-      a.shape16 = (m->mfma16 & 8) ? 3 : (m->mfma16 & 1);
       if (w.sync) a.status = sync_gru_status(m, w.sync);
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
@@ -1359,7 +1402,6 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           const half_t* sh = (const half_t*)(Bl + dw[d]->whh_s);
           b.p[d] = H3SArgs{vi.hi, vi.lo, vi.kst, sh, sh + r384 * Hp, (long)r384 * 16, Hp, nullptr, 0, nullptr,
                            1.f / (kStateScale * dw[d]->whh_scale), B, H3};
-          b.p[d].shape16 = (m->mfma16 & 16) ? 4 : (m->mfma16 & 64) ? 6 : (m->mfma16 & 32) ? 5 : (m->mfma16 & 4) ? 2 : ((m->mfma16 >> 1) & 1);      // 2: the four-wave form of the 16x16x32 step, 4: persistent barrier-free, 5: four waves + cell operands by LDS-DMA
           if (w.sync) b.p[d].status = sync_gru_status(m, w.sync);
           b.p[d].fault = m->fault;
           b.p[d].inject = (m->test_fault >> 2) & 1u;
@@ -1367,7 +1409,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       }
       if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s, 1);
       b.n = a.ndir; b.Hp = Hp; b.state_scale = kStateScale;
-      return (int)launch_gru_h3s(b, s);
+      return (int)launch_gru_step16(b, s, plan.planes_state);
     }
     H3Batch b{};
     GateBatch gb{};
@@ -1387,7 +1429,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
     }
     if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s);
     b.n = a.ndir; b.Hp = Hp;
-    if (B <= skinny_h3_max_m()) return (int)launch_skinny_gru_h3(b, s);
+    if (plan.step_skinny) return (int)launch_skinny_gru_h3(b, s);
     return (int)launch_gru_h3(b, s);
   };
   auto gi0 = [&](int t, int dir, const float*& p, long& ld) {
@@ -1400,7 +1442,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
   // by a memset node in front of the first launch of every forward
   const bool scaled_fmt = sf;         // (the layer loop below reuses the name `sf` for a state buffer)
   bool tail_planes_done = false;      // the persistent kernel of the top layer wrote relu(final states) as planes
-  const bool seq = h3 && !sf && w.sync && persist_on(m) && gru_seq_ok(L == 1 ? 2 : 3, B, Hp, T);
+  const bool seq = w.sync && (L == 1 ? plan.seq2 : plan.seq3);
   const size_t gran_bytes = seq_gran_words(m, B) * sizeof(float);
   // every forward clears its sync region -- arrival counters, granules, and the two STATUS words that tepose_forward_status
   // reads -- whether or not a persistent kernel will run (a stale or uninitialised status word would read as a give-up)
@@ -1452,14 +1494,6 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         }
         if (big.n) CK(launch_gemm_h3(big, s));
         if (sk.n) CK(launch_skinny_gemm_h3_batch(sk, s));
-      } else if (fuse) {
-        // only the slab each direction's FIRST step reads: fwd / rec forward frame 0 (flipped index 0), rec reverse flipped index T - 1
-        const int M1 = (int)Bs;
-        CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].wih_s, m->fwd[l].wih_scale, m->fwd[l].bih, w.gf, M1));
-        CK((hipError_t)proj(inr + (long)(T - 1) * Bs * 2 * Hp, 2 * Hp, m->rec_r[l].wih, m->rec_r[l].wih_p, m->rec_r[l].wih_s, m->rec_r[l].wih_scale,
-                            m->rec_r[l].bih, w.grr, M1));
-        CK((hipError_t)proj(inr, 2 * Hp, m->rec_f[l].wih, m->rec_f[l].wih_p, m->rec_f[l].wih_s, m->rec_f[l].wih_scale, m->rec_f[l].bih, w.grf,
-                            top ? B : M1));
       } else {
       CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].wih_s, m->fwd[l].wih_scale, m->fwd[l].bih,
                           w.gf, MT));
@@ -1472,11 +1506,10 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       ldg = H3;
     }
     // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
-    const bool fused_layer = fuse && l >= 1;
-    auto goff = [&](int q) -> long { return fused_layer ? 0 : (long)q * Bs * H3; };   // (a fused layer holds one slab of gate pre-activations per direction: its first step's)
+    auto goff = [&](int q) -> long { return (long)q * Bs * H3; };
 
     if (m->prof) { int rc = prof_mark(mm, s); if (rc) return rc; }
-    const bool use_seq = seq && gru_seq_ok(top ? 2 : 3, B, Hp, T);
+    const bool use_seq = seq && (top ? plan.seq2 : plan.seq3);
     GruSeqArgs sq{};
     for (int st = 0; st < T; ++st) {
       GruArgs a{};
@@ -1567,32 +1600,6 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         }
         continue;
       }
-      if (fused_layer && st > 0) {
-        // x_t of this step per direction: the previous layer's state slab (fwd: frame st; rec reverse: flipped index T - 1 - st; rec forward: flipped index st)
-        const float* xin[3] = {w.sf[(l - 1) & 1] + (long)st * Bs * Hp, w.sr[(l - 1) & 1] + (long)(T - 1 - st) * Bs * 2 * Hp,
-                               w.sr[(l - 1) & 1] + (long)st * Bs * 2 * Hp};
-        const int kx[3] = {Hp, 2 * Hp, 2 * Hp};
-        FuseBatch fb{};
-        const size_t r384 = (size_t)round_up(H3, 384);
-        for (int k = 0; k < nd; ++k) {
-          const EncWs::View vx = w.view16(xin[k]), vh = w.view16(a.d[k].hprev), vo = w.view16(a.d[k].hout);
-          if (!vx.hi || !vh.hi || !vo.hi) return (int)hipErrorInvalidValue;
-          FuseDir& f = fb.d[k];
-          f.Xh = vx.hi; f.Xl = vx.lo; f.x_kst = vx.kst;
-          f.Hh = vh.hi; f.Hl = vh.lo; f.h_kst = vh.kst;
-          const half_t* sh = (const half_t*)(Bl + dw[k]->wcat_s);
-          f.Wh = sh; f.Wl = sh + r384 * (size_t)(kx[k] + Hp); f.w_kst = (long)r384 * 16;
-          f.Kx = kx[k];
-          f.inv_scale = 1.f / (kStateScale * dw[k]->wcat_scale);
-          f.bias4 = Bl + dw[k]->bias4;
-          const bool fp32_out = top && st == T - 1;                 // the tail reads the top layer's last states as fp32 rows; every other state lives in its planes
-          f.hout = fp32_out ? a.d[k].hout : nullptr; f.ldo = a.d[k].ldo;
-          f.hout_hi = vo.hi; f.hout_lo = vo.lo; f.okst = vo.kst;
-        }
-        fb.n = nd; fb.M = B; fb.Hp = Hp; fb.state_scale = kStateScale;
-        CK(launch_gru_fuse16(fb, s));
-        continue;
-      }
       CK((hipError_t)step(a, wp, dw));
     }
     if (top && !use_seq) {  // forward direction of the top bi-GRU layer: one cell step from h = 0
@@ -1613,8 +1620,6 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       if (rc) return rc;
       // consumed cell steps of this layer: fwd T + rec_reverse T + rec forward (T, or 1 on the top layer)
       mm->prof_gru_flops += 2.0 * B * 3.0 * m->H * m->H * (2.0 * T + (top ? 1 : T));
-      // a fused layer's step launches also run the layer's input projection (fwd: K = H, the two rec directions: K = 2 H), T - 1 steps each
-      if (fused_layer) mm->prof_gru_flops += 2.0 * B * 3.0 * m->H * m->H * (T - 1.0) * (1.0 + 2.0 + (top ? 0.0 : 2.0));
     }
   }
   // ---- y_fwd = linear_fwd(relu(y[-1])), y_rec = linear_rec(relu(y_rec[0])) -------------------
@@ -1715,29 +1720,19 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
 
   // ---- layer-0 input projections: one GEMM for every direction that runs all T steps --------
   const int ld0 = (L >= 2 ? 9 : 6) * Hp;
-  const bool h3 = m->split && B > split_min_m();
+  const KernelPlan plan = select_kernels(m, B, T);     // every batch-class decision (see select_kernels)
+  const bool h3 = plan.h3;
   half_t* xh = (half_t*)w.xp;                       // hi / lo planes share the padded-input buffer
   half_t* xl = xh + (size_t)BT * kInputP;
   const size_t rows0 = (size_t)round_up(9 * Hp, 128);
   const half_t* w0h = (const half_t*)(Bl + m->wih0_p);
   const half_t* w0l = w0h + rows0 * kInputP;
-  // large batches of an L >= 2 model: the single-accumulator kernel (its input planes carry scale 1: same fp16 range
-  // as the other layout; elements below 2^-3 keep an absolute error <= 2^-25 instead of a relative one)
-  const bool g0big = h3 && m->g0_single_acc && L >= 2 && BT >= 8192;
-  // mid-size batches (cfg-B: 64 windows x 16 frames = 1024 rows): the same kernel with 128 x 288 tiles, which cut the 9 Hp
-  // columns into whole rounds of the chip; below ~512 rows the two-accumulator kernel's 128 x 128 tiles fill it better
-  static const int g0mid_min = [] { const char* e = getenv("TEPOSE_G0_MID_MIN_ROWS"); return e ? atoi(e) : 512; }();
-  bool g0mid = h3 && m->g0_single_acc && L >= 2 && !g0big && BT >= g0mid_min && BT > 128 && (9 * Hp) % 288 == 0;
-  if (g0mid) {   // whichever tile shape needs less time in whole rounds of the 256 CUs (a 128 x 288 tile takes ~2.1x a 128 x 128 one)
-    const long rt = (BT + 127) / 128;
-    const long r_mid = (rt * (9 * Hp / 288) + 255) / 256, r_old = (rt * ((9 * Hp + 127) / 128) + 255) / 256;
-    g0mid = 2.1 * (double)r_mid <= (double)r_old + 0.15;
-  }
+  // g0big: large batches of an L >= 2 model on the barrier-free scaled-plane kernel (its input planes carry scale 1: same fp16 range as the other
+  // layout; elements below 2^-3 keep an absolute error <= 2^-25 instead of a relative one).  g0mid: mid-size batches (cfg-B: 64 windows x 16 frames =
+  // 1024 rows) on 128 x 288 tiles, which cut the 9 Hp columns into whole rounds of the chip.  g0blk: gate pre-activations FRAME-major
+  // (plane row t * B + b: a GRU step then reads B consecutive rows) and 16 x 16-blocked (common.h gi_blk_offset).
+  const bool g0big = plan.g0big, g0mid = plan.g0mid, g0blk = plan.g0blk;
   const bool g0s = g0big || g0mid;
-  // large batches on the default kernels: layer-0 gate pre-activations FRAME-major (plane row t * B + b: a GRU step then reads B consecutive
-  // rows) and in the 16 x 16-blocked layout (common.h gi_blk_offset) -- the same condition as encoder_core's `gblk`, plus whole row tiles per frame
-  const bool g0blk = g0big && !g0mid && m->gru_single_acc && B >= m->s_min_b && m->gi_blk && (m->mfma16 & 9) == 9 && (m->mfma16 & 6) &&
-                     !(m->mfma16 & 16) && Hp % 32 == 0 && B % 16 == 0 && gemm_h3s_blocked_ok();
   // the caller's windows -> planes with one power-of-two scale per row (any finite fp32 magnitude; DESIGN 4b "range")
   // (with zero_sync the kernel also clears the forward's arrival counters / granules: it is the forward's first kernel)
   // (the forward's first kernel also clears its sync region -- arrival counters, granules, STATUS words -- so that a give-up of the
@@ -1764,7 +1759,6 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       const half_t* sh = (const half_t*)(Bl + m->wih0_s);
       H3SArgs a{xh, xl, BT * 16, sh, sh + rows256 * kInputP, (long)rows256 * 16, kInputP, w.g0, (long)ld0,
                 Bl + m->bih0, 1.f / m->w0_scale, (int)BT, ld0, w.rs};
-      a.shape16 = (m->mfma16 & 8) ? 3 : (m->mfma16 & 1);
       if (w.sync) a.status = sync_gru_status(m, w.sync);
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
@@ -1779,11 +1773,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       b.n = 1;
       // few rows (live stream, a handful of clips): the width-first kernel streams the 79 MB of W_ih planes with
       // N / 48 = 192 workgroups instead of 72 tiles of 128 rows
-      static const int g0_skinny_max = [] {
-        const char* e = getenv("TEPOSE_G0_SKINNY_MAX_M");
-        return e ? atoi(e) : 128;
-      }();
-      if (BT <= g0_skinny_max) CK(launch_skinny_gemm_h3(b.p[0], s));
+      if (plan.g0skinny) CK(launch_skinny_gemm_h3(b.p[0], s));
       else CK(launch_gemm_h3(b, s));
     } else {
       GemmArgs g = gemm(w.xp, kInputP, Bl + m->wih0, kInputP, w.g0, ld0, Bl + m->bih0, (int)BT, ld0);
@@ -1928,7 +1918,7 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
     // the three iterations from the model's own initial state as ONE product: xs = feat Mf^T + k0
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     CK((hipError_t)h3_mm(w.featP, Bl + m->mf_p, 256, kFeat, w.xs, kState, Bl + m->k0, N, kState, nullptr, 0, 0.f, nullptr, s));
-  } else if (w.split_fc && N <= reg_seq_max_n() && persist_on(m)) {
+  } else if (select_kernels(m, N, 1).reg_seq) {
     // small batches: the whole FC loop in one persistent launch (reg_seq.hip)
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
     RegSeqArgs ra{};
@@ -2160,12 +2150,11 @@ int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const
   if (!A || !W || !C || !workspace || M < 1 || N < 1 || K < 1) return TEPOSE_E_ARG;
   if (K % 32 != 0) return TEPOSE_E_SHAPE;
   if (ws_bytes < gemm_h3_ws_bytes(M, N, K)) return TEPOSE_E_WORKSPACE;
-  // TEPOSE_H3S=1 (read per call: this is the test / bench entry): the single-accumulator 256 x 256 kernel of gemm_h3s.hip,
-  // operand scales for the ranges of tools/h3_loop.py / h3_bench.py and tests/test_gpu_stress.py
+  // TEPOSE_H3S=1 (read per call: this is the test / bench entry): the scaled-plane barrier-free kernel of gemm_h3s16c.hip, operand scales for
+  // the ranges of tools/h3_loop.py / h3_bench.py and tests/test_gpu_stress.py; TEPOSE_H3S=mid: the 128 x 288-tile kernel of gemm_h3s.hip (N % 288 == 0)
   const char* pe = getenv("TEPOSE_H3S");
-  if (pe && atoi(pe) && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
-    CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, bias,
-                           atoi(pe) == 2 ? 1 : atoi(pe) == 3 ? 3 : 0));   // TEPOSE_H3S=2: the 16x16x32 MFMA shape (gemm_h3s16.hip); 3: its barrier-free experiment
+  if (pe && pe[0] && std::string(pe) != "0" && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
+    CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, bias, std::string(pe) == "mid" ? 1 : 0));
     return 0;
   }
   CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream));

@@ -326,7 +326,6 @@ struct H3SArgs {
   float inv_scale;                       // 1 / (pA * pW)
   int M, N;
   const float* row_scale;                // optional [M], as H3Args::row_scale (then pA = 1)
-  int shape16;                           // 1: v_mfma_f32_16x16x32_f16 instead of 32x32x16 (gemm_h3s16.hip; needs Kp % 32 == 0)
   // barrier-free kernels (gemm_h3s16c.hip): where a wave whose bounded LDS poll expired reports it -- the forward's status word
   // (workspace sync region, agent scope) and the handle's host-visible fault word (system scope); nullptr: debug counter + NaN only
   unsigned* status = nullptr;
@@ -335,43 +334,24 @@ struct H3SArgs {
   int c_blk_hp = 0;                      // != 0 (= Hp): C is a [rows][3 Hp] gate pre-activation matrix, written in the blocked layout (gi_blk_offset)
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
-hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // tag 0: the layer-0 projection (own kernel symbol for profiles)                                // state planes a GRU step writes
-hipError_t launch_gru_h3s(const H3SBatch& b, hipStream_t s);
+hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // every plain scaled-plane product of large batches (tag 0: the layer-0 projection: own kernel symbol for profiles)
 bool gemm_h3s16_ok(const H3SArgs& a);
-bool gemm_h3s_blocked_ok();
-hipError_t launch_gemm_h3s16(const H3SArgs& a, hipStream_t s, int tag);   // gemm_h3s16.hip
-hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag);  // gemm_h3s16c.hip: no barriers in the K loop (default for the plain products)
+hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag);  // gemm_h3s16c.hip: persistent, no workgroup barriers in the K loop
 unsigned h3s16c_read_err();
-void h3s16c_warm();                    // allocates the debug error counter (at handle creation: never inside a stream capture)
-bool gru_h3s16c_ok(const H3SBatch& b);
-hipError_t launch_gru_h3s16c(const H3SBatch& b, hipStream_t s);         // gemm_h3s16c.hip: persistent barrier-free fused GRU step
-bool gru_h3s16_ok(const H3SBatch& b);
-hipError_t launch_gru_h3s16(const H3SBatch& b, hipStream_t s);          // the fused GRU step on 16x16x32 (gemm_h3s16.hip)
+void h3s16c_warm();                    // allocates the current device's debug error counter (tepose_set_blob: never inside a stream capture)
+// gru_step16.hip: the fused GRU cell step of large batches; planes = the instantiation that takes its cell operands through the LDS-DMA stream and
+// rebuilds h_{t-1} from the state planes (full tiles + blocked layouts only: gru_step16_planes_ok)
+bool gru_step16_ok(const H3SBatch& b);
+bool gru_step16_planes_ok(const H3SBatch& b);
+hipError_t launch_gru_step16(const H3SBatch& b, hipStream_t s, bool planes);
 bool gemm_h3s_mid_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s);   // 128 x 288 tiles, N % 288 == 0
 hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, int Kp, long R, float p, void* hi,
-                                 void* lo, hipStream_t s, int tiled_hp = 0);   // tiled_hp = Hp: destination row q (gate-interleaved tile order,
-                                 // q = jt * 192 + wn * 96 + gate * 32 + i) takes source row gate * Hp + jt * 64 + wn * 32 + i
-// gru_fuse16.hip (round 5): one cell step of a layer >= 1 with the layer's input projection fused into the K loop -- [x_t | h_{t-1}] against the
-// planes of [W_ih | W_hh]; no gate pre-activations in memory.  One direction of one step:
-struct FuseDir {
-  const half_t *Xh, *Xl; long x_kst;     // this step's input rows (the previous layer's state slab) as scaled planes: view base, halfs between K-tiles
-  const half_t *Hh, *Hl; long h_kst;     // previous state planes of this direction
-  const half_t *Wh, *Wl; long w_kst;     // planes of [W_ih | W_hh]: rows in the gate-interleaved tile order padded to 384, K-tiles [0, Kx / 16) = W_ih
-  int Kx;                                // input width (Hp or 2 Hp), multiple of 32
-  float inv_scale;                       // 1 / (kStateScale * scale of the concatenated weight planes)
-  const float* bias4;                    // [4][Hp]: b_ir + b_hr | b_iz + b_hz | b_in | b_hn
-  float* hout; long ldo;                 // fp32 new state (row-major) where somebody reads it, else nullptr: the planes are the state
-  half_t *hout_hi, *hout_lo; long okst;  // planes of the new state: view base, halfs between 16-column groups
-};
-struct FuseBatch { FuseDir d[3]; int n, M, Hp; float state_scale; };
-bool gru_fuse16_ok(const FuseBatch& b);
-hipError_t launch_gru_fuse16(const FuseBatch& b, hipStream_t s);
-hipError_t launch_bias_cat(const float* bih, const float* bhh, float* out, int Hp, hipStream_t s);
+                                 void* lo, hipStream_t s);
 hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);
 size_t gemm_h3s_ws_bytes(int M, int N, int K);
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
                                int K, float pA, float pW, void* ws, hipStream_t s, const float* bias = nullptr,
-                               int shape16 = 0);
+                               int mid = 0);   // mid: the 128 x 288-tile kernel (N % 288 == 0) instead of the barrier-free persistent one
 
 }  // namespace tepose

@@ -315,315 +315,54 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// The fused GRU cell step of large batches in the same barrier-free form: 256 persistent workgroups walk the (direction, 256-row tile,
-// 64-unit tile) tiles of one step launch; eight waves of 64 rows x 96 columns (the r, z, n tiles of 32 hidden units; W_hh rows in the
-// gate-interleaved tile order); 28 KB stages, two pair slots (112 KB) + the counters.  Round 3's persistent 256-row step lost 4 % to the
-// 128-row form because one workgroup per CU kept all CUs in lock step (pipeline refill, cell update and store burst at the same time on
-// every SIMD); without barriers each wave runs its cell update -- 16-byte loads of the gate pre-activations / previous state, gate math,
-// 16-byte state store + two 8-byte plane stores -- whenever IT finishes a tile, under the other waves' MFMAs, and the request stream
-// runs on into the next tile.  Transposed product: a lane owns 4 consecutive hidden units of one row for r, z and n (no LDS turn).
-template <int TAG>
-__global__ void __launch_bounds__(512) gru_h3s16c_kernel(H3SBatch batch, int tilesM, int tilesJ, int GM, unsigned* err) {
-  constexpr int NWN = 2, NW = 8, NST = 4, MT = 4, NT = 6;
-  constexpr int HM = 256, HN = 192, HK = 16, RB = HK * 2, RPI = 1024 / RB;
-  constexpr int STAGE = (2 * HM + 2 * HN) * RB, TOT = STAGE / 1024, Q = TOT / NW, REM = TOT % NW, ND = Q + (REM ? 1 : 0);
-  constexpr int SPIN = 1 << 18;
-  static_assert(STAGE % 1024 == 0 && NST * STAGE + 64 <= 160 * 1024 && 2 * ND <= MT * 2, "ring / request slots");
-  typedef _Float16 h16x4c __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE + 64];
-  const int per_dir = tilesM * tilesJ, ntiles = batch.n * per_dir;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int t = lane & 15, g = lane >> 4;
-  const unsigned lds0 = (unsigned)(size_t)lds;
-  const unsigned cnt0 = lds0 + NST * STAGE;
-  if (tid < 16) ((unsigned*)(lds + NST * STAGE))[tid] = 0u;
-  __syncthreads();
-  auto fresh_lane = [&]() __attribute__((always_inline)) {
-    int l = lane;
-    asm volatile("" : "+v"(l));
-    return l;
-  };
-  const int nd = Q + (wave < REM ? 1 : 0);
-  const int i0 = wave * Q + min(wave, REM);
-  // rows of the stage image [A_hi | A_lo | W_hi | W_lo] this wave's requests cover (32 whole rows of one plane each: wave-uniform)
-  bool isA[ND], isLo[ND];
-  int lrow0[ND];
-#pragma unroll
-  for (int q = 0; q < ND; ++q) {
-    int ri = min(i0 + q, TOT - 1) * RPI;
-    isA[q] = ri < 2 * HM;
-    if (!isA[q]) ri -= 2 * HM;
-    isLo[q] = ri >= (isA[q] ? HM : HN);
-    lrow0[q] = isLo[q] ? ri - (isA[q] ? HM : HN) : ri;
-  }
-  const char* sbase[ND];
-  long kst[ND];
-  unsigned voff[ND];
-  int ddir = 0, dm0 = 0, dtj = 0;                          // the tile the request stream is in
-  auto decode = [&](int tile, int& dir, int& tm, int& tj) {
-    int tma, tn;
-    h3s16c_tile_of_block(tile, ntiles, batch.n * tilesM, tilesJ, tma, tn, GM);
-    dir = tma / tilesM; tm = tma - dir * tilesM; tj = tn;
-  };
-  auto setup = [&](int tile) {
-    int tm;
-    decode(tile, ddir, tm, dtj);
-    dm0 = tm * HM;
-    const H3SArgs& a = batch.p[ddir];
-    const int n0 = dtj * HN;
-    const int l = fresh_lane();
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-      const int grow = isA[q] ? min(dm0 + lrow0[q] + l / 2, a.M - 1) : n0 + lrow0[q] + l / 2;
-      voff[q] = (unsigned)grow * RB + 16u * (l & 1);
-      // (wave-uniform by construction -- the direction comes from the tile index, the plane from the wave number -- but indexed
-      // out of the kernel arguments at run time: say so, the request's base operand must be an SGPR pair)
-      const unsigned long long pb = (unsigned long long)(isA[q] ? (isLo[q] ? a.Al : a.Ah) : (isLo[q] ? a.Wl : a.Wh));
-      const unsigned long long ks = (unsigned long long)((isA[q] ? a.a_kst : a.w_kst) * 2);
-      sbase[q] = (const char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
-                               (unsigned)__builtin_amdgcn_readfirstlane((int)pb));
-      kst[q] = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ks >> 32)) << 32) |
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)ks));
-    }
-  };
-  auto request_one = [&](int pair, int k) __attribute__((always_inline)) {     // k-th of this wave's 2 nd requests of a pair
-    const int sgi = k / ND, q = k % ND;
-    if (REM == 0 || q < nd) {
-      const unsigned dst = lds0 + (unsigned)((((2 * pair + sgi) % NST) * STAGE) + (i0 + q) * 1024);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase[q]), "s"(dst) : "m0", "memory");
-      sbase[q] += kst[q];
-    }
-  };
-  auto bump = [&](int slot) __attribute__((always_inline)) {
-    if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt0 + 4u * (unsigned)slot), "v"(1u) : "memory");
-  };
-  bool dead = false;
-  const unsigned INJ = batch.p[0].inject;
-  auto poll = [&](int slot, int target) __attribute__((always_inline)) {
-    const unsigned addr = cnt0 + 4u * (unsigned)slot;
-    for (int spins = 0;; ++spins) {
-      unsigned v;
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-      if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - (unsigned)target - INJ) >= 0) break;
-      if (spins > SPIN) { dead = true; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  };
-  const unsigned sx = 16u * ((g & 1) ^ ((t >> 3) & 1)) + (unsigned)(g >> 1) * STAGE;
-  const unsigned abase = lds0 + (unsigned)(wm * 16 * MT + t) * RB + sx;
-  const unsigned bbase = lds0 + 2 * HM * RB + (unsigned)(wn * 16 * NT + t) * RB + sx;
-  constexpr int A_LO = HM * RB, W_LO = HN * RB;
-  const int NP = batch.p[0].Kp / (2 * HK);                 // the launcher guarantees equal, even K-tile counts >= 4 in every direction
-  const int Hp = batch.Hp;
+// Debug counter of give-ups, ONE PER DEVICE (a process-wide counter allocated on whichever device was current at the first tepose_create was
+// handed to launches on every other GPU of the process, whose atomicAdd would then fault instead of reporting).  Allocated by h3s16c_warm(), which
+// tepose_set_blob calls with the blob's device current -- never inside a stream capture; a device without a counter launches with nullptr (the kernel
+// then reports through the status / fault words only).
+static constexpr int kMaxDev = 64;
+static unsigned* g_h3s16c_err[kMaxDev] = {};
 
-  f32x4c acc[MT][NT];
-  h16x8c ah[MT], al[MT], bh[2][2], bl[2][2];
-#define TEPOSE_G_READ_B(BB, C)                                                                                                \
-  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                             \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh[(C) & 1][u]) : "v"(BB), "n"((2 * (C) + u) * 16 * RB));            \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[(C) & 1][u]) : "v"(BB), "n"((2 * (C) + u) * 16 * RB + W_LO));     \
-  }
-#define TEPOSE_G_WAIT_B(N, X)                                                                                                 \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(bh[X][0]), "+v"(bh[X][1]), "+v"(bl[X][0]), "+v"(bl[X][1]) : : "memory")
-  auto chunk = [&](int C, int X, bool dma, int pair) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        acc[i][2 * C + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], ah[i], acc[i][2 * C + u], 0, 0, 0);
-        // (request index = MFMA index: a compile-time subscript -- a run-time one sends sbase / voff / kst to LDS scratch)
-        if (i * 2 + u < 2 * ND) { if (dma) request_one(pair, i * 2 + u); }
-      }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) acc[i][2 * C + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[X][u], ah[i], acc[i][2 * C + u], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) acc[i][2 * C + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[X][u], al[i], acc[i][2 * C + u], 0, 0, 0);
-  };
-
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  setup(tile);
-  int dtile = tile, dpt = 0;
-#pragma unroll
-  for (int k = 0; k < 2 * ND; ++k) request_one(0, k);
-  ++dpt;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  bump(0);
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
-  int pt = 0, gp = 0;
-  int cdir = ddir, cm0 = dm0, ctj = dtj;                   // the tile being accumulated
-  for (;;) {
-    poll(gp & 1, NW * (gp / 2 + 1));
-    if (dead) break;
-    bool requested = false;
-    if (dpt >= NP) {
-      const int nt = dtile + (int)gridDim.x;
-      if (nt < ntiles) { dtile = nt; dpt = 0; setup(nt); }
-    }
-    if (dpt < NP) { ++dpt; requested = true; }
-    const unsigned par = (unsigned)(gp & 1) * 2u * STAGE;
-    const unsigned ab = abase + par, bb = bbase + par;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[i]) : "v"(ab), "n"(i * 16 * RB));
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[i]) : "v"(ab), "n"(i * 16 * RB + A_LO));
-    }
-    TEPOSE_G_READ_B(bb, 0)
-    TEPOSE_G_READ_B(bb, 1)
-    asm volatile("s_waitcnt lgkmcnt(4)"
-                 : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]),
-                   "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bl[0][0]), "+v"(bl[0][1])
-                 :
-                 : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    chunk(0, 0, requested, gp + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    TEPOSE_G_READ_B(bb, 2)                                  // the last fragment read of pair gp is issued: a bump below is behind it
-    TEPOSE_G_WAIT_B(4, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    chunk(1, 1, false, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (requested) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      bump((gp + 1) & 1);
-    }
-    TEPOSE_G_WAIT_B(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    chunk(2, 0, false, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    ++gp;
-    if (pt + 1 < NP) { ++pt; continue; }
-
-    // ---- cell update of the finished tile (cdir, cm0, ctj), this wave's 64 rows x 32 hidden units
-    {
-      const H3SArgs& a = batch.p[cdir];
-      const GateDir& d = batch.gate[cdir];
-      const int le = fresh_lane(), te = le & 15, ge = le >> 4;
-      const int jb = ctj * (32 * NWN) + wn * 32;
-      const bool vec = (((size_t)d.hout | (size_t)d.gi | (size_t)d.hprev | (size_t)d.bhh) & 15) == 0 && (d.ldo & 3) == 0 &&
-                       (d.ldgi & 3) == 0 && (d.ldh & 3) == 0;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = jb + u * 16 + 4 * ge;
-        if (j >= Hp) continue;
-        f32x4c br, bz, bn;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { br[c] = d.bhh[j + c]; bz[c] = d.bhh[Hp + j + c]; bn[c] = d.bhh[2 * Hp + j + c]; }
-        // every load of this unit tile first, then the gate math: one exposed latency per unit tile.  Measured neutral here and
-        // 2 % SLOWER in gru_h3s16_kernel<0,2> (11.70 vs 11.45 ms per forward: the loads arrive in bursts), which keeps one round at a time
-        f32x4c gr[MT], gz[MT], gn[MT], hp[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int row = min(cm0 + wm * 16 * MT + i * 16 + te, a.M - 1);
-          const float* gi = d.gi + (long)row * d.ldgi + j;
-          const float* hq = d.hprev + (long)row * d.ldh + j;
-          if (vec) {
-            gr[i] = *(const f32x4c*)gi; gz[i] = *(const f32x4c*)(gi + Hp); gn[i] = *(const f32x4c*)(gi + 2 * Hp);
-            hp[i] = *(const f32x4c*)hq;
-          } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { gr[i][c] = gi[c]; gz[i][c] = gi[Hp + c]; gn[i][c] = gi[2 * Hp + c]; hp[i][c] = hq[c]; }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int row = cm0 + wm * 16 * MT + i * 16 + te;
-          if (row >= a.M) continue;
-          f32x4c v;
-          _Float16 hh[4], ll[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float hr = acc[i][0 + u][c] * a.inv_scale, hz = acc[i][2 + u][c] * a.inv_scale, hn = acc[i][4 + u][c] * a.inv_scale;
-            const float rg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * (gr[i][c] + (hr + br[c]))));
-            const float zg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * (gz[i][c] + (hz + bz[c]))));
-            const float ng = 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * (gn[i][c] + rg * (hn + bn[c])))) - 1.f;
-            v[c] = (1.f - zg) * ng + zg * hp[i][c];
-            const float sv = v[c] * batch.state_scale;
-            hh[c] = (_Float16)sv;
-            ll[c] = (_Float16)(sv - (float)hh[c]);
-          }
-          float* ho = d.hout + (long)row * d.ldo + j;
-          const long o = (long)(j >> 4) * d.okst + plane16_index(row, j & 15, 0);
-          if (vec) {
-            *(f32x4c*)ho = v;
-          } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ho[c] = v[c];
-          }
-          *(h16x4c*)((_Float16*)d.hout_hi + o) = h16x4c{hh[0], hh[1], hh[2], hh[3]};
-          *(h16x4c*)((_Float16*)d.hout_lo + o) = h16x4c{ll[0], ll[1], ll[2], ll[3]};
-        }
-      }
-    }
-    const int next = tile + (int)gridDim.x;
-    if (next >= ntiles) break;
-    tile = next;
-    cdir = ddir; cm0 = dm0; ctj = dtj;                      // (the request stream switched to it in this tile's last interval)
-    pt = 0;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
-  }
-#undef TEPOSE_G_READ_B
-#undef TEPOSE_G_WAIT_B
-  if (dead && lane == 0) {
-    if (err) atomicAdd(err, 1u);
-    batch.gate[0].hout[0] = __builtin_nanf("");
-    if (batch.p[0].status) __hip_atomic_store(batch.p[0].status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (batch.p[0].fault) __hip_atomic_store(batch.p[0].fault, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+static unsigned* h3s16c_err_of_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return nullptr; }
+  return __atomic_load_n(&g_h3s16c_err[dev], __ATOMIC_ACQUIRE);
 }
 
-static unsigned* h3s16c_err() {
-  static unsigned* p = [] { unsigned* q = nullptr; if (hipMalloc((void**)&q, 256) != hipSuccess) return (unsigned*)nullptr; (void)hipMemset(q, 0, 256); return q; }();
-  return p;
+void h3s16c_warm() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return; }
+  if (__atomic_load_n(&g_h3s16c_err[dev], __ATOMIC_ACQUIRE)) return;
+  unsigned* q = nullptr;
+  if (hipMalloc((void**)&q, 256) != hipSuccess || !q) { (void)hipGetLastError(); return; }
+  (void)hipMemset(q, 0, 256);
+  unsigned* expected = nullptr;
+  if (!__atomic_compare_exchange_n(&g_h3s16c_err[dev], &expected, q, false, __ATOMIC_RELEASE, __ATOMIC_ACQUIRE)) (void)hipFree(q);   // another thread was first
 }
+
+bool gemm_h3s16_ok(const H3SArgs& a) { return a.Kp % 32 == 0 && a.Kp >= 64; }
 
 hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (a.Kp % 32 != 0 || a.Kp < 64) return hipErrorInvalidValue;
+  if (!gemm_h3s16_ok(a)) return hipErrorInvalidValue;
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   const int nt = tilesM * tilesN;
+  // row tiles per XCD group of the walk (the 32 workgroups of an XCD take GM x 32 / GM tiles at a time); layer-0 projection, ms at GM = 2 / 4 / 8 / 16 / 32:
+  // 10.92 / 10.82 / 10.74 / 11.37 / 12.37 (round 4)
   static const int gm = [] { const char* e = getenv("TEPOSE_S16_GM"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 32 ? v : 8; }();
-  if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, h3s16c_err());
-  else hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, h3s16c_err());
+  unsigned* err = h3s16c_err_of_current_device();
+  if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, err);
+  else hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, err);
   return hipGetLastError();
 }
 
-bool gru_h3s16c_ok(const H3SBatch& b) {
-  if (b.n < 1 || b.Hp % 64 != 0) return false;
-  for (int d = 0; d < b.n; ++d)
-    if (b.p[d].Kp % 32 != 0 || b.p[d].Kp < 128 || b.p[d].Kp != b.p[0].Kp || b.p[d].M != b.p[0].M) return false;
-  return true;
-}
-
-hipError_t launch_gru_h3s16c(const H3SBatch& b, hipStream_t s) {
-  if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
-  if (!gru_h3s16c_ok(b)) return hipErrorInvalidValue;
-  const int tM = (b.p[0].M + 255) / 256, tj = b.Hp / 64;
-  const int nt = b.n * tM * tj;
-  int GM = 8;
-  while (GM > 1 && tM % GM != 0) GM >>= 1;                // groups of GM row tiles x 32 / GM unit tiles that do not straddle directions
-  hipLaunchKernelGGL(gru_h3s16c_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, b, tM, tj, GM, h3s16c_err());
-  return hipGetLastError();
-}
-
-void h3s16c_warm() { (void)h3s16c_err(); }
-
-unsigned h3s16c_read_err() {
-  unsigned v = 0;
-  if (h3s16c_err()) (void)hipMemcpy(&v, h3s16c_err(), 4, hipMemcpyDeviceToHost);
-  return v;
+unsigned h3s16c_read_err() {            // sum over the devices that have a counter (unified addressing: readable from any current device)
+  unsigned total = 0;
+  for (int d = 0; d < kMaxDev; ++d) {
+    unsigned* p = __atomic_load_n(&g_h3s16c_err[d], __ATOMIC_ACQUIRE);
+    unsigned v = 0;
+    if (p && hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost) == hipSuccess) total += v;
+  }
+  return total;
 }
 
 }  // namespace tepose

@@ -504,6 +504,8 @@ int gru_seq_max_m() {
 
 static int device_cus() {
   static const int cus = [] {
+    const char* e = getenv("TEPOSE_ASSUME_CUS");     // planning on a machine without a device (tests/test_dispatch.py, tepose_select_kernels)
+    if (e && atoi(e) > 0) return atoi(e);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -534,15 +536,9 @@ hipError_t launch_gru_seq(const GruSeqArgs& a0, hipStream_t s) {
   if (a.M <= gru_seq_gran_max_m() && a.gran) return launch_gran(a, grid, s);
   if (a.M <= 16) return launch_mt<1>(a, grid, s);
   if (a.M <= 32) return launch_mt<2>(a, grid, s);
-  // 33..64 rows: a step is bound by the 4 KB per row of state planes every workgroup reads.  Where the chip has room
-  // (a 2-direction layer at H = 1024: 128 workgroups), two workgroups share a unit slice and take 32 rows each.
-  static const bool row_split = [] { const char* e = getenv("TEPOSE_SEQ_ROWSPLIT"); return e && atoi(e) != 0; }();
-  // (opt-in: it needs EVERY CU of the chip resident at once, which a second process's launch on the same GPU can deny
-  // until the bounded wait expires -- tools/soak_seq.py run twice concurrently; -15 us per forward at B = 64 when it is safe)
-  if (row_split && (int)grid.x * a.ndir * 2 <= device_cus()) {
-    grid.y = 2;
-    return launch_mt<2>(a, grid, s);
-  }
+  // 33..64 rows: four 16-row tiles per workgroup.  (Round 2 had an opt-in row split for 2-direction layers -- two workgroups per unit slice, 256
+  // workgroups, -15 us per forward at B = 64 -- removed in round 5: it needs EVERY CU of the chip resident at once, which a second process's launch on
+  // the same GPU can deny until the bounded wait expires.)
   return launch_mt<4>(a, grid, s);
 }
 

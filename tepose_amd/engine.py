@@ -467,6 +467,12 @@ class Engine:
         txt = (self.lib.tepose_kernel_info(self.handle) or b'').decode()
         return dict(kv.split('=', 1) for kv in txt.split(';') if '=' in kv) if txt else {}
 
+    def select_kernels(self, B, T):
+        """The kernel selection of an eval forward of B windows x T frames on this handle, family -> kernel symbol / layout (the C library's own
+        dispatch function: csrc/api.hip select_kernels).  No device needed."""
+        txt = (self.lib.tepose_select_kernels(self.handle, int(B), int(T)) or b'').decode()
+        return dict(kv.split('=', 1) for kv in txt.split(';') if '=' in kv) if txt else {}
+
     # ------------------------------------------------------------------ profiling hook (bench.py)
     def profile_enable(self, on):
         _lib.check(self.lib.tepose_profile_enable(self.handle, 1 if on else 0), 'tepose_profile_enable')

@@ -1,7 +1,9 @@
-"""GPU: the scaled-plane kernels on the other fp16 MFMA shape (csrc/gemm_h3s16.hip, v_mfma_f32_16x16x32_f16; TEPOSE_MFMA16 bit 1 =
-plain products, bit 2 = fused GRU step).  One MFMA spans two K-tiles there, so the sums are associated differently from the
-32x32x16 kernels: results agree to rounding, not bit for bit, and both must sit within the oracle's tolerance.  The knob is read
-when a handle is created, so both settings run in one process."""
+"""GPU: the kernel families a handle's named knobs select for large batches (csrc/api.hip select_kernels) against each other and the fp64 oracle.
+  TEPOSE_LARGE_BATCH_KERNELS = scaled (default: gemm_h3s_persist16c_kernel projections, gru_step16_kernel steps) | twoacc (gemm_h3_kernel family everywhere)
+  TEPOSE_GRU_STATE           = planes (default: gru_step16_kernel<true> -- cell operands through the LDS-DMA stream, h_{t-1} rebuilt from the state
+                               planes, full tiles only) | fp32 (gru_step16_kernel<false>)
+Different associations of the K sums (and, for `planes`, a 22-bit previous state): results agree to rounding, each within 2e-5 of the oracle on features;
+the give-up counter of the barrier-free kernels stays where it was."""
 import numpy as np
 import pytest
 import torch
@@ -12,36 +14,43 @@ from tepose_amd.testing import build_model
 
 pytestmark = pytest.mark.gpu
 
-# (L, H, B, T): row tiles of 128 with ragged last tiles, 1 / 2 / 3 layers (2- and 3-direction step launches), hidden sizes
-# whose unit tiles (64) do not fill the 4 x 8 walk, B at / just above the scaled-format threshold (2048)
-SHAPES = [(2, 1024, 2305, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (3, 512, 2049, 2), (2, 256, 4096, 4)]
+# (L, H, B, T): row tiles of 128 full (B % 128 == 0: the `planes` step kernel) and ragged (the fp32-state kernel at every knob), 1 / 2 / 3 layers (2- and
+# 3-direction step launches), hidden sizes whose unit tiles (64) do not fill the 4 x 8 walk, B at / just above the scaled-format threshold, long windows
+SHAPES = [(2, 1024, 2304, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (3, 512, 2048, 2), (2, 256, 4096, 4), (2, 128, 640, 16), (3, 64, 1280, 7)]
 
 
-@pytest.mark.parametrize('knob', ['1', '2', '3', '5', '13', '25'])     # bit 1 plain products, bit 2 GRU step (8 waves), bit 4 GRU step (4 waves of 64 x 96), bit 8 plain products barrier-free, bit 16 GRU step persistent + barrier-free
-def test_mfma16_kernels_against_the_default_shape_and_the_fp64_oracle(monkeypatch, knob):
+@pytest.mark.parametrize('knobs', [{'TEPOSE_GRU_STATE': 'fp32'}, {'TEPOSE_LARGE_BATCH_KERNELS': 'twoacc'}])
+def test_kernel_families_against_the_default_and_the_fp64_oracle(monkeypatch, knobs):
     from tepose_amd import _lib
     errs0 = int(_lib.load().tepose_debug_kernel_errors())            # process-wide counter (tests/test_gpu_status.py forces give-ups on purpose)
     for L, H, B, T in SHAPES:
         smpl_np = synth.synthetic_smpl(0)
         state = synth.synthetic_state_dict(L, H, 11)
-        monkeypatch.setenv('TEPOSE_MFMA16', '0')                           # every scaled-plane kernel on 32x32x16
         base, _, _ = build_model(L, H, seed=11, device='cuda', smpl_np=smpl_np, state=state)
-        monkeypatch.setenv('TEPOSE_MFMA16', knob)
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
         alt, _, _ = build_model(L, H, seed=11, device='cuda', smpl_np=smpl_np, state=state)
-        monkeypatch.delenv('TEPOSE_MFMA16', raising=False)
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        sel_b, sel_a = base._engine.select_kernels(B, T), alt._engine.select_kernels(B, T)
+        if 'TEPOSE_GRU_STATE' in knobs:
+            assert sel_a['gru_step'] == 'gru_step16_kernel<false>'
+            assert sel_b['gru_step'] == ('gru_step16_kernel<true>' if B % 128 == 0 else 'gru_step16_kernel<false>')
+        else:
+            assert 'h3s' not in sel_a['projection'] and 'step16' not in sel_a['gru_step'] and sel_a['gi1_layout' if L > 1 else 'gi0_layout'] == 'row_major'
         x = torch.from_numpy(synth.synthetic_windows(B, T, 42)).cuda()
         with torch.no_grad():
             fa = base.encoder(x).cpu().numpy()
+            fa2 = base.encoder(x).cpu().numpy()
             fb = alt.encoder(x).cpu().numpy()
-            fb2 = alt.encoder(x).cpu().numpy()
-        assert np.array_equal(fb, fb2), (L, H, B, T)                      # deterministic
+        assert np.array_equal(fa, fa2), (L, H, B, T)                      # deterministic
         assert np.abs(fa - fb).max() < 5e-6, (L, H, B, T, np.abs(fa - fb).max())
+        if 'TEPOSE_GRU_STATE' in knobs and B % 128 != 0:
+            assert np.array_equal(fa, fb)                                 # ragged row tiles: both handles run the fp32-state kernel
         enc, _ = O.split_state_dict(state, torch.float64)
+        rows = np.r_[0:40, B - 40:B]                                       # the first and the (possibly ragged) last row tile
         with torch.no_grad():
-            ref = O.encoder_fwd(enc, torch.from_numpy(synth.synthetic_windows(B, T, 42)[:48]).double(), L).numpy()
-        assert np.abs(fb[:48] - ref).max() < 2e-5, (L, H, B, T)
-        rows = np.r_[B - 48:B]                                             # the ragged last row tile too
-        with torch.no_grad():
-            ref2 = O.encoder_fwd(enc, torch.from_numpy(synth.synthetic_windows(B, T, 42)[rows]).double(), L).numpy()
-        assert np.abs(fb[rows] - ref2).max() < 2e-5, (L, H, B, T)
+            ref = O.encoder_fwd(enc, torch.from_numpy(synth.synthetic_windows(B, T, 42)[rows]).double(), L).numpy()
+        assert np.abs(fa[rows] - ref).max() < 2e-5, (L, H, B, T)
+        assert np.abs(fb[rows] - ref).max() < 2e-5, (L, H, B, T)
     assert int(_lib.load().tepose_debug_kernel_errors()) == errs0    # no wave of the barrier-free kernels ever gave up a poll

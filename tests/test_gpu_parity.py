@@ -69,18 +69,17 @@ def test_gemm_rejects_bad_arguments():
                                       (2, 128, 70, 9), (2, 1024, 40, 16), (3, 100, 250, 3), (2, 64, 333, 4), (2, 192, 129, 4),   # 512 <= B*T < 8192, L >= 2: 128 x 288 tiles (ragged last row tile)
                                       (2, 64, 1100, 8), (3, 100, 1030, 8), (2, 64, 4100, 3), (3, 100, 4097, 2), (2, 128, 2048, 2),   # B*T >= 8192: single-accumulator
                                       # layer-0 projection; B >= 640 (TEPOSE_S_MIN_B; 2048 until round 4): scaled-format recurrent path; class defaults: n_layers=1, hidden=2048
-                                      # B >= 640: the fused GRU step of large batches -- by default (round 4) gru_h3s16_kernel<0, 2> (16x16x32 MFMA, four
-                                      # waves of 64 x 96; 128-row tiles, full and ragged; unit-tile counts 3, 4, 5, 8, 16) and the layer >= 1 projections on
-                                      # gemm_h3s_persist16c_kernel (barrier-free); first steps on gru_first16_kernel where Hp % 128 == 0.  (The 32x32x16 kernels: tests/test_gpu_mfma16.py's TEPOSE_MFMA16=0 baseline.)
+                                      # B >= 640: the fused GRU step of large batches (gru_step16_kernel: 16x16x32 MFMA, four waves of 64 x 96; 128-row tiles,
+                                      # full -> the plane-fed instantiation, ragged -> the fp32-state one; unit-tile counts 3, 4, 5, 8, 16) and the layer >= 1
+                                      # projections on gemm_h3s_persist16c_kernel (barrier-free); first steps on gru_first16_kernel where Hp % 128 == 0
                                       (2, 192, 2100, 3), (2, 256, 2304, 3), (1, 320, 2050, 2), (3, 512, 2049, 2), (2, 1024, 2048, 2),
                                       (2, 1024, 2305, 3),
                                       # B * T >= 8192 AND B >= 640 AND B % 16 == 0: layer-0 gate pre-activations frame-major + 16 x 16-blocked (common.h gi_blk_offset),
                                       # layers >= 1 blocked whenever B >= 640; a ragged last 128-row tile (2064 = 16 * 128 + 16), three layers
                                       (2, 128, 2048, 4), (3, 256, 2064, 4), (2, 64, 2320, 5),
-                                      # B >= 640 AND B % 128 == 0, L >= 2 (round 5): the cell steps of layers >= 1 with the layer's input projection fused
-                                      # into the K loop (gru_fuse16_kernel: [x_t | h] against [W_ih | W_hh], no gate pre-activations in memory); two- and
-                                      # three-direction launches (3 layers: the middle layer runs all T steps of the rec forward direction too), Kx = Hp and 2 Hp,
-                                      # unit-tile counts 1 ... 16, T from 2 (one fused step) to 7
+                                      # B >= 640 AND B % 128 == 0 (round 5): every row tile full -> gru_step16_kernel<true> (cell operands through the LDS-DMA
+                                      # stream, h_{t-1} rebuilt from the state planes): two- and three-direction launches, 2 / 3 / 4 layers, unit-tile counts 1 ... 16,
+                                      # T from 2 (one step behind the first) to 7
                                       (2, 256, 1024, 6), (3, 128, 1280, 5), (2, 1024, 640, 4), (2, 64, 768, 7), (3, 192, 896, 3), (4, 64, 640, 3)])
 def test_encoder_vs_oracle(L, H, B, T, smpl_np):
     from oracle import tepose_ref as O

@@ -146,12 +146,11 @@ def test_both_numerics_modes_vs_fp64_oracle_at_the_published_size(monkeypatch, c
         assert (got['theta'][:, 75:] - ref['theta'][:, 75:]).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize('h3s', ['1', '2', '3'])   # 1: v_mfma_f32_32x32x16_f16 (gemm_h3s.hip), 2: 16x16x32 (gemm_h3s16.hip: pairs of K-tiles), 3: its barrier-free form (gemm_h3s16c.hip)
+@pytest.mark.parametrize('h3s', ['1'])   # the barrier-free persistent kernel on v_mfma_f32_16x16x32_f16 (gemm_h3s16c.hip): every plain scaled-plane product of large batches
 def test_single_accumulator_gemm_persistent_tiles_against_fp64(monkeypatch, h3s):
-    """csrc/gemm_h3s.hip, the plain product as a persistent kernel (256 workgroups walking the 256 x 256 tiles, the next
-    tile's stages requested before the finished tile's stores): more tiles than workgroups, partial edge tiles (their own
-    drained path), unaligned C rows (scalar stores), short K (no overlap), with and without bias; and the one-workgroup-
-    per-tile kernel (TEPOSE_H3S_PERSIST is latched per process, so that one is compared in tools/h3_bench.py)."""
+    """csrc/gemm_h3s16c.hip, the plain scaled-plane product as a persistent kernel (256 workgroups walking the 256 x 256 tiles, pairs of
+    K-tiles running on across tile boundaries): more tiles than workgroups, partial edge tiles, unaligned C rows (scalar stores), short K,
+    with and without bias."""
     from tepose_amd import _lib
     lib = _lib.load()
     monkeypatch.setenv('TEPOSE_H3S', h3s)
@@ -184,9 +183,9 @@ def test_single_accumulator_gemm_persistent_tiles_against_fp64(monkeypatch, h3s)
         assert torch.equal(C[:, :N], C2[:, :N])                             # deterministic
 
 
-@pytest.mark.parametrize('h3s', ['1', '2', '3'])
+@pytest.mark.parametrize('h3s', ['1'])
 def test_persistent_split_gemm_is_bitwise_repeatable_next_to_a_memory_and_mfma_heavy_stream(monkeypatch, h3s):
-    """The persistent plain product (csrc/gemm_h3s.hip, gemm_h3s_persist_kernel) lets a finished tile's 32 stores per wave stay
+    """The persistent plain product (csrc/gemm_h3s16c.hip, gemm_h3s_persist16c_kernel) lets a finished tile's stores stay
     in flight under the next tile's first K-tiles: `s_waitcnt vmcnt(2 Q + 32)` is only correct if memory instructions retire
     from the counter in ISSUE order.  That is the documented behaviour of this part (MI355X_MICROARCH.md, "s_waitcnt": "Loads,
     stores, atomics and LDS-DMA count together, in issue order (flat_* excepted ...)"; the kernel issues global_load_lds and

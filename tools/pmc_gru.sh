@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes over the recurrent part (tools/gru_step_bench.py) for the kernels that contain "gru" / "gemm_h3s":
-#   tools/pmc_gru.sh <tag> [env assignments for the run, e.g. TEPOSE_MFMA16=0]
+#   tools/pmc_gru.sh <tag> [env assignments for the run, e.g. TEPOSE_GRU_STATE=fp32]
 # Separate --pmc passes (never with the trace domains); digest by profiles/summarize.py pmcavg.  Every pass runs under its own
 # `timeout`: a TA_* counter set (TA_BUSY_avr, TA_*_STALLED_BY_TC_CYCLES_sum) did not finish in 20 minutes on this pool and was
 # dropped from the list -- do not put derived TA metrics back without a bound.

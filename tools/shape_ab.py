@@ -1,4 +1,4 @@
-"""A/B of kernel variants selected by environment knobs that a handle reads at creation (TEPOSE_MFMA16, ...), interleaved in
+"""A/B of kernel variants selected by environment knobs that a handle reads at creation (TEPOSE_GRU_STATE, TEPOSE_LARGE_BATCH_KERNELS, ...), interleaved in
 ONE process on ONE device (cdna_hip_programming.md rule 24): each variant is its own model on the same weights; rounds alternate.
     python tools/shape_ab.py [B] [rounds] VAR=val[,VAR=val] [VAR=val ...]     (the first variant is the baseline: '' = defaults)
 Per variant: layer-0 projection ms, recurrent part ms (the library's hipEvents), encoder ms (wall), max |feat - baseline feat|."""
@@ -15,7 +15,7 @@ from tepose_amd.testing import build_model  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-variants = sys.argv[3:] or ['TEPOSE_MFMA16=0', 'TEPOSE_MFMA16=5', 'TEPOSE_MFMA16=13']
+variants = sys.argv[3:] or ['', 'TEPOSE_GRU_STATE=fp32', 'TEPOSE_LARGE_BATCH_KERNELS=twoacc']
 dev = torch.device('cuda', 0)
 smpl_np = synth.synthetic_smpl(0)
 state = synth.synthetic_state_dict(2, 1024, 0)
