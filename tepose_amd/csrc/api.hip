@@ -616,7 +616,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   const bool seq_l0 = L == 1 ? k.seq2 : k.seq3;
   s += ";gru_step=";
   s += !k.h3 ? (B <= skinny_max_m() ? "skinny_gru_kernel" : "gru_step_kernel")
-       : k.scaled ? (k.planes_state ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>")
+       : k.scaled ? (k.planes_state && k.g0blk ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>")
        : seq_l0 ? (B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024 ? "gru_seq_kernel(granules)" : "gru_seq_kernel")
        : k.step_skinny ? "skinny_gru_h3_kernel" : "gemm_h3_kernel<GRU>";
   s += ";gru_first=";
@@ -625,6 +625,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
     s += ";projection_l1=";
     s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= skinny_max_m() ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
     s += std::string(";gi1_layout=") + (k.gblk ? "blocked" : "row_major");
+    if (k.scaled) s += std::string(";gru_step_l1=") + (k.planes_state ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>");
   }
   s += ";tail_regressor=";
   s += !k.reg_split ? "gemm_f32_kernel x (2 + 1 + 9)" : (m->tail_collapsed || !m->enc_packed) && m->collapse_env ? "collapsed: one product (skinny_gemm_h3_kernel / gemm_h3_kernel)"
@@ -1409,7 +1410,11 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       }
       if (a.first) return (int)launch_gru_first(gb, a.ndir, B, Hp, s, 1);
       b.n = a.ndir; b.Hp = Hp; b.state_scale = kStateScale;
-      return (int)launch_gru_step16(b, s, plan.planes_state);
+      // the plane-fed instantiation wants this layer's gate pre-activations blocked: layers >= 1 always are (gblk), layer 0 only where the projection
+      // wrote them frame-major + blocked (g0blk; not from the driver's cache ring).  One decision per layer: every step of a layer runs the same kernel.
+      bool planes = plan.planes_state;
+      for (int d = 0; d < a.ndir; ++d) planes = planes && a.d[d].gi_blk != 0;
+      return (int)launch_gru_step16(b, s, planes);
     }
     H3Batch b{};
     GateBatch gb{};

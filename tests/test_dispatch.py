@@ -50,7 +50,7 @@ def test_class_boundaries_of_the_published_architecture():
     assert s[(37, 6)]['gru_step'] == 'gru_seq_kernel'
     assert s[(65, T)]['gru_step'] == 'skinny_gru_h3_kernel' and s[(128, T)]['gru_step'] == 'skinny_gru_h3_kernel' and s[(129, T)]['gru_step'] == 'gemm_h3_kernel<GRU>'
     assert s[(639, T)]['gru_step'] == 'gemm_h3_kernel<GRU>' and s[(639, T)]['gi1_layout'] == 'row_major' and s[(639, T)]['projection_l1'] == 'gemm_h3_kernel'
-    assert s[(640, T)]['gru_step'] == 'gru_step16_kernel<true>' and s[(640, T)]['gi1_layout'] == 'blocked'
+    assert s[(640, T)]['gru_step'] == 'gru_step16_kernel<true>' and s[(640, T)]['gi1_layout'] == 'blocked' and s[(640, T)]['gru_step_l1'] == 'gru_step16_kernel<true>'
     assert s[(640, T)]['projection_l1'] == 'gemm_h3s_persist16c_kernel<1>' and s[(640, T)]['gru_first'] == 'gru_first16_kernel'
     # B % 128: the plane-fed step kernel needs full row tiles; B % 16: frame-major blocked layer-0 gate pre-activations need whole row tiles per frame
     assert s[(648, T)]['gru_step'] == 'gru_step16_kernel<false>' and s[(648, T)]['gi0_layout'] == 'row_major' and s[(648, T)]['gi1_layout'] == 'blocked'
@@ -60,6 +60,10 @@ def test_class_boundaries_of_the_published_architecture():
     # blend shapes: barrier-free persistent kernel from 512 persons; 1 - 4 persons: the one-launch SMPL kernel
     assert 'gemm_h3s_persist16c_kernel<1>' in s[(512, T)]['smpl'] and 'gemm_h3s_persist16c' not in s[(511, T)]['smpl']
     assert s[(4, T)]['smpl'] == 'smpl_small_kernel' and s[(5, T)]['smpl'] != 'smpl_small_kernel'
+    # layer 0 keeps the fp32-state step where its gate pre-activations are row-major (B * T < 8192), layers >= 1 are blocked from 640 windows on
+    s2 = _select(2, 1024, [(640, 4), (768, 8), (1024, 8)])
+    assert s2[(640, 4)]['gru_step'] == 'gru_step16_kernel<false>' and s2[(640, 4)]['gru_step_l1'] == 'gru_step16_kernel<true>' and s2[(640, 4)]['gi0_layout'] == 'row_major'
+    assert s2[(768, 8)]['gru_step'] == 'gru_step16_kernel<false>' and s2[(1024, 8)]['gru_step'] == 'gru_step16_kernel<true>'
     # cfg-C and the published window
     for key in ((8192, T), (8192, 6)):
         assert s[key]['projection'] == 'gemm_h3s_persist16c_kernel<0>' and s[key]['gru_step'] == 'gru_step16_kernel<true>'

@@ -34,8 +34,11 @@ def test_kernel_families_against_the_default_and_the_fp64_oracle(monkeypatch, kn
             monkeypatch.delenv(k, raising=False)
         sel_b, sel_a = base._engine.select_kernels(B, T), alt._engine.select_kernels(B, T)
         if 'TEPOSE_GRU_STATE' in knobs:
-            assert sel_a['gru_step'] == 'gru_step16_kernel<false>'
-            assert sel_b['gru_step'] == ('gru_step16_kernel<true>' if B % 128 == 0 else 'gru_step16_kernel<false>')
+            assert sel_a['gru_step'] == 'gru_step16_kernel<false>' and sel_a.get('gru_step_l1', 'gru_step16_kernel<false>') == 'gru_step16_kernel<false>'
+            if L >= 2:        # layers >= 1: blocked gate pre-activations from 640 windows on -> plane-fed wherever every row tile is full
+                assert sel_b['gru_step_l1'] == ('gru_step16_kernel<true>' if B % 128 == 0 else 'gru_step16_kernel<false>')
+            # layer 0: plane-fed only where its projection wrote frame-major blocked gate pre-activations (L >= 2, B * T >= 8192, B % 16 == 0)
+            assert sel_b['gru_step'] == ('gru_step16_kernel<true>' if (B % 128 == 0 and L >= 2 and B * T >= 8192) else 'gru_step16_kernel<false>')
         else:
             assert 'h3s' not in sel_a['projection'] and 'step16' not in sel_a['gru_step'] and sel_a['gi1_layout' if L > 1 else 'gi0_layout'] == 'row_major'
         x = torch.from_numpy(synth.synthetic_windows(B, T, 42)).cuda()
@@ -45,8 +48,8 @@ def test_kernel_families_against_the_default_and_the_fp64_oracle(monkeypatch, kn
             fb = alt.encoder(x).cpu().numpy()
         assert np.array_equal(fa, fa2), (L, H, B, T)                      # deterministic
         assert np.abs(fa - fb).max() < 5e-6, (L, H, B, T, np.abs(fa - fb).max())
-        if 'TEPOSE_GRU_STATE' in knobs and B % 128 != 0:
-            assert np.array_equal(fa, fb)                                 # ragged row tiles: both handles run the fp32-state kernel
+        if 'TEPOSE_GRU_STATE' in knobs and (B % 128 != 0 or L == 1):
+            assert np.array_equal(fa, fb)                                 # ragged row tiles / a one-layer model: both handles run the fp32-state kernel
         enc, _ = O.split_state_dict(state, torch.float64)
         rows = np.r_[0:40, B - 40:B]                                       # the first and the (possibly ragged) last row tile
         with torch.no_grad():
