@@ -193,6 +193,12 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
 int tepose_forward_status(tepose_model* m, void* workspace, void* stream);
 int tepose_status(tepose_model* m, void* stream);
 int tepose_status_peek(const tepose_model* m);
+/* Which kernel raised the fault: the handle's fault word while it is raised, else the code of the last fault a status call collected (0 = none yet).
+ * 1, 3 = the persistent recurrent kernel (gru_seq.hip; 3: a peer workgroup not resident after half the bound), 2 = the persistent regressor kernel
+ * (reg_seq.hip) -- residency problems: tepose_set_persistent(m, 0) is the remedy; 4 = a bounded LDS poll of the barrier-free projection kernel
+ * (gemm_h3s16c.hip) expired -- no wait there depends on another workgroup, so this is a kernel bug or a hardware fault, NOT a residency problem: switching
+ * the persistent kernels off does not help, report it.                                                                                        */
+int tepose_fault_code(const tepose_model* m);
 int tepose_set_persistent(tepose_model* m, int on);
 int tepose_uses_persistent(const tepose_model* m, int B, int T);
 /* Tests only: what TEPOSE_TEST_FAULT sets at tepose_create (bit 2: every poll of the barrier-free projection kernel; bit 0 / 1: the waits of the persistent recurrent / regressor

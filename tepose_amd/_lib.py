@@ -21,7 +21,7 @@ SYMBOLS = [
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
-    'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
+    'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_fault_code', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
     'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info', 'tepose_select_kernels', 'tepose_debug_set_test_fault', 'tepose_debug_kernel_errors',
 ]
 
@@ -38,6 +38,12 @@ E_TIMEOUT = -5
 class TeposeTimeout(TeposeError):
     """TEPOSE_E_TIMEOUT: a persistent small-batch kernel gave up waiting for its peers (GPU shared or CU-masked);
     the outputs of that forward are NaN.  Engine re-runs on the step-per-launch kernels where it owns the sync point."""
+
+
+class TeposeKernelFault(TeposeTimeout):
+    """The fault channel reported code 4: a bounded LDS poll of the barrier-free projection kernel (csrc/gemm_h3s16c.hip) expired.  No wait in that
+    kernel depends on another workgroup, so this is a kernel bug or a hardware fault -- not a shared / CU-masked GPU, and the persistent small-batch
+    kernels have nothing to do with it.  The forward's outputs are invalid (NaN-poisoned); the handle stays as it is."""
 
 
 def load():
@@ -110,6 +116,7 @@ def load():
     lib.tepose_debug_set_test_fault.argtypes = [c_void_p, c_uint]
     lib.tepose_debug_kernel_errors.restype = c_uint
     lib.tepose_status_peek.argtypes = [c_void_p]
+    lib.tepose_fault_code.argtypes = [c_void_p]
     lib.tepose_set_persistent.argtypes = [c_void_p, c_int]
     lib.tepose_uses_persistent.argtypes = [c_void_p, c_int, c_int]
     lib.tepose_profile_enable.argtypes = [c_void_p, c_int]

@@ -83,6 +83,7 @@ struct tepose_model {
   unsigned spin_limit = 1u << 21;               // polls (~1 us each) before a wait gives up
   int blend16_min_n = 512;                      // TEPOSE_BLEND16_MIN_N: rows from which the blend-shape product runs on gemm_h3s_persist16c_kernel (0x7fffffff = never)
   int gi_blk = 1;                               // TEPOSE_GI_BLK: large batches keep the layer >= 1 gate pre-activations in the 16 x 16-blocked layout (common.h gi_blk_offset)
+  int last_fault_code = 0;                      // the kernel code of the last fault a status call collected (tepose_fault_code)
   unsigned test_fault = 0;                      // TEPOSE_TEST_FAULT: bit 0 recurrent kernel, bit 1 regressor kernel wait for arrivals that never come
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
@@ -834,25 +835,41 @@ int tepose_status(tepose_model* m, void* stream) {
   if (!m) return TEPOSE_E_ARG;
   CK(hipStreamSynchronize((hipStream_t)stream));
   if (!m->fault) return 0;
-  return __atomic_exchange_n(m->fault, 0u, __ATOMIC_RELAXED) != 0u ? TEPOSE_E_TIMEOUT : 0;
+  const unsigned code = __atomic_exchange_n(m->fault, 0u, __ATOMIC_RELAXED);
+  if (code) m->last_fault_code = (int)code;
+  return code != 0u ? TEPOSE_E_TIMEOUT : 0;
 }
 
 int tepose_forward_status(tepose_model* m, void* workspace, void* stream) {
   if (!m || !workspace) return TEPOSE_E_ARG;
-  CK(hipStreamSynchronize((hipStream_t)stream));
+  hipStream_t s = (hipStream_t)stream;
+  CK(hipStreamSynchronize(s));
+  // every give-up raises BOTH the forward's status word (workspace) and the handle's fault word (pinned host memory, system scope): with the stream
+  // drained, a clear fault word means no forward of this handle gave up -- one host-memory read, no copy (the D2H copy + two null-stream
+  // memsets per small-batch forward of sync mode)
+  if (m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) == 0u) return 0;
   // the sync region is the first carve of every workspace (carve_encoder / carve_regressor): [.. | gru status | .. | reg status]
   unsigned* sy = (unsigned*)workspace;
-  // one copy of the span [recurrent status .. regressor status] (129 words: the regressor's arrival counters lie between them)
+  // one copy of the span [recurrent status .. regressor status] (129 words: the regressor's arrival counters lie between them), on the caller's stream
   unsigned span[32 + 96 + 1];
   static_assert(sizeof(span) == (32 + 96 + 1) * sizeof(unsigned), "span");
-  CK(hipMemcpy(span, sync_gru_status(m, sy), sizeof(span), hipMemcpyDeviceToHost));
+  CK(hipMemcpyAsync(span, sync_gru_status(m, sy), sizeof(span), hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
   const unsigned st[2] = {span[0], span[32 + 96]};
-  if ((st[0] | st[1]) == 0u) return 0;
+  if ((st[0] | st[1]) == 0u) return 0;          // somebody else's forward raised the handle's word: theirs to collect
   // once per faulted forward: a later forward that launches no persistent kernel does not clear the words itself
-  CK(hipMemset(sync_gru_status(m, sy), 0, sizeof(unsigned)));
-  CK(hipMemset(sync_reg_status(m, sy), 0, sizeof(unsigned)));
+  CK(hipMemsetAsync(sync_gru_status(m, sy), 0, sizeof(unsigned), s));
+  CK(hipMemsetAsync(sync_reg_status(m, sy), 0, sizeof(unsigned), s));
+  CK(hipStreamSynchronize(s));
+  m->last_fault_code = (int)(st[0] ? st[0] : st[1]);
   if (m->fault) __atomic_store_n(m->fault, 0u, __ATOMIC_RELAXED);   // or every entry point would go on refusing
   return TEPOSE_E_TIMEOUT;
+}
+
+int tepose_fault_code(const tepose_model* m) {
+  if (!m) return TEPOSE_E_ARG;
+  const unsigned live = m->fault ? __atomic_load_n(m->fault, __ATOMIC_RELAXED) : 0u;
+  return live ? (int)live : m->last_fault_code;
 }
 
 int tepose_set_persistent(tepose_model* m, int on) {

@@ -243,11 +243,20 @@ class Engine:
         self.degraded = False if on else self.degraded
         self._uses_persistent.clear()
 
+    def _raise_if_kernel_fault(self, what):
+        """Fault code 4 = the barrier-free projection kernel gave up a bounded LDS poll (a kernel bug or a hardware fault): nothing the step-per-launch
+        kernels would cure, so no switch, no shared-GPU warning, no silent re-run -- a distinct exception."""
+        if int(self.lib.tepose_fault_code(self.handle)) == 4:
+            raise _lib.TeposeKernelFault('%s: a wave of gemm_h3s_persist16c_kernel gave up a bounded LDS poll (fault code 4) -- the outputs of that forward '
+                                         'are invalid; this is not a residency problem (tepose_debug_kernel_errors() = %d)'
+                                         % (what, int(self.lib.tepose_debug_kernel_errors())))
+
     def check_status(self):
         """Synchronise the current stream and raise TeposeTimeout if a forward on this handle gave up since the last
         check (its outputs are NaN).  The handle is switched to the step-per-launch kernels first, so a re-run works."""
         rc = self.lib.tepose_status(self.handle, self._stream())
         if rc == _lib.E_TIMEOUT:
+            self._raise_if_kernel_fault('tepose_status')
             self._degrade('outputs since the last check are invalid')
         _lib.check(rc, 'tepose_status')
 
@@ -276,15 +285,24 @@ class Engine:
         except _lib.TeposeTimeout:
             # refused up front: an EARLIER forward on this handle gave up (lazy mode); clear, switch kernels, tell the caller
             self.lib.tepose_status(self.handle, self._stream())
+            self._raise_if_kernel_fault('an earlier forward')
             self._degrade('outputs of earlier forwards are invalid')
             raise
-        if self.status_mode == 'sync' and self.uses_persistent(B) and not torch.cuda.is_current_stream_capturing():
-            rc = self._forward_status(ws)
-            if rc == _lib.E_TIMEOUT:
-                self._degrade('re-running this forward')
-                out = call()
+        if self.status_mode == 'sync' and not torch.cuda.is_current_stream_capturing():
+            if self.uses_persistent(B):
                 rc = self._forward_status(ws)
-            _lib.check(rc, 'tepose_forward_status')
+                if rc == _lib.E_TIMEOUT:
+                    self._raise_if_kernel_fault('this forward')
+                    self._degrade('re-running this forward')
+                    out = call()
+                    rc = self._forward_status(ws)
+                _lib.check(rc, 'tepose_forward_status')
+            elif self.lib.tepose_status_peek(self.handle) == _lib.E_TIMEOUT:
+                # large batch: not synchronised by the library, but a fault word raised by a forward that has ALREADY finished (one host-memory read)
+                # is reported now rather than at the next call
+                self.lib.tepose_status(self.handle, self._stream())
+                self._raise_if_kernel_fault('a forward on this handle')
+                _lib.check(_lib.E_TIMEOUT, 'tepose_status')
         return out
 
     # ------------------------------------------------------------------ forward

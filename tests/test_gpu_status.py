@@ -219,11 +219,25 @@ def test_barrier_free_projection_give_up_reaches_the_failure_channel(smpl_np, mo
     torch.cuda.synchronize()
     assert int(lib.tepose_debug_kernel_errors()) > errs0           # the kernel's own counter
     assert lib.tepose_status_peek(eng.handle) != 0                 # the handle's host-visible fault word is up
-    with pytest.raises(_lib.TeposeTimeout):                        # ... so the next entry point refuses before queueing more work
-        with torch.no_grad():
-            model.encoder(x)
-    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == _lib.E_TIMEOUT
-    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0       # once
+    assert lib.tepose_fault_code(eng.handle) == 4                  # ... and says WHICH kernel: the barrier-free projection, not a residency problem
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == _lib.E_TIMEOUT       # the forward's own words: reported once
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == 0
+    assert lib.tepose_fault_code(eng.handle) == 4 and lib.tepose_status_peek(eng.handle) == 0
+    # the same through the engine: the next entry point refuses before queueing more work, as a DISTINCT exception -- the handle is not switched to
+    # the step-per-launch kernels and no shared-GPU warning is printed (code 4 has nothing to do with the persistent small-batch kernels)
+    with torch.no_grad():
+        model.encoder(x)
+    torch.cuda.synchronize()
+    assert lib.tepose_status_peek(eng.handle) != 0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        with pytest.raises(_lib.TeposeKernelFault):
+            with torch.no_grad():
+                model.encoder(x)
+    assert not eng.degraded and eng.uses_persistent(1)
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == 0       # collected handle-wide by the refusal: reported once in total
     # without the injected fault the same handle is healthy again
     assert lib.tepose_debug_set_test_fault(eng.handle, 0) == 0
     eng.check_status()
