@@ -556,7 +556,8 @@ def main():
             gpeak = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS if split else PEAK_F32_MFMA_TFLOPS
             res['roofline_gru_steps'] = {'bound': 'mfma', 'achieved': gach, 'peak': gpeak,
                                          'unit': 'TFLOP/s', 'frac': gach / gpeak,
-                                         'kernel': ('gemm_h3s_kernel<GRU> (single accumulator, cell update fused) + gru_first_kernel' if split else 'gru_step_kernel') +
+                                         'kernel': ('%s (scaled planes, single accumulator, cell update fused) + gru_first16_kernel' % eng.kernel_info().get('gru_step', '?')
+                                                    if split else 'gru_step_kernel') +
                                                    ': the %d step launches of one forward (5T+1 consumed cell steps, '
                                                    'first-step matmuls skipped but counted)' % (2 * T + 1),
                                          'ms_per_forward': g_ms / g_n}

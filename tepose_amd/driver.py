@@ -57,31 +57,36 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
     if not order:
         return results
     C, nmax = len(order), n[order[0]]
+    nj = 14 if J_regressor is not None else 49
+    tails = {'theta': (85,), 'verts': (6890, 3), 'kp_2d': (nj, 2), 'kp_3d': (nj, 3), 'rotmat': (24, 3, 3)}
     F = torch.zeros(C, nmax, 2048, device=dev)
-    TH = torch.zeros(C, nmax, 85, device=dev)
+    # theta history FRAME-major [frame][clip][85]: the forward of window j writes its predictions straight into frame j + T - 1 (rows [0, b) = the active
+    # clips: a prefix), where the next windows read them -- and the same buffer is the result `theta`.  Every kept output likewise has a step-major buffer
+    # [step][clip][...] whose slice [j, :b] is contiguous: a window step costs NO device copy and no tensor op besides the forward itself.
+    TH = torch.zeros(nmax, C, 85, device=dev)
     for s, i in enumerate(order):
         F[s, :n[i]] = features[i].to(dev, torch.float32)
-        TH[s, :T - 1] = theta_init[i].to(dev, torch.float32)
+        TH[:T - 1, s] = theta_init[i].to(dev, torch.float32)
     steps = [n[i] - T + 1 for i in order]                 # windows per clip, non-increasing
-    outs = {k: [None] * C for k in keep}
-    bufs = {}
+    bufs = {k: torch.empty((steps[0], C) + tails[k], device=dev) for k in keep if k != 'theta'}
+    eng = model._engine
     use_cache = (C >= 4) if cache_projections == 'auto' else bool(cache_projections)     # measured crossover
     if cache_projections == 'auto' and os.environ.get('TEPOSE_DRIVER_CACHE', '') in ('0', '1'):    # A/B and debugging
         use_cache = os.environ['TEPOSE_DRIVER_CACHE'] == '1'
+    with on_device(dev):
+        eng.pack_encoder(model.encoder, dev)
+        eng.pack_regressor(model.regressor, dev)
     if use_cache:
-        eng = model._engine
-        with on_device(dev):
-            eng.pack_encoder(model.encoder, dev)
-            eng.pack_regressor(model.regressor, dev)
         ring_n = max(T - 1, 1)
         ring = torch.empty(C, ring_n, eng.gate_width, device=dev)
         newest = torch.empty(C, eng.gate_width, device=dev)
         pws = torch.empty(int(eng.lib.tepose_project_frames_workspace_bytes(eng.handle, C)), dtype=torch.uint8, device=dev)
+        th_ld = TH.stride(1)
 
         def project(frame, theta, b):
             out = newest if theta is None else ring[:, frame % ring_n]
-            eng.project_frames(F[:, frame].data_ptr(), F.stride(0), None if theta is None else TH[:, frame].data_ptr(),
-                               TH.stride(0), b, out.data_ptr(), out.stride(0), pws)
+            eng.project_frames(F[:, frame].data_ptr(), F.stride(0), None if theta is None else TH[frame].data_ptr(),
+                               th_ld, b, out.data_ptr(), out.stride(0), pws)
         with on_device(dev):
             for t in range(T - 1):
                 project(t, True, C)
@@ -89,24 +94,21 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
         inp = torch.zeros(C, T, 2133, device=dev)
     for j in range(steps[0]):
         b = sum(1 for s in steps if s > j)                # active clips form the prefix [0, b)
-        if use_cache:
-            with on_device(dev):
+        out = {k: v[j] for k, v in bufs.items()}
+        out['theta'] = TH[j + T - 1]                      # feeds the next windows
+        with on_device(dev):
+            if use_cache:
                 if j > 0:
                     project(j + T - 2, True, b)           # previous newest frame, theta now known
                 project(j + T - 1, None, b)               # newest frame, theta slots zero
-                pred = eng.forward_cached(ring, j % ring_n, newest, b, T, J_regressor)
-        else:
-            x = inp[:b]
-            x[:, :, :2048] = F[:b, j:j + T]
-            x[:, :T - 1, 2048:] = TH[:b, j:j + T - 1]     # last frame's theta stays zero
-            pred = model(x, J_regressor=J_regressor)[0]
-        TH[:b, j + T - 1] = pred['theta']                 # feeds the next windows
-        for k in keep:
-            if k not in bufs:
-                bufs[k] = torch.empty((C, steps[0]) + tuple(pred[k].shape[1:]), device=dev)
-            bufs[k][:b, j] = pred[k]
+                eng.forward_cached(ring, j % ring_n, newest, b, T, J_regressor, out=out)
+            else:
+                x = inp[:b]
+                x[:, :, :2048] = F[:b, j:j + T]
+                x[:, :T - 1, 2048:] = TH[j:j + T - 1, :b].transpose(0, 1)     # last frame's theta stays zero
+                eng.forward(x, J_regressor, out=out)
     for s, i in enumerate(order):
-        results[i] = {k: bufs[k][s, :steps[s]].clone() for k in keep}
+        results[i] = {k: (TH[T - 1:T - 1 + steps[s], s] if k == 'theta' else bufs[k][:steps[s], s]).clone() for k in keep}
     return results
 
 

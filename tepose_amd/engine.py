@@ -383,15 +383,32 @@ class Engine:
             'rotmat': torch.empty((N, 24, 3, 3), dtype=torch.float32, device=dev),
         }
 
-    def forward(self, x, J_regressor):
+    def _out_views(self, out, B, nj, dev):
+        """The five output tensors of a forward: fresh ones, or the caller's (`out`: dict key -> contiguous fp32 cuda tensor whose first B rows are
+        written -- the clip drivers hand in slices of their result buffers, so that a window step costs no copy); keys the caller leaves out are fresh."""
+        if out is None:
+            return self._outputs(B, nj, dev)
+        shapes = {'theta': (85,), 'verts': (NUM_VERTS, 3), 'kp_2d': (nj, 2), 'kp_3d': (nj, 3), 'rotmat': (24, 3, 3)}
+        res = {}
+        for k, tail in shapes.items():
+            t = out.get(k)
+            if t is None:
+                t = torch.empty((B,) + tail, dtype=torch.float32, device=dev)
+            elif not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] >= B and tuple(t.shape[1:]) == tail):
+                raise ValueError('out[%r] must be a contiguous fp32 tensor on %s of shape [>= %d, %s], got %s %s' % (k, dev, B, tail, tuple(t.shape), t.dtype))
+            res[k] = t[:B]
+        return res
+
+    def forward(self, x, J_regressor, out=None):
         B, T = x.shape[:2]
         dev = x.device
         ws = self.workspace(B, T, dev)
         _, jp = self.jreg(J_regressor, dev)
         nj = 14 if J_regressor is not None else 49
+        given = out
 
         def call():
-            out = self._outputs(B, nj, dev)
+            out = self._out_views(given, B, nj, dev)
             _lib.check(self.lib.tepose_forward(
                 self.handle, x.data_ptr(), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
                 out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(),
@@ -421,15 +438,16 @@ class Engine:
                                                   out_ld, ws.data_ptr(), ws.numel(), self._stream()),
                    'tepose_project_frames')
 
-    def forward_cached(self, ring, first_slot, newest, B, T, J_regressor):
-        """ring [C, R, 9Hp], newest [C, 9Hp] (rows [0,B) used) -> output dict like forward()."""
+    def forward_cached(self, ring, first_slot, newest, B, T, J_regressor, out=None):
+        """ring [C, R, 9Hp], newest [C, 9Hp] (rows [0,B) used) -> output dict like forward(); `out`: see _out_views."""
         dev = ring.device
         ws = self.workspace(B, T, dev)
         _, jp = self.jreg(J_regressor, dev)
         nj = 14 if J_regressor is not None else 49
+        given = out
 
         def call():
-            out = self._outputs(B, nj, dev)
+            out = self._out_views(given, B, nj, dev)
             _lib.check(self.lib.tepose_forward_cached(
                 self.handle, ring.data_ptr(), ring.shape[1], int(first_slot), ring.stride(0), newest.data_ptr(),
                 newest.stride(0), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(), out['kp_3d'].data_ptr(),
