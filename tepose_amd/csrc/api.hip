@@ -388,7 +388,10 @@ struct EncWs {
 // Arrival counters of the persistent kernels (gru_seq.hip, reg_seq.hip), ONE block zeroed by one memset node per
 // forward.  It is the first carve of the encoder's and of the regressor's workspace, so that inside tepose_forward
 // (both share one region) it is the same memory: [L x 3 x 32 recurrent arrivals | 32 status | 3 x 32 regressor | 32 status].
-inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32; }
+inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32 + 4 * 256; }
+// (the last 4 x 256 words: progress lines of up to four barrier-free projection launches of a forward -- layer 0, then three of layers >= 1 -- for the
+// bounded-drift experiment, H3SArgs::throttle; zeroed with the rest of the region by the forward's first kernel)
+inline unsigned* sync_throttle(const tepose_model* m, unsigned* sy, int k) { return sy + (size_t)m->L * 96 + 32 + 96 + 32 + (size_t)(k & 3) * 256; }
 // floats of the granule buffers: [3 directions][2 buffers][16 rows][Hp] uint64, only where the persistent kernel can run
 inline size_t seq_gran_words(const tepose_model* m, int B) {
   return (m->split && B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
@@ -1785,6 +1788,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
       a.c_blk_hp = g0blk ? Hp : 0;
+      if (w.sync) a.throttle = sync_throttle(m, w.sync, 0);
       if (g0mid) CK(launch_gemm_h3s_mid(a, s));
       else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {

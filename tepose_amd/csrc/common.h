@@ -332,6 +332,7 @@ struct H3SArgs {
   unsigned* fault = nullptr;
   unsigned inject = 0;                   // tests: added to every poll target (1 = no poll can ever be met)
   int c_blk_hp = 0;                      // != 0 (= Hp): C is a [rows][3 Hp] gate pre-activation matrix, written in the blocked layout (gi_blk_offset)
+  unsigned* throttle = nullptr;          // experiment builds (-DTEPOSE_C_THROTTLE): [8 XCDs][32] progress words of this launch, zero at launch
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // every plain scaled-plane product of large batches (tag 0: the layer-0 projection: own kernel symbol for profiles)

@@ -6,7 +6,8 @@ encoder features in both modes for every configuration, the full forward for B <
 Not collected by pytest (it runs for as long as it is told to); round 1: about 1 900 configurations in four runs (498 in
 15 min on the final binary), worst absolute error 2.0e-6, none over the test tolerances (2e-5 features, 1e-4 outputs); round 3's
 final binary: 322 configurations in 15 min, worst 1.9e-6; round 4 (16x16x32 kernels, barrier-free projection): 260 configurations in 15 min, worst 1.9e-6; round 4's final binary (blocked layouts, scaled-format path from
-B = 640, full forwards up to B = 1300 against a random subset of the oracle's windows): 298 configurations in 14 min, 262 of them with the full forward, worst 2.4e-6."""
+B = 640, full forwards up to B = 1300 against a random subset of the oracle's windows): 298 configurations in 14 min, 262 of them with the full forward, worst 2.4e-6;
+round 5 (plane-fed step kernel, pruned dispatch): profiles/r05_README.md."""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
@@ -21,7 +22,7 @@ t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() +
 n = 0
 while time.time() < t_end:
     L = int(rng.choice([1, 2, 2, 3])); H = int(rng.choice([64, 100, 128, 192, 256, 320, 256, 512, 768, 1024]))   # % 256 == 0: persistent kernels
-    B = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 769, 1000, 1300, 2048, 2100, 4096, 4200]))
+    B = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 640, 768, 769, 1000, 1024, 1280, 1300, 2048, 2100, 4096, 4200]))   # % 128 == 0 from 640: the plane-fed step kernel
     T = int(rng.choice([1, 2, 3, 5, 6, 8, 16, 33]))
     if H >= 512 and B > 300:
         B = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 17, 32, 33, 48, 64, 65]))      # keep the fp64 oracle of big models affordable

@@ -43,8 +43,8 @@ def test_random_configurations_against_fp64_oracle():
     J = torch.from_numpy(smpl_np['J_regressor_h36m'])
     t0 = time.time()
     worst, n = 0.0, 0
-    Bs = [1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 769, 1000, 1300, 2048, 2100, 4096, 4200]
-    for i in range(36):
+    Bs = [1, 2, 3, 4, 5, 7, 16, 17, 31, 33, 48, 64, 65, 100, 128, 129, 200, 257, 400, 640, 769, 1000, 1280, 2048, 2100, 4096]   # % 128 == 0 from 640: the plane-fed step kernel
+    for i in range(30):
         L = int(rng.choice([1, 2, 2, 3]))
         H = int(rng.choice([64, 100, 128, 192, 256, 320]))
         B = int(Bs[i % len(Bs)] if i < len(Bs) else rng.choice(Bs))       # every batch class at least once
@@ -53,13 +53,13 @@ def test_random_configurations_against_fp64_oracle():
         e1, e2, e3 = _check(L, H, B, T, seed, smpl_np, J, full=B <= 300)
         assert max(e1, e2) < 2e-5 and e3 < 1e-4, (L, H, B, T, seed, e1, e2, e3)
         worst, n = max(worst, e1, e2, e3), n + 1
-        if time.time() - t0 > 55:                       # bounded: CI budget, the sweep order is deterministic
+        if time.time() - t0 > 40:                       # bounded: CI budget, the sweep order is deterministic
             break
     assert n >= 12, n
     print('fuzz: %d configurations, worst abs error %.2e, %.0f s' % (n, worst, time.time() - t0))
 
 
-@pytest.mark.parametrize('B,T', [(64, 16), (64, 6), (2048, 2), (4096, 2), (37, 6), (16, 16), (128, 4)])
+@pytest.mark.parametrize('B,T', [(64, 16), (64, 6), (2048, 2), (37, 6), (16, 16), (128, 4), (640, 3)])
 def test_published_architecture_batches_against_fp64_oracle(B, T):
     """n_layers = 2, hidden = 1024 (the published checkpoints): BASELINE.json config 2's shape (B = 64, T = 16), the
     37-clip lock-step shape of the 3DPW-test evaluation, and the batch thresholds of the large-batch kernels."""

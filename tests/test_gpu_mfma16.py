@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # (L, H, B, T): row tiles of 128 full (B % 128 == 0: the `planes` step kernel) and ragged (the fp32-state kernel at every knob), 1 / 2 / 3 layers (2- and
 # 3-direction step launches), hidden sizes whose unit tiles (64) do not fill the 4 x 8 walk, B at / just above the scaled-format threshold, long windows
-SHAPES = [(2, 1024, 2304, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (3, 512, 2048, 2), (2, 256, 4096, 4), (2, 128, 640, 16), (3, 64, 1280, 7)]
+SHAPES = [(2, 1024, 2304, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (3, 512, 2048, 2), (2, 256, 4096, 4), (2, 128, 640, 16)]
 
 
 @pytest.mark.parametrize('knobs', [{'TEPOSE_GRU_STATE': 'fp32'}, {'TEPOSE_LARGE_BATCH_KERNELS': 'twoacc'}])
