@@ -222,6 +222,12 @@ size_t tepose_project_frames_workspace_bytes(const tepose_model* m, int B);
 int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld, const float* theta,
                           long theta_ld, int B, float* out, long out_ld, void* workspace,
                           size_t ws_bytes, void* stream);
+/* Both projections of one window step in one call (the previous newest frame with its now-known theta -> out_prev rows, the newest frame with zero
+ * theta -> out_new rows): ONE product of 2 B rows, so the layer-0 weights are streamed once per step.  Results identical to two
+ * tepose_project_frames calls.  workspace >= tepose_project_frames_workspace_bytes(m, 2 * B).                                          */
+int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
+                              long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
+                              size_t ws_bytes, void* stream);
 /* TePose.forward for the window whose first frame sits in ring slot `first_slot`; clip b's ring
  * starts at ring_base + b*clip_stride; newest frame's row at newest + b*newest_ld.  Outputs and
  * workspace as tepose_forward.  Saves the T-fold re-projection (42 % of the FLOPs at T = 16).  */

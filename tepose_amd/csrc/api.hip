@@ -388,10 +388,7 @@ struct EncWs {
 // Arrival counters of the persistent kernels (gru_seq.hip, reg_seq.hip), ONE block zeroed by one memset node per
 // forward.  It is the first carve of the encoder's and of the regressor's workspace, so that inside tepose_forward
 // (both share one region) it is the same memory: [L x 3 x 32 recurrent arrivals | 32 status | 3 x 32 regressor | 32 status].
-inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32 + 4 * 256; }
-// (the last 4 x 256 words: progress lines of up to four barrier-free projection launches of a forward -- layer 0, then three of layers >= 1 -- for the
-// bounded-drift experiment, H3SArgs::throttle; zeroed with the rest of the region by the forward's first kernel)
-inline unsigned* sync_throttle(const tepose_model* m, unsigned* sy, int k) { return sy + (size_t)m->L * 96 + 32 + 96 + 32 + (size_t)(k & 3) * 256; }
+inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32; }
 // floats of the granule buffers: [3 directions][2 buffers][16 rows][Hp] uint64, only where the persistent kernel can run
 inline size_t seq_gran_words(const tepose_model* m, int B) {
   return (m->split && B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
@@ -1788,8 +1785,8 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
       a.c_blk_hp = g0blk ? Hp : 0;
-      if (w.sync) a.throttle = sync_throttle(m, w.sync, 0);
-      if (g0mid) CK(launch_gemm_h3s_mid(a, s));
+      static const bool mid16c = [] { const char* e = getenv("TEPOSE_G0_MID_KERNEL"); return e && std::string(e) == "persist16c"; }();   // A/B
+      if (g0mid && !mid16c) CK(launch_gemm_h3s_mid(a, s));
       else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {
       H3Batch b{};
@@ -1870,6 +1867,43 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
   }
   GemmArgs g = gemm(xp, kInputP, m->blob + m->wih0, kInputP, out, out_ld, m->blob + m->bih0, B, 9 * m->Hp);
   CK(launch_gemm(g, s));
+  return 0;
+}
+
+// Both projections of a window step of the clip driver as ONE product of 2 B rows (rows [0, B): the previous newest frame with its now-known theta ->
+// its ring slot; rows [B, 2 B): the newest frame with zero theta -> the `newest` rows): the 79 MB of layer-0 W_ih planes are streamed once per
+// step instead of twice, one input split instead of two.  Same GEMM rows as two tepose_project_frames calls: identical results.
+int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
+                              long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
+                              size_t ws_bytes, void* stream) {
+  if (!m || m->kind != 0 || !feat_prev || !feat_new || !theta_prev || !out_prev || !out_new || !workspace || B < 1) return TEPOSE_E_ARG;
+  if (!m->enc_packed) return TEPOSE_E_STATE;
+  if (ws_bytes < tepose_project_frames_workspace_bytes(m, 2 * B)) return TEPOSE_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int M = 2 * B;
+  const bool h3 = m->split && M > split_min_m();
+  if (!h3 || M > skinny_max_m()) {            // exact-fp32 handles / more rows than the width-first kernel takes: the two products one after the other
+    int rc = tepose_project_frames(m, feat_prev, feat_ld, theta_prev, theta_ld, B, out_prev, out_prev_ld, workspace, ws_bytes, stream);
+    if (rc) return rc;
+    return tepose_project_frames(m, feat_new, feat_ld, nullptr, 0, B, out_new, out_new_ld, workspace, ws_bytes, stream);
+  }
+  float* xp = (float*)workspace;
+  CK(launch_pad_rows(feat_prev, feat_ld, theta_prev, theta_ld, xp, B, s));
+  CK(launch_pad_rows(feat_new, feat_ld, nullptr, 0, xp + (size_t)B * kInputP, B, s));
+  const size_t xbytes = align_up((size_t)M * kInputP * sizeof(float), 256);
+  half_t* hi = (half_t*)((char*)workspace + xbytes);
+  half_t* lo = (half_t*)((char*)workspace + xbytes + xbytes / 2);
+  float* rs = (float*)((char*)workspace + 2 * xbytes + 512);
+  CK(launch_split_rows(xp, kInputP, M, kInputP, kInputP, M, 0, hi, lo, rs, s));
+  const int Np = round_up(9 * m->Hp, 128);
+  const half_t* wh = (const half_t*)(m->blob + m->wih0_p);
+  H3Args p{};
+  p.Ah = hi; p.Al = lo; p.a_kst = (long)M * 32;
+  p.Wh = wh; p.Wl = wh + (size_t)Np * kInputP; p.w_kst = (long)Np * 32; p.Kp = kInputP;
+  p.C = out_prev; p.ldc = out_prev_ld; p.bias = m->blob + m->bih0; p.M = M; p.N = 9 * m->Hp;
+  p.row_scale = rs;
+  p.C2 = out_new; p.ldc2 = out_new_ld; p.c_split = B;
+  CK(launch_skinny_gemm_h3(p, s));
   return 0;
 }
 
@@ -2179,11 +2213,12 @@ int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const
   // TEPOSE_H3S=1 (read per call: this is the test / bench entry): the scaled-plane barrier-free kernel of gemm_h3s16c.hip, operand scales for
   // the ranges of tools/h3_loop.py / h3_bench.py and tests/test_gpu_stress.py; TEPOSE_H3S=mid: the 128 x 288-tile kernel of gemm_h3s.hip (N % 288 == 0)
   const char* pe = getenv("TEPOSE_H3S");
-  if (pe && pe[0] && std::string(pe) != "0" && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
+  if (pe && pe[0] && std::string(pe) != "0" && std::string(pe).rfind("skinny", 0) != 0 && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
     CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, bias, std::string(pe) == "mid" ? 1 : 0));
     return 0;
   }
-  CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream));
+  // TEPOSE_H3S=skinny: the width-first kernel of skinny_h3.hip on the same planes, at any M (tools/mid_rows_gemm_bench.py)
+  CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream, pe && std::string(pe) == "skinny" ? 1 : 0));
   return 0;
 }
 

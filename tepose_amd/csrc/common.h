@@ -189,6 +189,9 @@ struct H3Args {
   // m % grp_rows of A and C -- the time slabs of the state buffers are padded to 16 rows, and at B = 1 fifteen of
   // every sixteen rows are padding that a product over the physical rows would stream W against
   int grp_rows, grp_stride;           // 0: identity
+  // optional second destination (width-first kernel only; no planes out, no addend): rows >= c_split are written to C2 + (row - c_split) * ldc2 instead --
+  // two row groups of ONE product land in two differently strided buffers (the clip driver's cached projections: ring slot + newest-frame row)
+  float* C2; long ldc2; int c_split;  // C2 == nullptr: none
 };
 struct GateDir {
   const float* gi; long ldgi;         // x W_ih^T + b_ih, [row*ldgi + g*Hp + j]
@@ -309,7 +312,7 @@ hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp
                              float* row_scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0,
                              int permT = 0);   // permT = T: source rows [B][T] -> plane rows / row_scale frame-major (t * B + b)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
-                              long ldc, int M, int N, int K, void* ws, hipStream_t s);
+                              long ldc, int M, int N, int K, void* ws, hipStream_t s, int kind = 0);
 size_t gemm_h3_ws_bytes(int M, int N, int K);
 // gemm_h3s.hip: single accumulator, 256 x 256 tiles, scaled planes in the [K/16][R][16] layout:
 // element (row, k) of an [R x Kp] matrix (Kp multiple of 16), value v stored as hi = fp16(v p), lo = fp16(v p - hi)
@@ -332,7 +335,6 @@ struct H3SArgs {
   unsigned* fault = nullptr;
   unsigned inject = 0;                   // tests: added to every poll target (1 = no poll can ever be met)
   int c_blk_hp = 0;                      // != 0 (= Hp): C is a [rows][3 Hp] gate pre-activation matrix, written in the blocked layout (gi_blk_offset)
-  unsigned* throttle = nullptr;          // experiment builds (-DTEPOSE_C_THROTTLE): [8 XCDs][32] progress words of this launch, zero at launch
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
 hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // every plain scaled-plane product of large batches (tag 0: the layer-0 projection: own kernel symbol for profiles)

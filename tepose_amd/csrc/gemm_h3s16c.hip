@@ -21,13 +21,14 @@
 // No wave waits for anything but its own workgroup's waves, which are resident by construction, so the polls cannot hang; they are
 // bounded all the same (a wave that gives up writes NaN to C[0], raises a counter that tepose_debug_kernel_errors() reads, and sets the
 // forward's status word / the handle's fault word: H3SArgs::status, ::fault -- the library's failure channel, include/tepose_amd.h).
+// Round 5, tried and removed (profiles/r05_throttle_ab.txt): a bounded-drift throttle between the 32 workgroups of an XCD -- every 4 pairs
+// wave 0 published the workgroup's pair count in its XCD's line of a progress array and looked, asynchronously, at the line fetched 4 pairs earlier; a workgroup
+// more than D pairs ahead of a peer slept.  Layer-0 projection, same box: no throttle 10.64 ms, D = 6: 11.15, D = 12: 10.76, D = 24: 10.77 -- the sleeping
+// leaders cost more than the shared panels they keep in L2 save (as the per-tile rendezvous of round 4 did).
 // Gate pre-activation outputs (H3SArgs::c_blk_hp) are written in the 16 x 16-blocked layout of common.h gi_blk_offset: the lane order
 // of this kernel's C fragment IS that layout's block order, so every tile store is one contiguous KB.
 #include "common.h"
 
-#ifndef TEPOSE_C_THROTTLE
-#define TEPOSE_C_THROTTLE 0   // round-5 experiment: > 0 = bounded drift between the 32 workgroups of an XCD -- a workgroup more than this many
-#endif                       // pairs of K-tiles ahead of the slowest one of its XCD sleeps (no rendezvous, no spin on the critical path); needs H3SArgs::throttle
 #ifndef TEPOSE_C_VAR
 #define TEPOSE_C_VAR 5     // A/B builds (bits 0-1: where the landing is confirmed: 0 after Q2, 1 after Q1, 2 after Q3; bit 2: the requests
 #endif                     // between the MFMAs of Q0 instead of one burst at the top).  5 = the measured best
@@ -181,31 +182,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
   int pt = 0, gp = 0;
   int tm0 = m0, tn0 = n0;
-#if TEPOSE_C_THROTTLE > 0
-  // Bounded drift (experiment): without barriers and launch boundaries the 32 workgroups of an XCD drift apart, and a panel they share has left the
-  // 4 MB L2 when the last of them asks for it (beyond-L2 traffic 4.8x algorithmic).  Every 4 pairs wave 0 publishes the workgroup's pair count in
-  // its XCD's line of a.throttle ([xcd][32] words, zero at launch) and looks at the line it fetched 4 pairs ago (asynchronously: the load rides
-  // under the pairs in between, its data is covered by the s_waitcnt vmcnt(0) of a landing confirmation) -- only a workgroup that finds itself more
-  // than TEPOSE_C_THROTTLE pairs ahead of a peer re-reads the line in a sleep loop (bounded).  The other waves follow through the LDS counters.
-  const bool thr_on = a.throttle != nullptr && gridDim.x == 256 && wave == 0;
-  unsigned* thr_line = thr_on ? a.throttle + (blockIdx.x & 7) * 32 : nullptr;
-  unsigned thr_peer = 0x7fffffffu;
-  const int thr_lane = lane & 31;
-#endif
   for (;;) {
-#if TEPOSE_C_THROTTLE > 0
-    if (thr_on && (gp & 3) == 0) {
-      asm volatile("" : "+v"(thr_peer));                   // (requested 4 pairs ago; landed: every interval in between executed s_waitcnt vmcnt(0))
-      int tries = 0;
-      while (__builtin_amdgcn_ballot_w64((int)((unsigned)gp - thr_peer) > TEPOSE_C_THROTTLE) != 0ull && tries < 256) {
-        __builtin_amdgcn_s_sleep(32);
-        thr_peer = __hip_atomic_load(thr_line + thr_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ++tries;
-      }
-      if (lane == 0) __hip_atomic_store(thr_line + (blockIdx.x >> 3), (unsigned)gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(thr_peer) : "v"(thr_line + thr_lane) : "memory");
-    }
-#endif
     poll(gp & 1, 8 * (gp / 2 + 1));
     if (dead) break;
     // the next pair in request order: this tile's, or the first one of this workgroup's next tile
@@ -334,9 +311,6 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
 #undef TEPOSE_C_READ_A
 #undef TEPOSE_C_READ_B
 #undef TEPOSE_C_WAIT_B
-#if TEPOSE_C_THROTTLE > 0
-  if (thr_on && lane == 0) __hip_atomic_store(thr_line + (blockIdx.x >> 3), 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done: nobody waits for this workgroup
-#endif
   if (dead && lane == 0) {                                   // never a plausible-looking wrong result with rc 0: NaN + the failure channel
     if (err) atomicAdd(err, 1u);
     a.C[0] = __builtin_nanf("");

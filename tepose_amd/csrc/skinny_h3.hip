@@ -249,7 +249,8 @@ __global__ void __launch_bounds__(64 * NW) skinny_gemm_h3_kernel(H3ArgsBatch bat
         if (a.bias) v += a.bias[col];
         if (a.addend) v += a.addend[row * a.ldadd + col];
         v *= sc;
-        a.C[row * a.ldc + col] = v;
+        if (a.C2 && row >= a.c_split) a.C2[(row - a.c_split) * a.ldc2 + col] = v;
+        else a.C[row * a.ldc + col] = v;
         if (a.Chi) {
           const long o = (long)(col >> 5) * a.c_kst + plane_index(row, col & 31, 0);
           split_hi_lo(v, a.Chi[o], a.Clo[o]);

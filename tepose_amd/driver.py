@@ -80,8 +80,9 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
         ring_n = max(T - 1, 1)
         ring = torch.empty(C, ring_n, eng.gate_width, device=dev)
         newest = torch.empty(C, eng.gate_width, device=dev)
-        pws = torch.empty(int(eng.lib.tepose_project_frames_workspace_bytes(eng.handle, C)), dtype=torch.uint8, device=dev)
+        pws = torch.empty(int(eng.lib.tepose_project_frames_workspace_bytes(eng.handle, 2 * C)), dtype=torch.uint8, device=dev)
         th_ld = TH.stride(1)
+        pair = os.environ.get('TEPOSE_DRIVER_PAIR', '1') != '0'      # A/B: 0 = the two projections of a step as two products
 
         def project(frame, theta, b):
             out = newest if theta is None else ring[:, frame % ring_n]
@@ -98,9 +99,16 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
         out['theta'] = TH[j + T - 1]                      # feeds the next windows
         with on_device(dev):
             if use_cache:
-                if j > 0:
-                    project(j + T - 2, True, b)           # previous newest frame, theta now known
-                project(j + T - 1, None, b)               # newest frame, theta slots zero
+                if j > 0 and not pair:
+                    project(j + T - 2, True, b)
+                    project(j + T - 1, None, b)
+                elif j > 0:
+                    # previous newest frame (theta now known) -> its ring slot, newest frame (theta slots zero) -> `newest`: ONE product of 2 b rows
+                    fp, fn = j + T - 2, j + T - 1
+                    eng.project_frame_pair(F[:, fp].data_ptr(), F[:, fn].data_ptr(), F.stride(0), TH[fp].data_ptr(), th_ld, b,
+                                           ring[:, fp % ring_n].data_ptr(), ring.stride(0), newest.data_ptr(), newest.stride(0), pws)
+                else:
+                    project(j + T - 1, None, b)           # newest frame, theta slots zero
                 eng.forward_cached(ring, j % ring_n, newest, b, T, J_regressor, out=out)
             else:
                 x = inp[:b]

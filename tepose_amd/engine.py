@@ -438,6 +438,11 @@ class Engine:
                                                   out_ld, ws.data_ptr(), ws.numel(), self._stream()),
                    'tepose_project_frames')
 
+    def project_frame_pair(self, feat_prev_ptr, feat_new_ptr, feat_ld, theta_prev_ptr, theta_ld, B, out_prev_ptr, out_prev_ld, out_new_ptr, out_new_ld, ws):
+        _lib.check(self.lib.tepose_project_frame_pair(self.handle, feat_prev_ptr, feat_new_ptr, feat_ld, theta_prev_ptr, theta_ld, B, out_prev_ptr,
+                                                      out_prev_ld, out_new_ptr, out_new_ld, ws.data_ptr(), ws.numel(), self._stream()),
+                   'tepose_project_frame_pair')
+
     def forward_cached(self, ring, first_slot, newest, B, T, J_regressor, out=None):
         """ring [C, R, 9Hp], newest [C, 9Hp] (rows [0,B) used) -> output dict like forward(); `out`: see _out_views."""
         dev = ring.device

@@ -7,11 +7,25 @@ acceleration error and MPVPE are taken per frame (evaluate.py:394-457).  Clips a
 each rank processes its share (tepose_amd.distributed.partition_clips), all its clips in
 lock-step, and rank 0 gathers one fixed-size record per clip.
 """
+import numpy as np
 import torch
 
 from . import distributed as D
 from . import metrics as M
 from .driver import run_clips
+
+
+def _to_device(a, dev, n=None):
+    """Host array (numpy or CPU tensor, any float type) -> contiguous fp32 device tensor of its first n rows.  The conversion runs in
+    numpy on the calling thread: a torch CPU op on a few hundred KB wakes the whole intra-op thread pool, and on a host whose CPU quota
+    is smaller than its core count (containers) the spinning pool gets the process throttled for the rest of the scheduler period --
+    measured as random 40-90 ms stalls, several per evaluation (profiles/r05_eval_stalls.txt)."""
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    a = np.asarray(a)
+    if n is not None:
+        a = a[:n]
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
 
 
 def mpii3d_valid_map(valid_i, n_pred):
@@ -30,7 +44,7 @@ def clip_metric_record(model, clip_id, clip, pred_j3d, pred_verts, dataset='3dpw
     pred_j3d [N, 49 | 14, 3], pred_verts [N, 6890, 3] = bootstrap frames + window predictions of ONE clip.
     Returns the clip's [8] record (metrics.clip_record) or None when the reference skips the clip."""
     dev = pred_j3d.device
-    target = torch.as_tensor(clip['joints3D'], dtype=torch.float32, device=dev)[:pred_j3d.shape[0]]   # evaluate.py:302
+    target = _to_device(clip['joints3D'], dev, pred_j3d.shape[0])                                      # evaluate.py:302
     valid_map = None
     if dataset == 'mpii3d':
         idx = torch.tensor(M.SPIN_TO_MPII3D_TEST, device=dev)
@@ -44,8 +58,8 @@ def clip_metric_record(model, clip_id, clip, pred_j3d, pred_verts, dataset='3dpw
     mpvpe = None
     if dataset == '3dpw':                                                   # evaluate.py:454-455
         n = pred_verts.shape[0]
-        tt = torch.cat([torch.zeros(n, 3), torch.as_tensor(clip['pose'], dtype=torch.float32)[:n],
-                        torch.as_tensor(clip['shape'], dtype=torch.float32)[:n]], dim=1).to(dev)
+        pose, shape = np.asarray(clip['pose'], dtype=np.float32)[:n], np.asarray(clip['shape'], dtype=np.float32)[:n]
+        tt = _to_device(np.concatenate([np.zeros((len(pose), 3), np.float32), pose, shape], axis=1), dev)
         mpvpe = M.vertex_metric(pred_verts, M.gt_vertices(model, tt))
     return M.clip_record(clip_id, m, mpvpe=mpvpe, valid_map=valid_map)
 
@@ -62,8 +76,8 @@ def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='
     mine = [i for i in mine if lengths[i] >= T]                       # evaluate.py:226-227
     if not mine:
         return torch.zeros(0, 8, dtype=torch.float64, device=dev), mine
-    feats = [torch.as_tensor(clips[names[i]]['features'], dtype=torch.float32, device=dev) for i in mine]
-    inits = [torch.as_tensor(clips[names[i]]['theta_pseu'][:T - 1], dtype=torch.float32, device=dev) for i in mine]
+    feats = [_to_device(clips[names[i]]['features'], dev) for i in mine]
+    inits = [_to_device(clips[names[i]]['theta_pseu'], dev, T - 1) for i in mine]
     # bootstrap: VIBE over the first T frames of every clip, keep frames 0..T-2 (evaluate.py:233-245)
     boot = model_vibe(torch.stack([f[:T] for f in feats]), J_regressor=J_regressor)[-1]
     seq = run_clips(model, feats, inits, T, J_regressor=J_regressor, keep=('kp_3d', 'verts'))
