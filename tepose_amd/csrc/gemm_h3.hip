@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
 
 // test / bench entry: fp32 A[M,K], W[N,K] -> planes in `ws` -> C (K multiple of 32)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
-                              long ldc, int M, int N, int K, void* ws, hipStream_t s) {
+                              long ldc, int M, int N, int K, void* ws, hipStream_t s, int kind) {
   const int Np = round_up(N, 128);
   const long Ra = M, Rw = Np;
   char* p = (char*)ws;
@@ -741,6 +741,7 @@ hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw
   b.p[0] = H3Args{(const half_t*)Ah, (const half_t*)Al, Ra * 32, (const half_t*)Wh, (const half_t*)Wl, Rw * 32, K,
                   C, ldc, bias, M, N};
   b.n = 1;
+  if (kind) return launch_skinny_gemm_h3(b.p[0], s);      // test / bench entry: the width-first kernel at any M
   return launch_gemm_h3(b, s);
 }
 
@@ -766,6 +767,17 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
   if (b.p[0].M <= 2048 && tilesM * tilesN * b.n < 1024) {     // few rows and < 4 rounds of 256-row tiles: 128-row
     // tiles quantise better (B=64: layer-0 projection 288 -> 576 tiles; B=64 forward 0.95 -> 0.89 ms)
     const int tm = (b.p[0].M + 127) / 128;
+    // ... and 64-row tiles (4 waves, 72 KB ring: two workgroups per CU) where they need fewer rounds of the chip.  Measured per round at K = 2144
+    // (profiles/r05_mid_rows_gemm.txt): a 128-row tile 47 us, one workgroup per CU; a 64-row tile 33 us, and 33 us x workgroups / 256 once they share
+    // CUs.  444 x 9216: 97.8 -> 62.8 us; 128 x 9216: 44.9 -> 34.4; 288 x 3072: 44.0 -> 33.2; 1024 x 3072 stays (49.2 against 53.0).
+    static const int t64 = [] { const char* e = getenv("TEPOSE_H3_TILE64"); return e ? atoi(e) : 1; }();     // 0: never (A/B)
+    const int tm64 = (b.p[0].M + 63) / 64;
+    const double w128 = (double)tm * tilesN * b.n, w64 = (double)tm64 * tilesN * b.n;
+    const double c128 = 47. * (double)(long)((w128 + 255.) / 256.), c64 = 33. * (w64 > 256. ? w64 / 256. : 1.);
+    if (t64 && c64 < 0.9 * c128) {
+      hipLaunchKernelGGL((gemm_h3_kernel<1, 2, 3, false, false, 2>), dim3(tm64 * tilesN, b.n), dim3(256), 0, s, b, tm64, tilesN);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL((gemm_h3_kernel<1, 2, 3, false, false>), dim3(tm * tilesN, b.n), dim3(512), 0, s, b, tm, tilesN);
     return hipGetLastError();
   }
