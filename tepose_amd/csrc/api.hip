@@ -1872,7 +1872,9 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
 
 // Both projections of a window step of the clip driver as ONE product of 2 B rows (rows [0, B): the previous newest frame with its now-known theta ->
 // its ring slot; rows [B, 2 B): the newest frame with zero theta -> the `newest` rows): the 79 MB of layer-0 W_ih planes are streamed once per
-// step instead of twice, one input split instead of two.  Same GEMM rows as two tepose_project_frames calls: identical results.
+// step instead of twice, one input split (which gathers the rows itself) instead of two pads and two splits.  Same GEMM rows on the same operands as
+// two tepose_project_frames calls; the width-first kernel may split K over 4 or 8 waves depending on the row count, so results agree to rounding
+// (bit for bit at the published width).
 int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
                               long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
                               size_t ws_bytes, void* stream) {
@@ -1881,20 +1883,19 @@ int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, con
   if (ws_bytes < tepose_project_frames_workspace_bytes(m, 2 * B)) return TEPOSE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int M = 2 * B;
-  const bool h3 = m->split && M > split_min_m();
-  if (!h3 || M > skinny_max_m()) {            // exact-fp32 handles / more rows than the width-first kernel takes: the two products one after the other
+  const bool h3 = m->split && B > split_min_m();       // (B, not 2 B: the same arithmetic class as tepose_project_frames at this B)
+  if (!h3 || M > skinny_max_m()) {            // exact-fp32 products / more rows than the width-first kernel takes: the two products one after the other
     int rc = tepose_project_frames(m, feat_prev, feat_ld, theta_prev, theta_ld, B, out_prev, out_prev_ld, workspace, ws_bytes, stream);
     if (rc) return rc;
     return tepose_project_frames(m, feat_new, feat_ld, nullptr, 0, B, out_new, out_new_ld, workspace, ws_bytes, stream);
   }
-  float* xp = (float*)workspace;
-  CK(launch_pad_rows(feat_prev, feat_ld, theta_prev, theta_ld, xp, B, s));
-  CK(launch_pad_rows(feat_new, feat_ld, nullptr, 0, xp + (size_t)B * kInputP, B, s));
   const size_t xbytes = align_up((size_t)M * kInputP * sizeof(float), 256);
   half_t* hi = (half_t*)((char*)workspace + xbytes);
   half_t* lo = (half_t*)((char*)workspace + xbytes + xbytes / 2);
   float* rs = (float*)((char*)workspace + 2 * xbytes + 512);
-  CK(launch_split_rows(xp, kInputP, M, kInputP, kInputP, M, 0, hi, lo, rs, s));
+  // the split kernel gathers the 2 B rows itself (features | theta, features | zeros): no padded fp32 copy, one launch instead of three
+  const RowPairSrc pr{feat_prev, theta_prev, feat_new, feat_ld, theta_ld, B};
+  CK(launch_split_rows(nullptr, 0, M, kInput, kInputP, M, 0, hi, lo, rs, s, nullptr, 0, 0, &pr));
   const int Np = round_up(9 * m->Hp, 128);
   const half_t* wh = (const half_t*)(m->blob + m->wih0_p);
   H3Args p{};

@@ -308,9 +308,12 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 // (hi = fp16(v), lo = fp16(v - hi)), else the blocked [K/32][R][32] format (lo = fp16((v - hi) * 2^11)).
 // zero / zero_bytes (multiple of 16): the kernel also clears that block -- the forward's arrival counters and granules,
 // when this is the forward's first kernel (saves the memset node).
+// optional gathered source of launch_split_rows (the clip driver's two per-step projections as one product): row r < B = features f0[r] | theta th0[r],
+// row r >= B = features f1[r - B] | zeros -- what two launch_pad_rows calls would have written to a padded buffer first (evaluate.py:248-252)
+struct RowPairSrc { const float* f0; const float* th0; const float* f1; long fld, thld; long B; };
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
                              float* row_scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0,
-                             int permT = 0);   // permT = T: source rows [B][T] -> plane rows / row_scale frame-major (t * B + b)
+                             int permT = 0, const RowPairSrc* pair = nullptr);   // permT = T: source rows [B][T] -> plane rows / row_scale frame-major (t * B + b)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                               long ldc, int M, int N, int K, void* ws, hipStream_t s, int kind = 0);
 size_t gemm_h3_ws_bytes(int M, int N, int K);

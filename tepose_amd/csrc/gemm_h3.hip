@@ -97,7 +97,7 @@ template <int NP, bool F16>
 __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ src, long ld, long rows, int K, int Kp,
                                                          long R, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                          float* __restrict__ row_scale, uint4* __restrict__ zero,
-                                                         long zero_n, int permT) {
+                                                         long zero_n, int permT, RowPairSrc pr) {
   typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float buf[8 * kRowsLd];
   // the forward's arrival counters / granules (first kernel of a forward: later kernels see them cleared)
@@ -111,15 +111,19 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     if (row >= rows) continue;                                // wave-uniform
     // permT = T: the source is [B][T] windows x frames, the planes (and row_scale) are FRAME-major: plane row t * B + b = source row b * T + t
     const long srow = permT ? (row % (rows / permT)) * permT + row / (rows / permT) : row;
-    const float* x = src + srow * ld;
+    // (pr.f0: the rows are gathered -- features | theta of one frame for rows < pr.B, features | zeros of another frame from there on: RowPairSrc)
+    const bool second = pr.f0 && row >= pr.B;
+    const float* x = pr.f0 ? (second ? pr.f1 + (row - pr.B) * pr.fld : pr.f0 + row * pr.fld) : src + srow * ld;
+    const float* xt = pr.f0 && !second ? pr.th0 + row * pr.thld - kFeat : nullptr;       // indexed by k >= kFeat
+    const int kf = pr.f0 ? kFeat : K;
     float v0[NP], v1[NP];
     float m = 0.f;
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int k = 2 * (lane + 64 * i);
-      v0[i] = k < K ? x[k] : 0.f;
-      v1[i] = k + 1 < K ? x[k + 1] : 0.f;
+      v0[i] = k < kf ? x[k] : (xt && k < K ? xt[k] : 0.f);
+      v1[i] = k + 1 < kf ? x[k + 1] : (xt && k + 1 < K ? xt[k + 1] : 0.f);
       m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));        // fmaxf drops NaN: tracked separately
       bad |= !(fabsf(v0[i]) <= 3.0e38f) || !(fabsf(v1[i]) <= 3.0e38f);
     }
@@ -180,13 +184,16 @@ template <bool F16>
 __global__ void __launch_bounds__(256) split_rows_few_kernel(const float* __restrict__ src, long ld, long rows, int K, int Kp,
                                                              long R, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                              float* __restrict__ row_scale, uint4* __restrict__ zero,
-                                                             long zero_n) {
+                                                             long zero_n, RowPairSrc pr) {
   typedef _Float16 h16x8v __attribute__((ext_vector_type(8)));
   __shared__ float wmax[4];
   __shared__ int wbad[4];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero[i] = uint4{0u, 0u, 0u, 0u};
   const long row = blockIdx.x;
-  const float* x = src + row * ld;
+  const bool second = pr.f0 && row >= pr.B;
+  const float* x = pr.f0 ? (second ? pr.f1 + (row - pr.B) * pr.fld : pr.f0 + row * pr.fld) : src + row * ld;
+  const float* xt = pr.f0 && !second ? pr.th0 + row * pr.thld - kFeat : nullptr;
+  const int kf = pr.f0 ? kFeat : K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NO = 2;                                        // octets per thread: Kp <= 4096
   float v[NO][8];
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(256) split_rows_few_kernel(const float* __rest
     const int k0 = 8 * ((int)threadIdx.x + 256 * o);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      v[o][i] = (k0 + i < K) ? x[k0 + i] : 0.f;
+      v[o][i] = (k0 + i < kf) ? x[k0 + i] : (xt && k0 + i < K ? xt[k0 + i] : 0.f);
       m = fmaxf(m, fabsf(v[o][i]));
       bad |= !(fabsf(v[o][i]) <= 3.0e38f);
     }
@@ -248,27 +255,29 @@ static int split_few_max_rows() {
 }
 
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
-                             float* row_scale, hipStream_t s, void* zero, size_t zero_bytes, int permT) {
+                             float* row_scale, hipStream_t s, void* zero, size_t zero_bytes, int permT, const RowPairSrc* pair) {
   if (rows <= 0) return hipSuccess;
+  const RowPairSrc pr = pair ? *pair : RowPairSrc{};
+  if (pair && (permT || !pr.f0 || !pr.f1 || !pr.th0 || K <= kFeat)) return hipErrorInvalidValue;
   if (permT && (rows % permT != 0 || rows <= split_few_max_rows())) return hipErrorInvalidValue;
   if (zero_bytes % 16 != 0) return hipErrorInvalidValue;
   if (Kp > 64 * 2 * 17 || Kp > kRowsLd || (Kp & 31)) return hipErrorInvalidValue;        // the [., 2144] input rows
   if (rows <= split_few_max_rows() && Kp <= 4096) {
     if (fmt16)
       hipLaunchKernelGGL((split_rows_few_kernel<true>), dim3((unsigned)rows), dim3(256), 0, s, src, ld, rows, K, Kp, R,
-                         (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
+                         (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), pr);
     else
       hipLaunchKernelGGL((split_rows_few_kernel<false>), dim3((unsigned)rows), dim3(256), 0, s, src, ld, rows, K, Kp, R,
-                         (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16));
+                         (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), pr);
     return hipGetLastError();
   }
   const dim3 grid((unsigned)((rows + 7) / 8));
   if (fmt16)
     hipLaunchKernelGGL((split_rows_kernel<17, true>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
-                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), permT);
+                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), permT, pr);
   else
     hipLaunchKernelGGL((split_rows_kernel<17, false>), grid, dim3(256), 0, s, src, ld, rows, K, Kp, R, (_Float16*)hi,
-                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), permT);
+                       (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), permT, pr);
   return hipGetLastError();
 }
 
@@ -773,7 +782,8 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
     static const int t64 = [] { const char* e = getenv("TEPOSE_H3_TILE64"); return e ? atoi(e) : 1; }();     // 0: never (A/B)
     const int tm64 = (b.p[0].M + 63) / 64;
     const double w128 = (double)tm * tilesN * b.n, w64 = (double)tm64 * tilesN * b.n;
-    const double c128 = 47. * (double)(long)((w128 + 255.) / 256.), c64 = 33. * (w64 > 256. ? w64 / 256. : 1.);
+    // (more than one 64-row workgroup per CU: the first sharing costs 1.55 rounds whatever the count -- 288 workgroups 51.8 us, 384: 53.0, 504: 62.8)
+    const double c128 = 47. * (double)(long)((w128 + 255.) / 256.), c64 = 33. * (w64 <= 256. ? 1. : (w64 / 256. > 1.55 ? w64 / 256. : 1.55));
     if (t64 && c64 < 0.9 * c128) {
       hipLaunchKernelGGL((gemm_h3_kernel<1, 2, 3, false, false, 2>), dim3(tm64 * tilesN, b.n), dim3(256), 0, s, b, tm64, tilesN);
       return hipGetLastError();

@@ -176,3 +176,35 @@ def test_padded_validation_batch_matches_reference_trainer_loop():
     out2 = validate_padded(model, target, T)
     assert out2['pred_kp_3d'].shape[0] == sum(max(n - T + 1, 0) for n in (lens[0], 0, lens[2], lens[3]))
     assert out2['pred_kp_3d'].shape[1] == 49
+
+
+@pytest.mark.parametrize('H,B', [(64, 1), (64, 3), (64, 20), (64, 37), (64, 100), (64, 500), (1024, 37)])
+def test_frame_pair_projection_is_the_two_projections(H, B, smpl_np):
+    """tepose_project_frame_pair (ONE product of 2 B gathered rows: previous newest frame with its theta -> ring slot, newest frame with zero theta -> the
+    `newest` rows; evaluate.py:248-252) against two tepose_project_frames calls.  The same GEMM rows on the same operands; what may differ is how many
+    waves the width-first kernel splits K over (4 or 8, by rows and width), i.e. the grouping of the partial sums: equal to rounding everywhere, and bit
+    for bit where both run the same instantiation (the published width) or fall back to the two calls (B <= 4: exact-fp32 kernels; 2 B > 768)."""
+    from tepose_amd.engine import on_device
+    from tepose_amd.testing import build_model
+    model, _, _ = build_model(2, H, seed=4, device='cuda', smpl_np=smpl_np)
+    eng = model._engine
+    dev = torch.device('cuda', 0)
+    w = torch.from_numpy(synth.synthetic_windows(B, 2, 31)).to(dev)              # [B, 2 frames, 2133]
+    F = w[:, :, :2048].contiguous()
+    TH = w[:, 0, 2048:].contiguous()
+    with on_device(dev):
+        eng.pack_encoder(model.encoder, dev)
+        gw = eng.gate_width
+        ws = torch.empty(int(eng.lib.tepose_project_frames_workspace_bytes(eng.handle, 2 * B)), dtype=torch.uint8, device=dev)
+        a_prev, a_new = torch.full((B, gw), float('nan'), device=dev), torch.full((B, 3, gw), float('nan'), device=dev)
+        b_prev, b_new = torch.full((B, gw), float('nan'), device=dev), torch.full((B, 3, gw), float('nan'), device=dev)
+        eng.project_frames(F[:, 0].data_ptr(), F.stride(0), TH.data_ptr(), TH.stride(0), B, a_prev.data_ptr(), a_prev.stride(0), ws)
+        eng.project_frames(F[:, 1].data_ptr(), F.stride(0), None, 0, B, a_new[:, 1].data_ptr(), a_new.stride(0), ws)
+        eng.project_frame_pair(F[:, 0].data_ptr(), F[:, 1].data_ptr(), F.stride(0), TH.data_ptr(), TH.stride(0), B, b_prev.data_ptr(), b_prev.stride(0),
+                               b_new[:, 1].data_ptr(), b_new.stride(0), ws)
+    torch.cuda.synchronize()
+    assert torch.isfinite(b_prev).all() and torch.isfinite(b_new[:, 1]).all()
+    assert float((a_prev - b_prev).abs().max()) < 5e-6 and float((a_new[:, 1] - b_new[:, 1]).abs().max()) < 5e-6
+    if B <= 4 or 2 * B > 768 or H == 1024:
+        assert torch.equal(a_prev, b_prev) and torch.equal(a_new[:, 1], b_new[:, 1])
+    assert torch.isnan(b_new[:, 0]).all() and torch.isnan(b_new[:, 2]).all()      # the strided destination: nothing beside its rows is touched
