@@ -223,8 +223,9 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
                           long theta_ld, int B, float* out, long out_ld, void* workspace,
                           size_t ws_bytes, void* stream);
 /* Both projections of one window step in one call (the previous newest frame with its now-known theta -> out_prev rows, the newest frame with zero
- * theta -> out_new rows): ONE product of 2 B rows, so the layer-0 weights are streamed once per step.  Results identical to two
- * tepose_project_frames calls.  workspace >= tepose_project_frames_workspace_bytes(m, 2 * B).                                          */
+ * theta -> out_new rows): ONE product of 2 B rows, so the layer-0 weights are streamed once per step.  The same GEMM rows on the same operands as two
+ * tepose_project_frames calls (equal to rounding: the width-first kernel may group the K partial sums differently at another row count; bit for bit at
+ * the published width); B <= 4 and 2 B > 768 run as those two calls.  workspace >= tepose_project_frames_workspace_bytes(m, 2 * B).     */
 int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
                               long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
                               size_t ws_bytes, void* stream);
