@@ -53,7 +53,7 @@ def test_random_configurations_against_fp64_oracle():
         e1, e2, e3 = _check(L, H, B, T, seed, smpl_np, J, full=B <= 300)
         assert max(e1, e2) < 2e-5 and e3 < 1e-4, (L, H, B, T, seed, e1, e2, e3)
         worst, n = max(worst, e1, e2, e3), n + 1
-        if time.time() - t0 > 40:                       # bounded: CI budget, the sweep order is deterministic
+        if time.time() - t0 > 30:                       # bounded: CI budget, the sweep order is deterministic
             break
     assert n >= 12, n
     print('fuzz: %d configurations, worst abs error %.2e, %.0f s' % (n, worst, time.time() - t0))

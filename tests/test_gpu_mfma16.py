@@ -51,7 +51,7 @@ def test_kernel_families_against_the_default_and_the_fp64_oracle(monkeypatch, kn
         if 'TEPOSE_GRU_STATE' in knobs and (B % 128 != 0 or L == 1):
             assert np.array_equal(fa, fb)                                 # ragged row tiles / a one-layer model: both handles run the fp32-state kernel
         enc, _ = O.split_state_dict(state, torch.float64)
-        rows = np.r_[0:40, B - 40:B]                                       # the first and the (possibly ragged) last row tile
+        rows = np.r_[0:12, B - 12:B]                                       # rows of the first and of the (possibly ragged) last row tile
         with torch.no_grad():
             ref = O.encoder_fwd(enc, torch.from_numpy(synth.synthetic_windows(B, T, 42)[rows]).double(), L).numpy()
         assert np.abs(fa[rows] - ref).max() < 2e-5, (L, H, B, T)
