@@ -1785,8 +1785,8 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
       a.c_blk_hp = g0blk ? Hp : 0;
-      static const bool mid16c = [] { const char* e = getenv("TEPOSE_G0_MID_KERNEL"); return e && std::string(e) == "persist16c"; }();   // A/B
-      if (g0mid && !mid16c) CK(launch_gemm_h3s_mid(a, s));
+      // (the barrier-free 256 x 256 kernel loses on mid-size batches: 1024 rows are 144 of its tiles -- 0.138 against 0.119 ms, profiles/r05_mid_rows_gemm.txt)
+      if (g0mid) CK(launch_gemm_h3s_mid(a, s));
       else CK(launch_gemm_h3s(a, s, 0));
     } else if (h3) {
       H3Batch b{};
