@@ -1,7 +1,7 @@
-// gemm_h3s_persist16c_kernel: the persistent scaled-plane product on v_mfma_f32_16x16x32_f16 (gemm_h3s16.hip) WITHOUT workgroup
-// barriers in its K loop (round 4; default for the plain products since: TEPOSE_MFMA16 bit 8).
+// gemm_h3s_persist16c_kernel: the persistent scaled-plane product on v_mfma_f32_16x16x32_f16 WITHOUT workgroup barriers in its K loop
+// (round 4; every plain product of large batches since; the barrier form it replaced was removed in round 5, DESIGN_history.md).
 //
-// What the stamps of the barrier form say (tools/s16_stamps.py): per pair of stages a wave spends 4776 cycles for 3072 of MFMA; the
+// What the stamps of the barrier form said (round 4, profiles/r04_shape_ab.txt): per pair of stages a wave spends 4776 cycles for 3072 of MFMA; the
 // two waves of a SIMD leave every barrier together, read their fragments together (matrix pipe idle) and multiply together.  Here the
 // eight waves of a workgroup are coupled only through DATA: per ring slot one LDS counter `landed` that every wave bumps when its own
 // share of a pair's LDS-DMA requests has landed.  A wave's interval for pair p:
@@ -14,7 +14,7 @@
 // No s_barrier: waves drift (half an interval before anybody waits), the partners on a SIMD fall into opposite phases -- one reads
 // fragments while the other multiplies.  Pairs run on across tiles (a tile is set up where its first pair is requested); the epilogue
 // is per wave (bias and row scales straight from global memory), so nothing synchronises at a tile boundary either.  Same fragments,
-// same K order, same accumulators as gemm_h3s_persist16_kernel: bit-identical results.
+// same K order, same accumulators as the barrier form had: its results were bit-identical.
 // Measured (profiles/r04_shape_ab.txt): MFMA pipes 71 % busy instead of 64 %, 1.76-1.79 GHz instead of 1.86-1.92 (the chip gives part
 // of it back), layer-0 projection 10.91 ms against 11.65 (same box, two rounds); where the landing is confirmed matters: after Q1
 // 10.91, after Q2 11.18, after Q3 11.56 (drift tolerance beats request lead time); requests in one burst at the top: 11.08.

@@ -366,7 +366,7 @@ hipError_t launch_lbs_compact(const float* lbsW, int* cidx, float* cval, int* ma
 // transforms are gathered from the LDS copy of A (3 x 16-byte reads per joint).  HBM-bound:
 // 12 B in + 12 B out per (person, vertex).
 #ifndef TEPOSE_SKIN_DIAG
-#define TEPOSE_SKIN_DIAG 0   // diagnostic builds only (tools/race_probe_smpl_diag.py): every wave of the skinning
+#define TEPOSE_SKIN_DIAG 0   // diagnostic builds only (the race probes of round 4, profiles/r04_packed_fp32_erratum.txt): every wave of the skinning
 #endif                       // kernel records when it ran and where (s_memrealtime at entry / exit, HW_ID at entry / exit)
 #if TEPOSE_SKIN_DIAG
 __device__ unsigned tepose_skin_check_buf[16 + 64 * 32];
