@@ -558,6 +558,10 @@ namespace {
 // (the predicates used to be spread over encoder_fwd_impl / encoder_core / carve_regressor as conjunctions of knob bits.)
 // Pure host function of (handle knobs, L, Hp, B, T): no device call, so tests/test_dispatch.py pins every class boundary on a machine without a GPU
 // (tepose_select_kernels).  The launch code below consumes these fields; nothing else decides a kernel family.
+inline int l1_skinny_max_rows() {
+  static const int v = [] { const char* e = getenv("TEPOSE_L1_SKINNY_MAX_ROWS"); return e ? atoi(e) : 192; }();
+  return v;
+}
 struct KernelPlan {
   bool h3 = false;            // split-precision kernels (split-mode handle, B > TEPOSE_SPLIT_MIN_M); else the exact-fp32 kernels of gemm.hip / skinny.hip
   bool scaled = false;        // large batch: recurrent-state planes in the scaled format, layer >= 1 projections and cell steps on the scaled-plane kernels
@@ -609,7 +613,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   const int L = m->L;
   const long BT = (long)B * T;
   std::string s = "input=";
-  s += !k.h3 ? "pad_input_kernel" : BT <= 64 ? "split_rows_few_kernel" : "split_rows_kernel";
+  s += !k.h3 ? "pad_input_kernel" : (BT <= split_few_max_rows() && !k.g0blk) ? "split_rows_few_kernel" : "split_rows_kernel";
   s += ";projection=";
   s += !k.h3 ? (BT <= skinny_max_m() ? "skinny_gemm_kernel" : "gemm_f32_kernel")
        : k.g0big ? "gemm_h3s_persist16c_kernel<0>" : k.g0mid ? "gemm_h3s_kernel<1, 3, 4, 3, 4>" : k.g0skinny ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel";
@@ -624,7 +628,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   s += !k.h3 ? "gru_step_kernel" : (seq_l0 ? "(in gru_seq_kernel)" : (k.scaled && m->Hp % 128 == 0 ? "gru_first16_kernel" : "gru_first_kernel"));
   if (L >= 2) {
     s += ";projection_l1=";
-    s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= skinny_max_m() ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
+    s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= l1_skinny_max_rows() ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
     s += std::string(";gi1_layout=") + (k.gblk ? "blocked" : "row_major");
     if (k.scaled) s += std::string(";gru_step_l1=") + (k.planes_state ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>");
   }
@@ -1501,8 +1505,11 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
                         mk(vf, Hp, m->fwd[l].wih_p, m->fwd[l].bih, w.gf, MT)};
         H3ArgsBatch sk{};
         H3Batch big{};
+        // width-first kernel up to 192 real rows (three 64-row passes over the weights), tiles above: with 64-row tiles (launch_gemm_h3, round 5) the tile
+        // kernel is flat at ~35 us up to a round of the chip, the width-first one costs ~12-16 us per pass (222 rows: 48.7 -> 37 us; 150 rows: stays)
         for (H3Args& a : pa) {
-          if (a.M <= skinny_max_m()) {
+          const long real_rows = a.M == MT ? (long)B * T : (long)a.M;
+          if (a.M <= skinny_max_m() && real_rows <= l1_skinny_max_rows()) {
             // width-first kernel: only the B real rows of every 16-row-padded time slab (B = 1: 16 rows instead of 256)
             if (a.M == MT && Bs != B) { a.M = B * T; a.grp_rows = B; a.grp_stride = (int)Bs; }
             sk.p[sk.n++] = a;

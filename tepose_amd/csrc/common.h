@@ -308,6 +308,7 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 // (hi = fp16(v), lo = fp16(v - hi)), else the blocked [K/32][R][32] format (lo = fp16((v - hi) * 2^11)).
 // zero / zero_bytes (multiple of 16): the kernel also clears that block -- the forward's arrival counters and granules,
 // when this is the forward's first kernel (saves the memset node).
+int split_few_max_rows();              // rows up to which launch_split_rows runs one workgroup per row (TEPOSE_SPLIT_FEW_MAX_ROWS, 1024)
 // optional gathered source of launch_split_rows (the clip driver's two per-step projections as one product): row r < B = features f0[r] | theta th0[r],
 // row r >= B = features f1[r - B] | zeros -- what two launch_pad_rows calls would have written to a padded buffer first (evaluate.py:248-252)
 struct RowPairSrc { const float* f0; const float* th0; const float* f1; long fld, thld; long B; };

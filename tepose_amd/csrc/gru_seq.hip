@@ -536,7 +536,8 @@ hipError_t launch_gru_seq(const GruSeqArgs& a0, hipStream_t s) {
   if (a.M <= gru_seq_gran_max_m() && a.gran) return launch_gran(a, grid, s);
   if (a.M <= 16) return launch_mt<1>(a, grid, s);
   if (a.M <= 32) return launch_mt<2>(a, grid, s);
-  // 33..64 rows: four 16-row tiles per workgroup.  (Round 2 had an opt-in row split for 2-direction layers -- two workgroups per unit slice, 256
+  if (a.M <= 48) return launch_mt<3>(a, grid, s);      // 33..48 rows (37 clips in lock-step): three tiles -- a quarter less state through the L2 port per step
+  // 49..64 rows: four 16-row tiles per workgroup.  (Round 2 had an opt-in row split for 2-direction layers -- two workgroups per unit slice, 256
   // workgroups, -15 us per forward at B = 64 -- removed in round 5: it needs EVERY CU of the chip resident at once, which a second process's launch on
   // the same GPU can deny until the bounded wait expires.)
   return launch_mt<4>(a, grid, s);

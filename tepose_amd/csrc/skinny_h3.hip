@@ -281,7 +281,13 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
   } else if (maxM <= 32) {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else if (maxM <= 64 && nt * b.n < 96 && narrow64()) {
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
+    // (as above: <= 128 blocks -- the collapsed regressor product, N = 160: 10 blocks -- split K over 8 waves: the block's chain of dependent weight
+    // chunks halves; 37 rows x 160 x 3072: 16 -> 9 us)
+    static const bool w8 = [] { const char* e = getenv("TEPOSE_SKINNY_W8"); return e ? atoi(e) != 0 : true; }();
+    if (w8 && (maxN + 15) / 16 * b.n <= 128)
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 8>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
+    else
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
   } else {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (maxM + 63) / 64, b.n), dim3(256), 0, s, b);
   }

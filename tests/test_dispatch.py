@@ -35,9 +35,14 @@ def _built():
 def test_class_boundaries_of_the_published_architecture():
     T = 16
     s = _select(2, 1024, [(1, T), (4, T), (5, T), (8, T), (9, T), (32, T), (64, T), (65, T), (128, T), (129, T), (511, T), (512, T), (639, T), (640, T),
-                          (648, T), (656, T), (768, T), (8192, T), (8192, 6), (1360, 6), (1376, 6), (37, 6)])
-    # input split: one workgroup per row up to 64 rows
-    assert s[(4, T)]['input'] == 'split_rows_few_kernel' and s[(5, T)]['input'] == 'split_rows_kernel'
+                          (648, T), (656, T), (768, T), (8192, T), (8192, 6), (1360, 6), (1376, 6), (37, 6), (32, 6)])
+    # input split: one workgroup per row up to 1024 rows (B * T), the 8-rows-per-block kernel above
+    assert s[(4, T)]['input'] == 'split_rows_few_kernel' and s[(64, T)]['input'] == 'split_rows_few_kernel' and s[(65, T)]['input'] == 'split_rows_kernel'
+    assert s[(37, 6)]['input'] == 'split_rows_few_kernel' and s[(8192, T)]['input'] == 'split_rows_kernel'
+    # layer >= 1 projections: width-first kernel up to 192 real rows (three 64-row passes), tiles above
+    assert s[(5, T)]['projection_l1'] == 'skinny_gemm_h3_kernel' and s[(8, T)]['projection_l1'] == 'skinny_gemm_h3_kernel'       # 80 / 128 rows
+    assert s[(32, 6)]['projection_l1'] == 'skinny_gemm_h3_kernel' and s[(37, 6)]['projection_l1'] == 'gemm_h3_kernel'              # 192 / 222 rows
+    assert s[(32, T)]['projection_l1'] == 'gemm_h3_kernel'
     # layer-0 projection: width-first kernel up to 128 rows | 128 x 128 tiles | 128 x 288 tiles where they need fewer whole rounds (from 512 rows) |
     # barrier-free persistent kernel from B * T = 8192
     assert s[(8, T)]['projection'] == 'skinny_gemm_h3_kernel' and s[(9, T)]['projection'] == 'gemm_h3_kernel'
