@@ -149,7 +149,9 @@ __global__ void __launch_bounds__(256) skinny_gru_h3_kernel(H3Batch batch, int M
 // a block owns 16*MT rows x 48 columns, K split over the 4 waves exactly as above.
 // NT: 16-column tiles per block (3 = 48 columns; 1 = 16 columns for narrow products of few rows, where 48-column blocks
 // would leave most CUs without a weight stream: N = 2048 -> 43 blocks vs 128)
-template <int MT, int NT = 3, int NW = 4>
+// DEPTH: K-tiles a wave keeps in flight (chunk buffers in registers).  The narrow forms (NT = 1: a handful of blocks streaming a small weight matrix, each
+// wave a chain of dependent round trips to the Infinity Cache) take 4: same arithmetic in the same order, half the round trips.
+template <int MT, int NT = 3, int NW = 4, int DEPTH = 2>
 __global__ void __launch_bounds__(64 * NW) skinny_gemm_h3_kernel(H3ArgsBatch batch) {
   const H3Args& a = batch.p[blockIdx.z];          // up to 3 independent products per launch (their own M, N, K)
   if ((int)blockIdx.x * (16 * NT) >= a.N || (int)blockIdx.y * 16 * MT >= a.M) return;   // the grid covers the largest one
@@ -211,6 +213,7 @@ __global__ void __launch_bounds__(64 * NW) skinny_gemm_h3_kernel(H3ArgsBatch bat
       for (int t = 0; t < NT; ++t)
         accx[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k.al[i], k.wh[t], accx[i][t], 0, 0, 0);
   };
+  if constexpr (DEPTH == 2) {
   if (c0 < c1) {
     Chunk p, n;
     load(c0, p);
@@ -222,6 +225,20 @@ __global__ void __launch_bounds__(64 * NW) skinny_gemm_h3_kernel(H3ArgsBatch bat
         if (c + 2 < c1) load(c + 2, p);
         mma(n);
       }
+    }
+  }
+  } else {
+    Chunk buf[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (c0 + d < c1) load(c0 + d, buf[d]);
+    for (int c = c0; c < c1; c += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d)
+        if (c + d < c1) {
+          mma(buf[d]);
+          if (c + d + DEPTH < c1) load(c + d + DEPTH, buf[d]);
+        }
     }
   }
 #pragma unroll
@@ -265,19 +282,37 @@ static bool narrow64() {
   return v;
 }
 
+static bool mt1_rows16() {
+  static const bool v = [] { const char* e = getenv("TEPOSE_SKINNY_MT1"); return e ? atoi(e) != 0 : true; }();
+  return v;
+}
+
 hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
   int maxM = 0, maxN = 0;
   for (int i = 0; i < b.n; ++i) { maxM = b.p[i].M > maxM ? b.p[i].M : maxM; maxN = b.p[i].N > maxN ? b.p[i].N : maxN; }
   if (b.n <= 0 || maxM <= 0 || maxN <= 0) return hipSuccess;
   const int nt = (maxN + 47) / 48;
   static const int nt1_max = [] { const char* e = getenv("TEPOSE_SKINNY_NT1_BELOW"); return e ? atoi(e) : 96; }();
+  {
+    // narrow products (the collapsed regressor product: 160 columns = 10 blocks of 16; the 2048-column tail linears at <= 16 rows): a CU takes in ~50 GB/s,
+    // so the launch lasts as long as its busiest block's bytes -- one 16-row tile per block (W re-read per row tile from L2, A never clamped-and-repeated)
+    // puts them on rows x more CUs: 64 rows x 160 x 3072 on 40 blocks of 392 KB instead of 10 of 960 KB
+    const bool mt1 = mt1_rows16();
+    const int blocks16 = (maxN + 15) / 16 * b.n, rowtiles = (maxM + 15) / 16;
+    if (mt1 && nt * b.n < nt1_max && blocks16 * rowtiles <= 256) {
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<1, 1, 8, 4>), dim3((maxN + 15) / 16, rowtiles, b.n), dim3(512), 0, s, b);
+      return hipGetLastError();
+    }
+  }
   if (maxM <= 32 && nt * b.n < nt1_max) {          // few rows, narrow product: 16-column blocks put a weight stream on 3x the CUs
     // (<= 128 such blocks -- the 2048-column tail linears: 8 waves split K, twice the weight bytes in flight per CU)
     static const bool w8 = [] { const char* e = getenv("TEPOSE_SKINNY_W8"); return e ? atoi(e) != 0 : true; }();
     if (w8 && (maxN + 15) / 16 * b.n <= 128)
-      hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 8>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 8, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
     else
-      hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 4, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
+  } else if (maxM <= 16 && mt1_rows16()) {         // one window / a handful of clips: a second, clamped-and-repeated row tile would be a fifth of the block's bytes
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<1>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else if (maxM <= 32) {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else if (maxM <= 64 && nt * b.n < 96 && narrow64()) {
@@ -285,9 +320,9 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
     // chunks halves; 37 rows x 160 x 3072: 16 -> 9 us)
     static const bool w8 = [] { const char* e = getenv("TEPOSE_SKINNY_W8"); return e ? atoi(e) != 0 : true; }();
     if (w8 && (maxN + 15) / 16 * b.n <= 128)
-      hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 8>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 8, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
     else
-      hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
+      hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 4, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
   } else {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (maxM + 63) / 64, b.n), dim3(256), 0, s, b);
   }
