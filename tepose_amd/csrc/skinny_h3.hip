@@ -323,6 +323,8 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 8, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
     else
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 4, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
+  } else if (maxM <= 48 && mt1_rows16()) {         // three row tiles: no clamped fourth one (a seventh of the block's bytes)
+    hipLaunchKernelGGL((skinny_gemm_h3_kernel<3>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else {
     hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (maxM + 63) / 64, b.n), dim3(256), 0, s, b);
   }
