@@ -53,13 +53,13 @@ def test_random_configurations_against_fp64_oracle():
         e1, e2, e3 = _check(L, H, B, T, seed, smpl_np, J, full=B <= 300)
         assert max(e1, e2) < 2e-5 and e3 < 1e-4, (L, H, B, T, seed, e1, e2, e3)
         worst, n = max(worst, e1, e2, e3), n + 1
-        if time.time() - t0 > 30:                       # bounded: CI budget, the sweep order is deterministic
+        if time.time() - t0 > 22:                       # bounded: CI budget, the sweep order is deterministic
             break
     assert n >= 12, n
     print('fuzz: %d configurations, worst abs error %.2e, %.0f s' % (n, worst, time.time() - t0))
 
 
-@pytest.mark.parametrize('B,T', [(64, 16), (64, 6), (2048, 2), (37, 6), (16, 16), (128, 4), (640, 3)])
+@pytest.mark.parametrize('B,T', [(64, 16), (2048, 2), (37, 6), (128, 4), (640, 3)])
 def test_published_architecture_batches_against_fp64_oracle(B, T):
     """n_layers = 2, hidden = 1024 (the published checkpoints): BASELINE.json config 2's shape (B = 64, T = 16), the
     37-clip lock-step shape of the 3DPW-test evaluation, and the batch thresholds of the large-batch kernels."""

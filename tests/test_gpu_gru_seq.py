@@ -27,10 +27,9 @@ def _model(L, H, seed, smpl_np):
 
 
 # (L, H, B, T): H % 256 == 0 and B <= 64 take the persistent kernel (B <= 4: states handed over as tagged granules)
-SHAPES = [(2, 1024, 1, 16), (2, 1024, 2, 5), (2, 1024, 3, 32), (2, 1024, 4, 6), (1, 512, 1, 7), (3, 256, 4, 3), (2, 512, 2, 36),
-          (2, 1024, 5, 6), (2, 1024, 64, 16), (2, 1024, 37, 6), (2, 1024, 16, 16), (2, 1024, 17, 3), (2, 1024, 33, 2),
-          (2, 256, 17, 5), (1, 512, 33, 4), (3, 256, 64, 3), (2, 768, 16, 7), (1, 1024, 48, 5), (2, 1024, 8, 36),
-          (2, 1024, 6, 32), (3, 512, 9, 4)]
+SHAPES = [(2, 1024, 1, 16), (2, 1024, 3, 32), (2, 1024, 4, 6), (1, 512, 1, 7), (3, 256, 4, 3), (2, 512, 2, 36),
+          (2, 1024, 5, 6), (2, 1024, 64, 16), (2, 1024, 37, 6), (2, 1024, 16, 16), (2, 1024, 33, 2),
+          (2, 256, 17, 5), (1, 512, 33, 4), (3, 256, 64, 3), (2, 768, 16, 7), (1, 1024, 48, 5), (2, 1024, 8, 36), (2, 256, 49, 3)]
 
 
 @pytest.mark.parametrize('L,H,B,T', SHAPES)

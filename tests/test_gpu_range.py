@@ -33,7 +33,7 @@ def _enc_errors(model, state, x, L):
     return float((got - r64).abs().max()), float((r32 - r64).abs().max())
 
 
-@pytest.mark.parametrize('scale', [1e-3, 1.0, 50.0, 1e3, 1e6])
+@pytest.mark.parametrize('scale', [1e-3, 50.0, 1e6])
 @pytest.mark.parametrize('L,H,B,T', [(2, 256, 6, 5), (2, 1024, 3, 4), (2, 64, 2100, 4), (1, 128, 40, 3)])
 def test_feature_scales_through_the_encoder(scale, L, H, B, T, smpl_np):
     """features x {1e-3 .. 1e6} (1e6 is far beyond the fp16 range), theta slots untouched; persistent kernel (B <= 64),
