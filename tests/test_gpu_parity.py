@@ -241,6 +241,31 @@ def test_full_size_batch_matches_oracle_on_sampled_rows(smpl_np):
     _check_theta(big['theta'][idx.cuda()].cpu().double().numpy(), ref['theta'].double().numpy(), None)
 
 
+@pytest.mark.parametrize('L,H,B,T', [(2, 256, 48, 4),     # 192 real rows: layer-1 projections still width-first; 48 rows: three-tile persistent kernel and GEMM
+                                      (2, 256, 49, 4),     # 196 rows: tiles; 49 rows: four tiles
+                                      (2, 64, 64, 16),     # 1024 rows: the last size of the one-workgroup-per-row input split
+                                      (2, 64, 205, 5),     # 1025 rows: the 8-rows-per-block split
+                                      (2, 64, 400, 2),     # collapsed regressor product: 25 row tiles x 10 column blocks = 250 one-tile blocks
+                                      (2, 64, 416, 2),     # 26 x 10 = 260 > 256: the 64-row form
+                                      (1, 64, 16, 3), (1, 64, 17, 3), (2, 128, 33, 2)])   # 1 | 2 | 3 row tiles exactly in the width-first GEMM
+def test_round5_threshold_neighbours_match_the_oracle(L, H, B, T, smpl_np):
+    """Both sides of every row-count threshold that round 5 added to the small / mid batch dispatch (profiles/r05_mid_rows_gemm.txt, section 4): the
+    full forward against the fp64-accumulating CPU oracle on the first and last rows of the batch, finite everywhere."""
+    from oracle import tepose_ref as O
+    model, state, _ = _model(L, H, 23, smpl_np)
+    x = synth.synthetic_windows(B, T, 61)
+    J = torch.from_numpy(smpl_np['J_regressor_h36m'])
+    with torch.no_grad():
+        out = model(_dev(x), J_regressor=J)[0]
+    for v in out.values():
+        assert torch.isfinite(v).all()
+    rows = np.unique(np.r_[0:min(20, B), max(B - 20, 0):B])
+    ref = O.tepose_fwd(state, smpl_np, x[rows], L, J_regressor=smpl_np['J_regressor_h36m'])
+    for k in ('verts', 'kp_3d', 'rotmat', 'kp_2d'):
+        assert (out[k][rows].cpu() - ref[k]).abs().max() < TOL, (k, float((out[k][rows].cpu() - ref[k]).abs().max()))
+    _check_theta(out['theta'][rows].cpu().double().numpy(), ref['theta'].double().numpy(), None)
+
+
 def test_row_permutation_equivariance(smpl_np):
     model, _, _ = _model(1, 128, 2, smpl_np)
     x = _dev(synth.synthetic_windows(70, 5, 21))
