@@ -311,22 +311,24 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 8, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
     else
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 4, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
-  } else if (maxM <= 16 && mt1_rows16()) {         // one window / a handful of clips: a second, clamped-and-repeated row tile would be a fifth of the block's bytes
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<1>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
-  } else if (maxM <= 32) {
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
-  } else if (maxM <= 64 && nt * b.n < 96 && narrow64()) {
+  } else if (maxM <= 64 && maxM > 32 && nt * b.n < 96 && narrow64()) {
     // (as above: <= 128 blocks -- the collapsed regressor product, N = 160: 10 blocks -- split K over 8 waves: the block's chain of dependent weight
-    // chunks halves; 37 rows x 160 x 3072: 16 -> 9 us)
+    // chunks halves)
     static const bool w8 = [] { const char* e = getenv("TEPOSE_SKINNY_W8"); return e ? atoi(e) != 0 : true; }();
     if (w8 && (maxN + 15) / 16 * b.n <= 128)
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 8, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
     else
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 4, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
-  } else if (maxM <= 48 && mt1_rows16()) {         // three row tiles: no clamped fourth one (a seventh of the block's bytes)
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<3>), dim3(nt, 1, b.n), dim3(256), 0, s, b);
   } else {
-    hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), dim3(nt, (maxM + 63) / 64, b.n), dim3(256), 0, s, b);
+    // row tiles dealt evenly over the fewest passes of <= 4 tiles: a block never loads a clamped-and-repeated tile beyond the last one of the batch
+    // (74 rows = 5 tiles: 3 + 2 instead of 4 + 1 and three repeats; 16 rows: 1 tile instead of 2)
+    const int tiles = (maxM + 15) / 16, passes = (tiles + 3) / 4;
+    const int mt = mt1_rows16() ? (tiles + passes - 1) / passes : (maxM <= 32 ? 2 : 4);
+    const dim3 grid(nt, (tiles + mt - 1) / mt, b.n);
+    if (mt <= 1) hipLaunchKernelGGL((skinny_gemm_h3_kernel<1>), grid, dim3(256), 0, s, b);
+    else if (mt == 2) hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), grid, dim3(256), 0, s, b);
+    else if (mt == 3) hipLaunchKernelGGL((skinny_gemm_h3_kernel<3>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((skinny_gemm_h3_kernel<4>), grid, dim3(256), 0, s, b);
   }
   return hipGetLastError();
 }
