@@ -229,6 +229,15 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
 int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
                               long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
                               size_t ws_bytes, void* stream);
+/* One iteration of the reference's window loop (evaluate.py:247-269, demo.py:238-252) for B clips in lock-step as ONE call: tepose_project_frame_pair
+ * (previous newest frame with its now-known theta -> `out_prev`, normally its ring slot; newest frame with zero theta -> `newest`) followed by
+ * tepose_forward_cached on the window starting at ring slot `first_slot`.  Same arguments and results as those two calls (workspace >=
+ * tepose_workspace_bytes(m, B, T), pair_workspace >= tepose_project_frames_workspace_bytes(m, 2 * B)); the forward's sync region is cleared by the
+ * projection's input-split kernel instead of a memset node of its own.                                                                        */
+int tepose_window_step(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev, long theta_ld,
+                       float* out_prev, long out_prev_ld, float* newest, long newest_ld, const float* ring_base, int ring, int first_slot,
+                       long clip_stride, int B, int T, const void* jreg_packed, float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
+                       void* workspace, size_t ws_bytes, void* pair_workspace, size_t pair_ws_bytes, void* stream);
 /* TePose.forward for the window whose first frame sits in ring slot `first_slot`; clip b's ring
  * starts at ring_base + b*clip_stride; newest frame's row at newest + b*newest_ld.  Outputs and
  * workspace as tepose_forward.  Saves the T-fold re-projection (42 % of the FLOPs at T = 16).  */

@@ -18,7 +18,7 @@ SYMBOLS = [
     'tepose_encoder_fwd', 'tepose_regressor_fwd', 'tepose_forward', 'tepose_gemm_workspace_bytes',
     'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read', 'tepose_create_vibe', 'tepose_create_vibe_ex', 'tepose_vibe_feature_dim',
     'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
-    'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_project_frame_pair', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
+    'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_project_frame_pair', 'tepose_window_step', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
     'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_fault_code', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
@@ -105,6 +105,8 @@ def load():
     lib.tepose_project_frames_workspace_bytes.restype = c_size_t
     lib.tepose_project_frames.argtypes = [c_void_p, fp, c_long, fp, c_long, c_int, fp, c_long, fp, c_size_t, c_void_p]
     lib.tepose_project_frame_pair.argtypes = [c_void_p, fp, fp, c_long, fp, c_long, c_int, fp, c_long, fp, c_long, fp, c_size_t, c_void_p]
+    lib.tepose_window_step.argtypes = [c_void_p, fp, fp, c_long, fp, c_long, fp, c_long, fp, c_long, fp, c_int, c_int, c_long, c_int, c_int, fp, fp, fp, fp, fp, fp,
+                                       fp, c_size_t, fp, c_size_t, c_void_p]
     lib.tepose_forward_cached.argtypes = [c_void_p, fp, c_int, c_int, c_long, fp, c_long, c_int, c_int, fp, fp, fp, fp,
                                           fp, fp, fp, c_size_t, c_void_p]
     lib.tepose_gemm_h3_workspace_bytes.argtypes = [c_int, c_int, c_int]

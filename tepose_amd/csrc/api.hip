@@ -1882,9 +1882,26 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
 // step instead of twice, one input split (which gathers the rows itself) instead of two pads and two splits.  Same GEMM rows on the same operands as
 // two tepose_project_frames calls; the width-first kernel may split K over 4 or 8 waves depending on the row count, so results agree to rounding
 // (bit for bit at the published width).
+namespace {
+int project_frame_pair_impl(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
+                            long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
+                            size_t ws_bytes, void* stream, void* zero, size_t zero_bytes, bool* zeroed);
+}
+
 int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
                               long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
                               size_t ws_bytes, void* stream) {
+  return project_frame_pair_impl(m, feat_prev, feat_new, feat_ld, theta_prev, theta_ld, B, out_prev, out_prev_ld, out_new, out_new_ld, workspace, ws_bytes,
+                                 stream, nullptr, 0, nullptr);
+}
+
+namespace {
+// `zero` / `zero_bytes`: a region the input-split kernel clears on its way (the following forward's sync region: tepose_window_step); *zeroed says
+// whether it did (the two-call fallbacks do not)
+int project_frame_pair_impl(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev,
+                            long theta_ld, int B, float* out_prev, long out_prev_ld, float* out_new, long out_new_ld, void* workspace,
+                            size_t ws_bytes, void* stream, void* zero, size_t zero_bytes, bool* zeroed) {
+  if (zeroed) *zeroed = false;
   if (!m || m->kind != 0 || !feat_prev || !feat_new || !theta_prev || !out_prev || !out_new || !workspace || B < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
   if (ws_bytes < tepose_project_frames_workspace_bytes(m, 2 * B)) return TEPOSE_E_WORKSPACE;
@@ -1902,7 +1919,9 @@ int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, con
   float* rs = (float*)((char*)workspace + 2 * xbytes + 512);
   // the split kernel gathers the 2 B rows itself (features | theta, features | zeros): no padded fp32 copy, one launch instead of three
   const RowPairSrc pr{feat_prev, theta_prev, feat_new, feat_ld, theta_ld, B};
-  CK(launch_split_rows(nullptr, 0, M, kInput, kInputP, M, 0, hi, lo, rs, s, nullptr, 0, 0, &pr));
+  const bool z = zero && zero_bytes && zero_bytes % 16 == 0;
+  CK(launch_split_rows(nullptr, 0, M, kInput, kInputP, M, 0, hi, lo, rs, s, z ? zero : nullptr, z ? zero_bytes : 0, 0, &pr));
+  if (zeroed) *zeroed = z;
   const int Np = round_up(9 * m->Hp, 128);
   const half_t* wh = (const half_t*)(m->blob + m->wih0_p);
   H3Args p{};
@@ -1915,10 +1934,55 @@ int tepose_project_frame_pair(const tepose_model* m, const float* feat_prev, con
   return 0;
 }
 
+int forward_cached_impl(const tepose_model* m, const float* ring_base, int ring, int first_slot, long clip_stride, const float* newest, long newest_ld, int B,
+                        int T, const void* jreg_packed, float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace,
+                        size_t ws_bytes, void* stream, bool sync_zeroed);
+}  // namespace
+
+// One iteration of the reference's window loop (evaluate.py:247-269, demo.py:238-252) for B clips in lock-step, as ONE call: both layer-0 projections of
+// the step (tepose_project_frame_pair: the previous newest frame with its now-known theta -> its ring slot `out_prev`, the newest frame with zero theta ->
+// `newest`) and then TePose.forward of the window from the cached projections (tepose_forward_cached).  Same results as the two calls; the forward's
+// sync region is cleared by the projection's input-split kernel instead of a memset node of its own, and a host loop makes one call per step.
+int tepose_window_step(const tepose_model* m, const float* feat_prev, const float* feat_new, long feat_ld, const float* theta_prev, long theta_ld,
+                       float* out_prev, long out_prev_ld, float* newest, long newest_ld, const float* ring_base, int ring, int first_slot,
+                       long clip_stride, int B, int T, const void* jreg_packed, float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,
+                       void* workspace, size_t ws_bytes, void* pair_workspace, size_t pair_ws_bytes, void* stream) {
+  if (!m || m->kind != 0 || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
+  if (!m->enc_packed) return TEPOSE_E_STATE;
+  if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
+  if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
+  // the forward's sync region: the first carve of its workspace (as tepose_forward_cached lays it out)
+  void* zero = nullptr;
+  size_t zero_bytes = 0;
+  {
+    const size_t feat_bytes = align_up((size_t)B * 2 * kFeat * sizeof(float), 256);
+    const size_t rest_bytes = (ws_bytes & ~(size_t)255) - feat_bytes;
+    Carver c(workspace, rest_bytes);
+    EncWs w;
+    carve_encoder(m, B, T, c, w);
+    if (c.cur > rest_bytes) return TEPOSE_E_WORKSPACE;
+    if (w.sync) { zero = (void*)w.sync; zero_bytes = sync_zero_bytes(m, B); }
+  }
+  bool zeroed = false;
+  int rc = project_frame_pair_impl(m, feat_prev, feat_new, feat_ld, theta_prev, theta_ld, B, out_prev, out_prev_ld, newest, newest_ld, pair_workspace,
+                                   pair_ws_bytes, stream, zero, zero_bytes, &zeroed);
+  if (rc) return rc;
+  return forward_cached_impl(m, ring_base, ring, first_slot, clip_stride, newest, newest_ld, B, T, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat,
+                             workspace, ws_bytes, stream, zeroed);
+}
+
 int tepose_forward_cached(const tepose_model* m, const float* ring_base, int ring, int first_slot, long clip_stride,
                           const float* newest, long newest_ld, int B, int T, const void* jreg_packed, float* theta,
                           float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                           void* stream) {
+  return forward_cached_impl(m, ring_base, ring, first_slot, clip_stride, newest, newest_ld, B, T, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat,
+                             workspace, ws_bytes, stream, false);
+}
+
+namespace {
+int forward_cached_impl(const tepose_model* m, const float* ring_base, int ring, int first_slot, long clip_stride, const float* newest, long newest_ld, int B,
+                        int T, const void* jreg_packed, float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace,
+                        size_t ws_bytes, void* stream, bool sync_zeroed) {
   if (!m || m->kind != 0 || !ring_base || !newest || !workspace || B < 1 || T < 1 || ring < T - 1 || ring < 1 ||
       first_slot < 0 || first_slot >= ring)
     return TEPOSE_E_ARG;
@@ -1939,11 +2003,12 @@ int tepose_forward_cached(const tepose_model* m, const float* ring_base, int rin
   const int ld0 = 9 * m->Hp;
   G0Src src{ring_base, ld0, clip_stride, first_slot, ring, newest, newest_ld, newest + 6 * m->Hp, newest_ld};
   const bool col = m->tail_collapsed && m->split && B > split_min_m();
-  int rc = encoder_core(m, src, B, T, 0, feat, w, s, nullptr, false, col ? feat : nullptr);
+  int rc = encoder_core(m, src, B, T, 0, feat, w, s, nullptr, sync_zeroed, col ? feat : nullptr);
   if (rc) return rc;
   return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
                         rest_bytes, stream, false, true, col ? feat : nullptr);    // (encoder_core cleared the shared sync region)
 }
+}  // namespace
 
 int tepose_regressor_fwd(const tepose_model* m, const float* feat, int N, int n_iter, const void* jreg_packed,
                          float* theta, float* verts, float* kp_3d, float* kp_2d, float* rotmat,

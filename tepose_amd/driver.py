@@ -83,6 +83,7 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
         pws = torch.empty(int(eng.lib.tepose_project_frames_workspace_bytes(eng.handle, 2 * C)), dtype=torch.uint8, device=dev)
         th_ld = TH.stride(1)
         pair = os.environ.get('TEPOSE_DRIVER_PAIR', '1') != '0'      # A/B: 0 = the two projections of a step as two products
+        one_call = pair and os.environ.get('TEPOSE_DRIVER_PAIR', '1') != '2'      # A/B: 2 = pair projection and forward as two library calls
 
         def project(frame, theta, b):
             out = newest if theta is None else ring[:, frame % ring_n]
@@ -102,6 +103,12 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
                 if j > 0 and not pair:
                     project(j + T - 2, True, b)
                     project(j + T - 1, None, b)
+                elif j > 0 and one_call:
+                    # the whole step as ONE library call: both projections as one product of 2 b rows, then the forward from the cached projections
+                    fp, fn = j + T - 2, j + T - 1
+                    eng.window_step(F[:, fp].data_ptr(), F[:, fn].data_ptr(), F.stride(0), TH[fp].data_ptr(), th_ld, ring[:, fp % ring_n].data_ptr(),
+                                    ring.stride(0), ring, j % ring_n, newest, b, T, J_regressor, pws, out=out)
+                    continue
                 elif j > 0:
                     # previous newest frame (theta now known) -> its ring slot, newest frame (theta slots zero) -> `newest`: ONE product of 2 b rows
                     fp, fn = j + T - 2, j + T - 1

@@ -461,6 +461,26 @@ class Engine:
             return out
         return self._run(B, call, ws)
 
+    def window_step(self, feat_prev_ptr, feat_new_ptr, feat_ld, theta_prev_ptr, theta_ld, out_prev_ptr, out_prev_ld, ring, first_slot, newest, B, T, J_regressor,
+                    pair_ws, out=None):
+        """One lock-step of the clip driver as one library call (tepose_window_step): the step's two layer-0 projections as one product (previous newest
+        frame + its theta -> `out_prev`, newest frame + zero theta -> `newest`), then the forward of the window from the cached projections."""
+        dev = ring.device
+        ws = self.workspace(B, T, dev)
+        _, jp = self.jreg(J_regressor, dev)
+        nj = 14 if J_regressor is not None else 49
+        given = out
+
+        def call():
+            out = self._out_views(given, B, nj, dev)
+            _lib.check(self.lib.tepose_window_step(
+                self.handle, feat_prev_ptr, feat_new_ptr, feat_ld, theta_prev_ptr, theta_ld, out_prev_ptr, out_prev_ld, newest.data_ptr(), newest.stride(0),
+                ring.data_ptr(), ring.shape[1], int(first_slot), ring.stride(0), B, T, jp, out['theta'].data_ptr(), out['verts'].data_ptr(),
+                out['kp_3d'].data_ptr(), out['kp_2d'].data_ptr(), out['rotmat'].data_ptr(), ws.data_ptr(), ws.numel(), pair_ws.data_ptr(), pair_ws.numel(),
+                self._stream()), 'tepose_window_step')
+            return out
+        return self._run(B, call, ws)
+
     # ------------------------------------------------------------------ VIBE bootstrap encoder
     def _vibe_enc_tensors(self, enc):
         ts = []

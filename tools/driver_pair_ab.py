@@ -13,7 +13,7 @@ inits = [torch.from_numpy(synth.synthetic_windows(1, 6, 200 + i)[0, :5, 2048:].c
 steps = int(lens.max()) - 5
 res = {}
 for rnd in range(3):
-    for name, env in (('pair', '1'), ('two', '0'), ('nocache', None)):
+    for name, env in (('step', '1'), ('pair', '2'), ('two', '0'), ('nocache', None)):
         os.environ['TEPOSE_DRIVER_PAIR'] = env or '1'
         torch.cuda.synchronize(); t0 = time.perf_counter()
         run_clips(model, feats, inits, 6, J_regressor=J, keep=('kp_3d', 'verts'), cache_projections=(env is not None))
@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'after-big':
     del xb
     res = {}
     for rnd in range(2):
-        for name, env in (('pair', '1'), ('nocache', None)):
+        for name, env in (('step', '1'), ('nocache', None)):
             os.environ['TEPOSE_DRIVER_PAIR'] = env or '1'
             torch.cuda.synchronize(); t0 = time.perf_counter()
             run_clips(model, feats, inits, 6, J_regressor=J, keep=('kp_3d', 'verts'), cache_projections=(env is not None))
