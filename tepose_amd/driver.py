@@ -44,8 +44,7 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
     cache_projections: keep every frame's layer-0 gate pre-activations (x W_ih^T + b_ih, 3 directions) in a
     per-clip ring, so a window step projects 2 frames per clip (the newest one with zero theta and the
     previous one with its now-known theta) instead of all `seqlen` (saves up to 42 % of the
-    FLOPs).  'auto' turns it on from 4 concurrent clips (below that the two extra small launches per
-    step cost more than the re-projection they save).
+    FLOPs).  'auto' turns it on from 2 concurrent clips.
 
     Returns a list (same order as the input) of dicts key -> [N_i - seqlen + 1, ...] tensors:
     the prediction for the last frame of every window, i.e. frames seqlen-1 .. N_i-1."""
@@ -70,7 +69,9 @@ def _run_clips(model, features, theta_init, seqlen, J_regressor, keep, cache_pro
     steps = [n[i] - T + 1 for i in order]                 # windows per clip, non-increasing
     bufs = {k: torch.empty((steps[0], C) + tails[k], device=dev) for k in keep if k != 'theta'}
     eng = model._engine
-    use_cache = (C >= 4) if cache_projections == 'auto' else bool(cache_projections)     # measured crossover
+    # measured (tools/driver_cache_crossover.py, round 5): with the step as one library call the cache wins at every clip count (1 clip: -3 ... -5 %);
+    # one clip stays uncached so that it runs the very kernels of the live-stream session (tepose_amd.stream, compared bit for bit in the tests)
+    use_cache = (C >= 2) if cache_projections == 'auto' else bool(cache_projections)
     if cache_projections == 'auto' and os.environ.get('TEPOSE_DRIVER_CACHE', '') in ('0', '1'):    # A/B and debugging
         use_cache = os.environ['TEPOSE_DRIVER_CACHE'] == '1'
     with on_device(dev):
