@@ -25,6 +25,8 @@ s = buf.cpu().view(3, 36, 8).double() / 100.0          # us ; the last launch (t
 names = ['start', 'poll', 'bar1', 'mfma', 'bar2', 'cell', 'drain', 'arrive']
 for d in range(2):
     print('direction', d)
+    r0 = s[d, 0]
+    print('  step  0 (first step: element-wise, W_hh slices loading)  ' + '  '.join('%s %5.2f' % (names[k], float(r0[k] - r0[0])) for k in range(1, 8)) + '   | next start +%.2f' % float(s[d, 1, 0] - r0[0]))
     for st in range(1, T - 1):
         r = s[d, st]
         print('  step %2d  ' % st + '  '.join('%s %5.2f' % (names[k], float(r[k] - r[0])) for k in range(1, 8)) +
