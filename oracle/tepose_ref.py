@@ -177,7 +177,8 @@ def rotmat_to_angle_axis(R):
 
 
 def batch_rodrigues(aa):
-    """smplx.lbs.batch_rodrigues [published algorithm; parity unpinned]:
+    """smplx.lbs.batch_rodrigues [published algorithm]; pinned to the Rodrigues the reference itself holds,
+    lib/utils/geometry.py:22-65 (quaternion form of the same map), by tests/golden/geometry.npz `rod_*` (2e-8 in fp64):
     angle = ||aa + 1e-8||, R = I + sin K + (1-cos) K^2."""
     angle = torch.norm(aa + 1e-8, dim=1, keepdim=True)
     d = aa / angle

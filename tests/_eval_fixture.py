@@ -1,6 +1,6 @@
 """Shared by the CPU and GPU tests of BASELINE config 4's evaluation branches: rebuild the synthetic `*_db.pt` a
-tests/golden/eval_*.npz fixture was generated from (tests/golden/make_golden.py::eval_case -- the reference's own
-evaluate.py flow with its TePose / VIBE classes and metric functions) and return it with the expected values."""
+tests/golden/eval_*.npz fixture was generated from (tests/golden/make_golden.py::eval_case -- the statements of the
+reference's own evaluate.py, executed from the file as AST slices, with its TePose / VIBE classes and metric functions) and return it with the expected values."""
 import os
 
 import numpy as np

@@ -1,0 +1,55 @@
+"""The fixture generator pins the flow goldens to the reference's OWN statements (tests/golden/make_golden.py executes
+AST slices of /root/reference/evaluate.py and the unbound Trainer.validate / Trainer.evaluate): it must not contain
+retyped runs of those files, and re-running it must reproduce the committed flow fixtures bit for bit.
+
+Build container only (skipped where /root/reference or the generator is absent: the generator is listed in
+`.gpurunignore` and never travels to the GPU box)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+GEN = os.path.join(ROOT, 'tests', 'golden', 'make_golden.py')
+
+pytestmark = pytest.mark.skipif(not (os.path.isfile(os.path.join(REF, 'evaluate.py')) and os.path.isfile(GEN)),
+                                reason='reference checkout or generator absent')
+
+
+def _code_lines(path):
+    out = []
+    for l in open(path):
+        l = re.sub(r'\s+', '', l.split('#')[0])
+        if l:
+            out.append(l)
+    return out
+
+
+@pytest.mark.parametrize('ref', ['evaluate.py', 'lib/core/trainer.py', 'lib/core/tester.py', 'lib/utils/smooth_pose.py',
+                                 'lib/utils/eval_utils.py'])
+def test_generator_holds_no_run_of_reference_lines(ref):
+    g, r = _code_lines(GEN), _code_lines(os.path.join(REF, ref))
+    runs = {tuple(r[i:i + 3]) for i in range(len(r) - 2)}
+    hits = [i for i in range(len(g) - 2) if tuple(g[i:i + 3]) in runs]
+    assert not hits, [g[i] for i in hits[:5]]
+
+
+def test_generator_is_not_in_the_gpu_payload():
+    with open(os.path.join(ROOT, '.gpurunignore')) as f:
+        assert 'tests/golden/make_golden.py' in [l.strip() for l in f]
+
+
+def test_flow_fixtures_regenerate_bit_identically(tmp_path):
+    p = subprocess.run([sys.executable, GEN, '--out', str(tmp_path), 'flows'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    made = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.npz'))
+    assert len(made) == 9 and sum(f.startswith('eval_') for f in made) == 4, made
+    for f in made:
+        a, b = np.load(os.path.join(str(tmp_path), f)), np.load(os.path.join(ROOT, 'tests', 'golden', f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == 'f'), (f, k)

@@ -123,3 +123,30 @@ def test_smpl_few_persons_every_input_mode(n):
     model, _, _ = build_model(1, 64, seed=1, device='cuda', smpl_np=smpl_np)
     gt = gt_vertices(model, torch.from_numpy(theta[:n].copy()).cuda())
     assert (gt.cpu() - O.verts_from_theta(smpl_np, theta[:n])).abs().max() < 1e-4
+
+
+def test_axis_angle_input_matches_the_reference_held_rodrigues():
+    """pose2rot=True paths (standalone SMPL call, MPVPE ground-truth mesh) against rotations made by the REFERENCE's own
+    batch_rodrigues (lib/utils/geometry.py:22-65; tests/golden/geometry.npz `rod_*`: 12 persons x 24 joints with angles 0,
+    1e-9, 1e-4, random, pi -+ 1e-3, beyond 2 pi, both signs) pushed through oracle.lbs in float64.  1e-5 on vertices and
+    joints (the library's Rodrigues is the smplx closed form: 2e-8 from the reference's in exact arithmetic)."""
+    from oracle import tepose_ref as O
+    from tepose_amd.metrics import gt_vertices
+    from tepose_amd.smpl import SMPL
+    from tepose_amd.testing import build_model
+    g = np.load(os.path.join(GOLDEN, 'geometry.npz'))
+    smpl_np = synth.synthetic_smpl(0)
+    pose = torch.from_numpy(g['rod_aa']).view(12, 24, 3)
+    betas = torch.from_numpy(synth.normal('rod/betas', (12, 10), std=0.5))
+    s = O.smpl_tensors(smpl_np, torch.float64)
+    v_ref, posed = O.lbs(s, betas.double(), torch.from_numpy(g['rod_R64']).view(12, 24, 3, 3))
+    j_ref = O.smpl_joints49(s, v_ref, posed)
+    smpl = SMPL.from_tables(smpl_np).cuda()
+    for n in (12, 3):                                       # the four-launch chain and the one-launch small form
+        out = smpl(betas=betas[:n].cuda(), body_pose=pose[:n, 1:].cuda(), global_orient=pose[:n, 0:1].cuda())
+        assert (out.vertices.cpu().double() - v_ref[:n]).abs().max() < 1e-5
+        assert (out.joints.cpu().double() - j_ref[:n]).abs().max() < 1e-5
+    model, _, _ = build_model(1, 64, seed=1, device='cuda', smpl_np=smpl_np)
+    theta = torch.cat([torch.tensor([[1., 0., 0.]]).expand(12, 3), pose.reshape(12, 72), betas], dim=1).contiguous()
+    gt = gt_vertices(model, theta.cuda())                   # tepose_smpl_verts_from_theta (eval_utils.py:155-169)
+    assert (gt.cpu().double() - v_ref).abs().max() < 1e-5

@@ -116,6 +116,19 @@ def test_lbs_global_rotation_is_rigid_about_root(smpl_np):
     assert ((j0 - root) @ Q.t() + root - j1).abs().max() < 1e-10
 
 
+def test_batch_rodrigues_matches_the_reference_held_form():
+    """axis-angle -> R: the only Rodrigues the reference HOLDS is lib/utils/geometry.py:22-65 (quaternion form,
+    |theta + 1e-8|); tests/golden/geometry.npz `rod_*` = its outputs (fp32 and the same statements in fp64) on angles 0,
+    1e-9, 1e-4, random, pi -+ 1e-3, beyond 2 pi, both signs.  The oracle's closed form (I + sin K + (1 - cos) K^2, what
+    smplx publishes) is a different expression, so not bitwise: 1e-7 in fp64 (the 1e-8 bias enters the two forms
+    differently), 1e-6 in fp32."""
+    g = np.load(os.path.join(GOLDEN, 'geometry.npz'))
+    aa = torch.from_numpy(g['rod_aa'])
+    assert aa.shape == (288, 3)
+    assert (O.batch_rodrigues(aa.double()) - torch.from_numpy(g['rod_R64'])).abs().max() < 1e-7
+    assert (O.batch_rodrigues(aa) - torch.from_numpy(g['rod_R'])).abs().max() < 1e-6
+
+
 def test_batch_rodrigues_is_rotation():
     R = _rand_rot(50, 3)
     # the published form normalises by ||aa + 1e-8||, so orthogonality holds to ~1e-7 only
@@ -262,8 +275,8 @@ def test_regressor_per_call_init_golden(name, smpl_np):
 
 
 def test_oracle_padded_validation_batch_matches_reference_golden(smpl_np):
-    """lib/core/trainer.py:307-357 on a padded batch (tests/golden/make_golden.py::padded_case runs the reference model
-    through that loop, padding windows included): a clip's kept rows do not depend on the padded windows the reference also
+    """lib/core/trainer.py:307-357 on a padded batch (tests/golden/make_golden.py::padded_case calls the reference's unbound
+    Trainer.validate on it, padding windows included): a clip's kept rows do not depend on the padded windows the reference also
     computes, so clip-by-clip (the oracle's run_clip) reproduces the accumulators in the trainer's order."""
     g = np.load(os.path.join(GOLDEN, 'padded_L2H128_T5.npz'))
     L, H, T, seed_w, seed_x = [int(v) for v in g['meta'][:5]]
