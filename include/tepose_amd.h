@@ -334,6 +334,10 @@ int tepose_profile_read(tepose_model* m, double* total_ms, int* n_launches, doub
 /* Same switch, second kernel class: total time of the GRU-step launch sequences (one interval per layer
  * per forward) and the algorithmic FLOPs of the consumed cell steps of one forward.          */
 int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward);
+/* Third class: the layer >= 1 input projections of the encoder (tepose.py:53-64 layers 1..L-1), i.e. what runs between
+ * the step sequences of two consecutive layers -- the gaps of the interval list above.  Does not reset the list
+ * (tepose_profile_read_gru does): call it first.                                              */
+int tepose_profile_read_l1proj(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward);
 
 #ifdef __cplusplus
 }

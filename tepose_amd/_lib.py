@@ -18,7 +18,7 @@ SYMBOLS = [
     'tepose_encoder_fwd', 'tepose_regressor_fwd', 'tepose_forward', 'tepose_gemm_workspace_bytes',
     'tepose_gemm_f32', 'tepose_profile_enable', 'tepose_profile_read', 'tepose_create_vibe', 'tepose_create_vibe_ex', 'tepose_vibe_feature_dim',
     'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
-    'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_project_frame_pair', 'tepose_window_step', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
+    'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_project_frame_pair', 'tepose_window_step', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_profile_read_l1proj', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
     'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_fault_code', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
@@ -40,8 +40,9 @@ class TeposeTimeout(TeposeError):
     the outputs of that forward are NaN.  Engine re-runs on the step-per-launch kernels where it owns the sync point."""
 
 
-class TeposeKernelFault(TeposeTimeout):
-    """The fault channel reported code 4: a bounded LDS poll of the barrier-free projection kernel (csrc/gemm_h3s16c.hip) expired.  No wait in that
+class TeposeKernelFault(TeposeError):
+    """(A sibling of TeposeTimeout, not a subclass: the retry loops that catch TeposeTimeout -- run_clips, StreamSession -- must not re-run on it.)
+    The fault channel reported code 4: a bounded LDS poll of the barrier-free projection kernel (csrc/gemm_h3s16c.hip) expired.  No wait in that
     kernel depends on another workgroup, so this is a kernel bug or a hardware fault -- not a shared / CU-masked GPU, and the persistent small-batch
     kernels have nothing to do with it.  The forward's outputs are invalid (NaN-poisoned); the handle stays as it is."""
 
@@ -125,6 +126,7 @@ def load():
     lib.tepose_profile_enable.argtypes = [c_void_p, c_int]
     lib.tepose_profile_read.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     lib.tepose_profile_read_gru.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
+    lib.tepose_profile_read_l1proj.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     for name in SYMBOLS:
         getattr(lib, name)              # AttributeError here = the built library is older than this binding
     if lib.tepose_version() != 1:

@@ -5,8 +5,10 @@
 
 #include <stdlib.h>
 
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -84,6 +86,12 @@ struct tepose_model {
   int blend16_min_n = 512;                      // TEPOSE_BLEND16_MIN_N: rows from which the blend-shape product runs on gemm_h3s_persist16c_kernel (0x7fffffff = never)
   int gi_blk = 1;                               // TEPOSE_GI_BLK: large batches keep the layer >= 1 gate pre-activations in the 16 x 16-blocked layout (common.h gi_blk_offset)
   int last_fault_code = 0;                      // the kernel code of the last fault a status call collected (tepose_fault_code)
+  // The fault word is shared by every stream and thread of the handle and ANY status call clears it, so "the word is clear" says nothing about one
+  // particular forward once somebody else has collected: `collected` counts the clears that found the word raised, and every forward notes the count
+  // it was queued under, per workspace (its status words live there).  tepose_forward_status trusts the clear word only while the count stands still.
+  mutable std::mutex q_mu;
+  mutable std::unordered_map<const void*, unsigned> q_gen;
+  mutable unsigned collected = 0;               // guarded by q_mu
   unsigned test_fault = 0;                      // TEPOSE_TEST_FAULT: bit 0 recurrent kernel, bit 1 regressor kernel wait for arrivals that never come
   // profiling of the dominant kernel (layer-0 input-projection GEMM)
   bool prof = false;
@@ -93,6 +101,7 @@ struct tepose_model {
   std::vector<hipEvent_t> ev_gru;               // pairs around each layer's sequence of GRU-step launches
   size_t ev_gru_used = 0;
   double prof_gru_flops = 0.0;                  // algorithmic FLOPs of all GRU steps of one forward
+  double prof_l1_flops = 0.0;                   // algorithmic FLOPs of the layer >= 1 input projections (launched between two GRU intervals)
 };
 
 namespace {
@@ -548,6 +557,20 @@ int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
 static inline bool fault_pending(const tepose_model* m) {
   return m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) != 0u;
 }
+// entry of a forward that owns status words in `workspace`: refused while the word is raised, else noted with the collection count it starts under
+static inline int forward_begin(const tepose_model* m, const void* workspace) {
+  { const int rc = forward_begin(m, workspace); if (rc) return rc; }
+  if (workspace) {
+    std::lock_guard<std::mutex> g(m->q_mu);
+    if (m->q_gen.size() > 4096) m->q_gen.clear();        // callers that never reuse a workspace: an unknown workspace takes the slow path, which is always right
+    m->q_gen[workspace] = m->collected;
+  }
+  return 0;
+}
+static inline void fault_collected(const tepose_model* m) {
+  std::lock_guard<std::mutex> g(m->q_mu);
+  ++m->collected;
+}
 static inline bool persist_on(const tepose_model* m) {
   return __atomic_load_n(&m->persist, __ATOMIC_RELAXED) && m->fault != nullptr;   // (tepose_set_persistent may run on another thread)
 }
@@ -840,7 +863,7 @@ int tepose_status(tepose_model* m, void* stream) {
   CK(hipStreamSynchronize((hipStream_t)stream));
   if (!m->fault) return 0;
   const unsigned code = __atomic_exchange_n(m->fault, 0u, __ATOMIC_RELAXED);
-  if (code) m->last_fault_code = (int)code;
+  if (code) { m->last_fault_code = (int)code; fault_collected(m); }
   return code != 0u ? TEPOSE_E_TIMEOUT : 0;
 }
 
@@ -850,8 +873,13 @@ int tepose_forward_status(tepose_model* m, void* workspace, void* stream) {
   CK(hipStreamSynchronize(s));
   // every give-up raises BOTH the forward's status word (workspace) and the handle's fault word (pinned host memory, system scope): with the stream
   // drained, a clear fault word means no forward of this handle gave up -- one host-memory read, no copy (the D2H copy + two null-stream
-  // memsets per small-batch forward of sync mode)
-  if (m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) == 0u) return 0;
+  // memsets per small-batch forward of sync mode) -- PROVIDED nobody has collected a fault since this forward was queued (another thread's
+  // tepose_status / tepose_forward_status clears the shared word; this forward's own status word is then the only trace of its give-up)
+  if (m->fault && __atomic_load_n(m->fault, __ATOMIC_RELAXED) == 0u) {
+    std::lock_guard<std::mutex> g(m->q_mu);
+    auto it = m->q_gen.find(workspace);
+    if (it != m->q_gen.end() && it->second == m->collected) return 0;
+  }
   // the sync region is the first carve of every workspace (carve_encoder / carve_regressor): [.. | gru status | .. | reg status]
   unsigned* sy = (unsigned*)workspace;
   // one copy of the span [recurrent status .. regressor status] (129 words: the regressor's arrival counters lie between them), on the caller's stream
@@ -866,7 +894,7 @@ int tepose_forward_status(tepose_model* m, void* workspace, void* stream) {
   CK(hipMemsetAsync(sync_reg_status(m, sy), 0, sizeof(unsigned), s));
   CK(hipStreamSynchronize(s));
   m->last_fault_code = (int)(st[0] ? st[0] : st[1]);
-  if (m->fault) __atomic_store_n(m->fault, 0u, __ATOMIC_RELAXED);   // or every entry point would go on refusing
+  if (m->fault && __atomic_exchange_n(m->fault, 0u, __ATOMIC_RELAXED) != 0u) fault_collected(m);   // (cleared, or every entry point would go on refusing)
   return TEPOSE_E_TIMEOUT;
 }
 
@@ -1313,6 +1341,7 @@ int tepose_profile_enable(tepose_model* m, int on) {
   m->prof_flops = 0.0;
   m->ev_gru_used = 0;
   m->prof_gru_flops = 0.0;
+  m->prof_l1_flops = 0.0;
   return 0;
 }
 
@@ -1533,6 +1562,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       }
       gf = w.gf; grr = w.grr; grf = w.grf;
       ldg = H3;
+      if (m->prof) mm->prof_l1_flops += 2.0 * 3.0 * m->H * ((double)B * T * m->H + (double)B * T * 2.0 * m->H + (double)(top ? B : B * T) * 2.0 * m->H);
     }
     // offset of sequence position q (a frame t for layer 0, a time-major slab otherwise)
     auto goff = [&](int q) -> long { return (long)q * Bs * H3; };
@@ -1718,12 +1748,33 @@ int tepose_profile_read_gru(tepose_model* m, double* total_ms, int* n_forwards, 
   *flops_per_forward = nf > 0 ? m->prof_gru_flops / nf : 0.0;
   m->ev_gru_used = 0;
   m->prof_gru_flops = 0.0;
+  m->prof_l1_flops = 0.0;
+  return 0;
+}
+
+// the layer >= 1 input projections are what runs between the end of layer l-1's step sequence and the start of layer l's:
+// the gaps of the GRU interval list.  Does not reset (tepose_profile_read_gru does): call it first.
+int tepose_profile_read_l1proj(tepose_model* m, double* total_ms, int* n_forwards, double* flops_per_forward) {
+  if (!m || !total_ms || !n_forwards || !flops_per_forward) return TEPOSE_E_ARG;
+  const size_t per = 2 * (size_t)m->L;
+  double tot = 0.0;
+  for (size_t f = 0; (f + 1) * per <= m->ev_gru_used; ++f)
+    for (int l = 1; l < m->L; ++l) {
+      CK(hipEventSynchronize(m->ev_gru[f * per + 2 * l]));
+      float ms = 0.f;
+      CK(hipEventElapsedTime(&ms, m->ev_gru[f * per + 2 * l - 1], m->ev_gru[f * per + 2 * l]));
+      tot += ms;
+    }
+  const int nf = (int)(m->ev_gru_used / per);
+  *total_ms = tot;
+  *n_forwards = nf;
+  *flops_per_forward = nf > 0 ? m->prof_l1_flops / nf : 0.0;
   return 0;
 }
 
 int tepose_encoder_fwd(const tepose_model* m, const float* x, int B, int T, int is_train, float* feat,
                        void* workspace, size_t ws_bytes, void* stream) {
-  if (m && fault_pending(m)) return TEPOSE_E_TIMEOUT;       // an earlier forward on this handle gave up: say so before more work is queued
+  if (m) { const int rc = forward_begin(m, workspace); if (rc) return rc; }   // an earlier forward on this handle gave up: say so before more work is queued
   return encoder_fwd_impl(m, x, B, T, is_train, feat, workspace, ws_bytes, stream, nullptr, nullptr, false, nullptr);
 }
 
@@ -1949,7 +2000,7 @@ int tepose_window_step(const tepose_model* m, const float* feat_prev, const floa
                        void* workspace, size_t ws_bytes, void* pair_workspace, size_t pair_ws_bytes, void* stream) {
   if (!m || m->kind != 0 || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
-  if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
+  { const int rc = forward_begin(m, workspace); if (rc) return rc; }
   if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
   // the forward's sync region: the first carve of its workspace (as tepose_forward_cached lays it out)
   void* zero = nullptr;
@@ -1987,7 +2038,7 @@ int forward_cached_impl(const tepose_model* m, const float* ring_base, int ring,
       first_slot < 0 || first_slot >= ring)
     return TEPOSE_E_ARG;
   if (!m->enc_packed) return TEPOSE_E_STATE;
-  if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
+  { const int rc = forward_begin(m, workspace); if (rc) return rc; }
   if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   // [shared scratch | feature]: the scratch comes FIRST, so that its first carve -- the sync region with the forward's status
@@ -2021,7 +2072,7 @@ int tepose_regressor_fwd_init(const tepose_model* m, const float* feat, int N, i
                               const float* init_shape, const float* init_cam, const void* jreg_packed, float* theta,
                               float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                               void* stream) {
-  if (m && fault_pending(m)) return TEPOSE_E_TIMEOUT;
+  if (m) { const int rc = forward_begin(m, workspace); if (rc) return rc; }
   return regressor_impl(m, feat, N, n_iter, init_pose, init_shape, init_cam, jreg_packed, theta, verts, kp_3d, kp_2d,
                         rotmat, workspace, ws_bytes, stream, false, false);
 }
@@ -2128,7 +2179,7 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
                    float* verts, float* kp_3d, float* kp_2d, float* rotmat, void* workspace, size_t ws_bytes,
                    void* stream) {
   if (!m || !workspace || B < 1 || T < 1) return TEPOSE_E_ARG;
-  if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
+  { const int rc = forward_begin(m, workspace); if (rc) return rc; }
   if (ws_bytes < tepose_workspace_bytes(m, B, T)) return TEPOSE_E_WORKSPACE;
   // [shared scratch | feature]: the encoder's scratch is dead once `feat` exists; the scratch comes FIRST, so that its first
   // carve -- the sync region with the forward's status words -- sits at the workspace base for every entry point

@@ -300,8 +300,11 @@ class Engine:
             elif self.lib.tepose_status_peek(self.handle) == _lib.E_TIMEOUT:
                 # large batch: not synchronised by the library, but a fault word raised by a forward that has ALREADY finished (one host-memory read)
                 # is reported now rather than at the next call
+                # (handle-wide: the forward that gave up may be another caller's -- its own tepose_forward_status still reports it, the library
+                # tracks collections per forward -- but the handle is switched like on every other path, so the raise is never the only effect)
                 self.lib.tepose_status(self.handle, self._stream())
                 self._raise_if_kernel_fault('a forward on this handle')
+                self._degrade('a small-batch forward on this handle gave up; its outputs are invalid')
                 _lib.check(_lib.E_TIMEOUT, 'tepose_status')
         return out
 
@@ -542,6 +545,13 @@ class Engine:
         ms, n, fl = c_double(), c_int(), c_double()
         _lib.check(self.lib.tepose_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
                    'tepose_profile_read')
+        return ms.value, n.value, fl.value
+
+    def profile_read_l1proj(self):
+        """(ms, forwards, flops per forward) of the layer >= 1 input projections; call before profile_read_gru (which resets)."""
+        ms, n, fl = c_double(), c_int(), c_double()
+        _lib.check(self.lib.tepose_profile_read_l1proj(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
+                   'tepose_profile_read_l1proj')
         return ms.value, n.value, fl.value
 
     def profile_read_gru(self):

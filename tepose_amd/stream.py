@@ -78,6 +78,8 @@ class StreamSession:
                     self.win.copy_(self.saved)
             if self.use_graph:
                 self._capture()
+            else:
+                self._captured_for = self._signature()
         self.stream.synchronize()
 
     # one step, queued on the current stream: what the graph captures
@@ -101,6 +103,25 @@ class StreamSession:
         eng = self.model._engine
         return (eng.packed_generation, eng.blob.data_ptr() if eng.blob is not None else 0, self.ws.data_ptr())
 
+    def _refresh(self):
+        """Before a step: re-pack if the model's parameters changed in place since the last pack (outside any capture -- a replay would go on
+        using the old packed blob without a sign), grow the session's workspace if the packed model now needs more, and re-capture a graph
+        whose blob / workspace are no longer the ones it was captured against.  Same for the eager (graph=False) session."""
+        eng = self.model._engine
+        with torch.cuda.stream(self.stream):
+            eng.pack_model(self.model, self.dev)                       # no-op while the parameter signatures stand
+        if self._signature() == self._captured_for:
+            return
+        need = eng.workspace_bytes(1, self.T)
+        if self.ws.numel() < need:
+            self.stream.synchronize()
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        if self.graph is not None:
+            with torch.cuda.stream(self.stream):
+                self._capture()
+        else:
+            self._captured_for = self._signature()
+
     def _capture(self):
         """Queue-free capture of one step with the session's own workspace; remembers which packed blob it was captured
         against (a re-pack or an adopted blob invalidates the graph: push() re-captures)."""
@@ -118,14 +139,9 @@ class StreamSession:
         if torch.is_tensor(feature) and feature.is_cuda:
             feature = feature.cpu()
         self.feat_host.copy_(torch.as_tensor(feature, dtype=torch.float32).reshape(2048))
-        if self.graph is not None and self._signature() != self._captured_for:
-            # the blob the graph was captured against was re-packed (another caller's forward after a weight change: kernel
-            # selection may differ, e.g. the fp16-range fallback) or replaced (adopt_blob, device move): capture again
-            need = eng.workspace_bytes(1, self.T)
-            if self.ws.numel() < need:
-                self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-            with torch.cuda.stream(self.stream):
-                self._capture()
+        # the blob the graph was captured against may have been re-packed (a weight change, here or by another caller: kernel selection may
+        # differ, e.g. the fp16-range fallback) or replaced (adopt_blob, device move)
+        self._refresh()
         for attempt in (0, 1):
             with torch.cuda.stream(self.stream), eng.use_workspace(self.ws):
                 if self.graph is not None:
@@ -141,6 +157,7 @@ class StreamSession:
                 _lib.check(_lib.E_TIMEOUT, 'StreamSession.push')
             # a persistent kernel gave up inside the replayed graph: clear, switch kernels, re-capture, recompute this frame
             eng.lib.tepose_status(eng.handle, self.stream.cuda_stream)
+            eng._raise_if_kernel_fault('StreamSession.push')             # code 4: not a residency problem -- no switch, no re-run
             eng._degrade('StreamSession recomputes this frame and re-captures its graph')
             with torch.cuda.stream(self.stream):
                 self.win.copy_(self.saved)

@@ -77,3 +77,25 @@ def test_self_launch_builds_the_drivers_command_line(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
     assert cmd[-6:] == ['--gpus', '8', '--steps', '5', '--warmup', '2'] and cmd[-7].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_flat_scalars_surface_the_secondary_results_at_top_level():
+    """The driver's record keeps top-level values only: the strict-arithmetic figure and the other kernels' fractions must be scalars of
+    the JSON line itself, and the dtype string must survive a 120-character cut."""
+    res = {'value': 300000.0,
+           'exact_fp32_mode': {'value': 90000.0, 'ms_per_step': 91.0, 'whole_path_frac_of_f32_mfma_peak': 0.86, 'roofline': {'frac': 0.87}},
+           'roofline': {'avg_ms': 10.5}, 'roofline_gru_steps': {'frac': 0.5, 'ms_per_forward': 9.9, 'traffic_ratio': 2.3},
+           'roofline_l1_projections': {'frac': 0.54, 'ms_per_forward': 5.8},
+           'eval_driver': {'projection_cache': {'frames_per_s': 110000.0, 'ms_per_lock_step': 0.159, 'seconds': 0.3}, 'speedup_vs_reference_cpu_loop': 4000.0},
+           'other_shapes': {'cfgB_b64_T16': {'ms_per_forward': 0.52}, 'cfgA_b1_T16': {'ms_per_forward': 0.135}, 'note': 'x'},
+           'cpu_baseline': {'value': 300.0, 'cores': 8}}
+    f = bench.flat_scalars(res)
+    for k in ('value_exact_fp32', 'ms_per_step_exact_fp32', 'frac_exact_fp32_of_f32_mfma_peak', 'gru_steps_frac', 'gru_steps_traffic_ratio',
+              'l1_projection_frac', 'eval_frames_per_s', 'eval_ms_per_lock_step', 'cfgB_ms', 'cfgA_ms'):
+        assert isinstance(f[k], float), k
+    assert f['speedup_vs_cpu_baseline'] == 1000.0 and f['speedup_exact_fp32_vs_cpu_baseline'] == 300.0
+    assert 'cfgE_ms' not in f                                   # absent sources stay absent
+    assert bench.flat_scalars({'value': 1.0}) == {}
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    line = [l for l in src.splitlines() if 'value_exact_fp32' in l and 'MFMAs' in l][0]
+    assert len(line.strip().strip(",'")) <= 120

@@ -251,3 +251,66 @@ def test_barrier_free_projection_give_up_reaches_the_failure_channel(smpl_np, mo
         ref = O.encoder_fwd(enc, x[:64].cpu().double(), 2)
     assert (good[:64].cpu().double() - ref).abs().max() < 2e-5
     del feat
+
+
+def test_a_fault_collected_by_another_caller_is_still_reported_to_its_forward(smpl_np, monkeypatch):
+    """the handle's fault word is shared by every stream and thread and ANY status call clears it.  Forward A gives up; before
+    A's caller asks, another caller collects the word handle-wide (tepose_status).  A's own tepose_forward_status must not take the clear
+    word for "nobody gave up": the library counts collections and falls back to A's status words -- TEPOSE_E_TIMEOUT, exactly once."""
+    from tepose_amd import _lib
+    model, _ = _faulty_model(monkeypatch, smpl_np, 1, mode='lazy')
+    eng, lib = model._engine, model._engine.lib
+    x = torch.from_numpy(synth.synthetic_windows(2, 5, 16)).cuda()
+    with torch.no_grad():
+        out = model(x)[0]                                           # lazy mode: queued, gives up, nobody has looked yet
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tepose_status(eng.handle, st) == _lib.E_TIMEOUT      # the other caller: syncs, collects, clears
+    assert lib.tepose_status_peek(eng.handle) == 0
+    assert not torch.isfinite(out['verts']).all()
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == _lib.E_TIMEOUT
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == 0
+
+
+def test_sync_mode_never_returns_nan_while_another_thread_polls_the_handle(smpl_np, monkeypatch):
+    """The same race with real threads: a poller calls tepose_status on a side stream in a loop while the main thread runs faulting
+    forwards in the default (sync) mode, re-arming the persistent kernels every time.  Every forward must come back repaired (finite,
+    equal to the step-per-launch result) although the poller regularly gets to the fault word first."""
+    import threading
+    import time
+    model, _ = _faulty_model(monkeypatch, smpl_np, 1)
+    eng, lib = model._engine, model._engine.lib
+    x = torch.from_numpy(synth.synthetic_windows(3, 5, 17)).cuda()
+    side = torch.cuda.Stream()
+    stop, stolen = threading.Event(), [0]
+
+    def poll():
+        while not stop.is_set():
+            if lib.tepose_status(eng.handle, side.cuda_stream) != 0:
+                stolen[0] += 1
+            time.sleep(0.0005)
+
+    th = threading.Thread(target=poll)
+    th.start()
+    try:
+        ref = None
+        for it in range(12):
+            eng.set_persistent(True)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                try:
+                    with torch.no_grad():
+                        out = model(x)[0]
+                except Exception as e:                              # refused up front because the poller has not collected yet: fine, never silent
+                    from tepose_amd import _lib
+                    assert isinstance(e, _lib.TeposeTimeout)
+                    continue
+            torch.cuda.synchronize()
+            assert torch.isfinite(out['verts']).all() and torch.isfinite(out['theta']).all(), it
+            if ref is None:
+                ref = out['verts'].clone()
+            assert torch.equal(out['verts'], ref), it
+    finally:
+        stop.set()
+        th.join()
+    assert ref is not None
+    print('  poller collected the fault word first in %d of 12 forwards' % stolen[0])
