@@ -559,7 +559,7 @@ static inline bool fault_pending(const tepose_model* m) {
 }
 // entry of a forward that owns status words in `workspace`: refused while the word is raised, else noted with the collection count it starts under
 static inline int forward_begin(const tepose_model* m, const void* workspace) {
-  { const int rc = forward_begin(m, workspace); if (rc) return rc; }
+  if (fault_pending(m)) return TEPOSE_E_TIMEOUT;
   if (workspace) {
     std::lock_guard<std::mutex> g(m->q_mu);
     if (m->q_gen.size() > 4096) m->q_gen.clear();        // callers that never reuse a workspace: an unknown workspace takes the slow path, which is always right
