@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(512) gemm_h3s_persist16c_kernel(H3SArgs a, int
 static constexpr int kMaxDev = 64;
 static unsigned* g_h3s16c_err[kMaxDev] = {};
 
-static unsigned* h3s16c_err_of_current_device() {
+unsigned* h3s16c_err_of_device() {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return nullptr; }
   return __atomic_load_n(&g_h3s16c_err[dev], __ATOMIC_ACQUIRE);
@@ -353,7 +353,7 @@ hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag) {
   // row tiles per XCD group of the walk (the 32 workgroups of an XCD take GM x 32 / GM tiles at a time); layer-0 projection, ms at GM = 2 / 4 / 8 / 16 / 32:
   // 10.92 / 10.82 / 10.74 / 11.37 / 12.37 (round 4)
   static const int gm = [] { const char* e = getenv("TEPOSE_S16_GM"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 32 ? v : 8; }();
-  unsigned* err = h3s16c_err_of_current_device();
+  unsigned* err = h3s16c_err_of_device();
   if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, err);
   else hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, err);
   return hipGetLastError();

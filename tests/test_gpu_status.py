@@ -237,7 +237,10 @@ def test_barrier_free_projection_give_up_reaches_the_failure_channel(smpl_np, mo
             with torch.no_grad():
                 model.encoder(x)
     assert not eng.degraded and eng.uses_persistent(1)
-    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == 0       # collected handle-wide by the refusal: reported once in total
+    # the refusal collected the HANDLE's word; the forward's own status words still answer for that forward (a handle-wide collection -- by
+    # this caller or any other thread -- must not hide a give-up from the forward's own check), once
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == _lib.E_TIMEOUT
+    assert lib.tepose_forward_status(eng.handle, eng._ws.data_ptr(), st) == 0
     # without the injected fault the same handle is healthy again
     assert lib.tepose_debug_set_test_fault(eng.handle, 0) == 0
     eng.check_status()
