@@ -142,6 +142,9 @@ def flat_scalars(res):
         'eval_ms_per_lock_step': ('eval_driver', 'projection_cache', 'ms_per_lock_step'),
         'eval_seconds': ('eval_driver', 'projection_cache', 'seconds'),
         'eval_speedup_vs_reference_cpu_loop': ('eval_driver', 'speedup_vs_reference_cpu_loop'),
+        'eval_model_critical_path_seconds': ('eval_driver', 'lockstep_cost_model', 'critical_path_seconds'),
+        'eval_model_predicted_speedup_8gpu': ('eval_driver', 'lockstep_cost_model', 'predicted_speedup', '8'),
+        'eval_model_predicted_over_measured_1gpu': ('eval_driver', 'lockstep_cost_model', 'predicted_over_measured_world1'),
         'cfgB_ms': ('other_shapes', 'cfgB_b64_T16', 'ms_per_forward'),
         'cfgA_ms': ('other_shapes', 'cfgA_b1_T16', 'ms_per_forward'),
         'cfgE_ms': ('other_shapes', 'cfgE_b1_T32_stream', 'ms_per_forward'),
@@ -328,6 +331,14 @@ def eval_driver_block(model, state, smpl_np, device, L, H, cpu_budget_s=8.0, wit
             os.environ.pop('TEPOSE_DRIVER_CACHE', None)
         else:
             os.environ['TEPOSE_DRIVER_CACHE'] = old
+    # the lock-step cost model behind the clip partitioner (tepose_amd.distributed.StepCost): its table re-measured on this box, its prediction for THIS
+    # database at world 1 next to the measurement above, and its projection for 2 / 4 / 8 GPUs -- MODEL, not measurement (the driver measures the real curve)
+    from tepose_amd.distributed import StepCost, predicted_scaling
+    from tepose_amd.evaluate import measure_step_ms
+    table = measure_step_ms(model, T, J_regressor=J)
+    out['step_ms_table'] = {str(k): v for k, v in table.items()}
+    out['lockstep_cost_model'] = predicted_scaling([int(n) for n in lens], T, StepCost(table))
+    out['lockstep_cost_model']['predicted_over_measured_world1'] = out['lockstep_cost_model']['predicted_seconds']['1'] / out['projection_cache']['seconds']
     if with_cpu:
         # the reference's loop for ONE clip on the host cores: B = 1 windows, strictly serial (best thread count of 1 / 4 / 8)
         from oracle import tepose_ref as O

@@ -84,8 +84,6 @@ struct tepose_model {
   bool persist = true;                          // false: step-per-launch kernels at every batch size (tepose_set_persistent)
   unsigned spin_limit = 1u << 21;               // polls (~1 us each) before a wait gives up
   int blend16_min_n = 512;                      // TEPOSE_BLEND16_MIN_N: rows from which the blend-shape product runs on gemm_h3s_persist16c_kernel (0x7fffffff = never)
-  int gru_wide = 0;                             // TEPOSE_GRU_WIDE=1: plane-fed step of batches with B % 256 == 0 on the barrier-free 256-row-tile kernel (gru_step16w.hip)
-  int gruw_gm = 8;                              // TEPOSE_GRUW_GM: row tiles per XCD group of its walk
   int gi_blk = 1;                               // TEPOSE_GI_BLK: large batches keep the layer >= 1 gate pre-activations in the 16 x 16-blocked layout (common.h gi_blk_offset)
   int last_fault_code = 0;                      // the kernel code of the last fault a status call collected (tepose_fault_code)
   // The fault word is shared by every stream and thread of the handle and ANY status call clears it, so "the word is clear" says nothing about one
@@ -592,7 +590,6 @@ struct KernelPlan {
   bool scaled = false;        // large batch: recurrent-state planes in the scaled format, layer >= 1 projections and cell steps on the scaled-plane kernels
   bool gblk = false;          // ... with the layer >= 1 gate pre-activations and the fp32 states between steps in the 16 x 16-blocked layout
   bool planes_state = false;  // ... and the step kernel's PLANES instantiation (every tile full: B % 128 == 0)
-  bool wide_step = false;     // ... on the barrier-free 256-row-tile kernel (gru_step16w.hip; B % 256 == 0, TEPOSE_GRU_WIDE)
   bool g0big = false, g0mid = false, g0blk = false, g0skinny = false;     // layer-0 projection class
   bool seq2 = false, seq3 = false;   // the persistent recurrent kernel serves 2- / 3-direction layers of this (B, T)
   bool step_skinny = false;   // (not scaled, not seq) width-first step kernel
@@ -607,7 +604,6 @@ KernelPlan select_kernels(const tepose_model* m, int B, int T, bool assume_ready
   k.scaled = k.h3 && m->large_scaled && B >= m->s_min_b;
   k.gblk = k.scaled && m->gi_blk && Hp % 32 == 0;
   k.planes_state = k.gblk && m->state_planes && B % 128 == 0;
-  k.wide_step = k.planes_state && m->gru_wide != 0 && B % 256 == 0;
   // layer-0 projection
   k.g0big = k.h3 && m->large_scaled && L >= 2 && BT >= 8192;
   static const int g0mid_min = [] { const char* e = getenv("TEPOSE_G0_MID_MIN_ROWS"); return e ? atoi(e) : 512; }();
@@ -648,7 +644,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   const bool seq_l0 = L == 1 ? k.seq2 : k.seq3;
   s += ";gru_step=";
   s += !k.h3 ? (B <= skinny_max_m() ? "skinny_gru_kernel" : "gru_step_kernel")
-       : k.scaled ? (k.planes_state && k.g0blk ? (k.wide_step ? "gru_step16w_kernel" : "gru_step16_kernel<true>") : "gru_step16_kernel<false>")
+       : k.scaled ? (k.planes_state && k.g0blk ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>")
        : seq_l0 ? (B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024 ? "gru_seq_kernel(granules)" : "gru_seq_kernel")
        : k.step_skinny ? "skinny_gru_h3_kernel" : "gemm_h3_kernel<GRU>";
   s += ";gru_first=";
@@ -657,7 +653,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
     s += ";projection_l1=";
     s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= l1_skinny_max_rows() ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
     s += std::string(";gi1_layout=") + (k.gblk ? "blocked" : "row_major");
-    if (k.scaled) s += std::string(";gru_step_l1=") + (k.planes_state ? (k.wide_step ? "gru_step16w_kernel" : "gru_step16_kernel<true>") : "gru_step16_kernel<false>");
+    if (k.scaled) s += std::string(";gru_step_l1=") + (k.planes_state ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>");
   }
   s += ";tail_regressor=";
   s += !k.reg_split ? "gemm_f32_kernel x (2 + 1 + 9)" : (m->tail_collapsed || !m->enc_packed) && m->collapse_env ? "collapsed: one product (skinny_gemm_h3_kernel / gemm_h3_kernel)"
@@ -706,10 +702,6 @@ static void read_env_knobs(tepose_model* m) {
   m->blend16_min_n = e ? atoi(e) : 512;
   e = getenv("TEPOSE_GI_BLK");
   m->gi_blk = e ? atoi(e) : 1;
-  e = getenv("TEPOSE_GRU_WIDE");
-  m->gru_wide = e ? atoi(e) : 0;
-  e = getenv("TEPOSE_GRUW_GM");
-  m->gruw_gm = e && atoi(e) >= 1 && atoi(e) <= 64 ? atoi(e) : 8;
   refresh_kernel_info(m);
 }
 
@@ -1472,7 +1464,6 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       // wrote them frame-major + blocked (g0blk; not from the driver's cache ring).  One decision per layer: every step of a layer runs the same kernel.
       bool planes = plan.planes_state;
       for (int d = 0; d < a.ndir; ++d) planes = planes && a.d[d].gi_blk != 0;
-      if (planes && plan.wide_step && gru_step16w_ok(b)) return (int)launch_gru_step16w(b, s, m->gruw_gm);
       return (int)launch_gru_step16(b, s, planes);
     }
     H3Batch b{};

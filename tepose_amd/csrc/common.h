@@ -351,9 +351,6 @@ void h3s16c_warm();                    // allocates the current device's debug e
 bool gru_step16_ok(const H3SBatch& b);
 bool gru_step16_planes_ok(const H3SBatch& b);
 hipError_t launch_gru_step16(const H3SBatch& b, hipStream_t s, bool planes);
-// gru_step16w.hip: the plane-fed step on the barrier-free pipeline, 256-row tiles, one persistent workgroup per CU (M % 256 == 0)
-bool gru_step16w_ok(const H3SBatch& b);
-hipError_t launch_gru_step16w(const H3SBatch& b, hipStream_t s, int gm);
 unsigned* h3s16c_err_of_device();      // the current device's debug counter of give-ups of the barrier-free kernels (nullptr: none)
 bool gemm_h3s_mid_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s);   // 128 x 288 tiles, N % 288 == 0

@@ -11,10 +11,61 @@ import torch
 import torch.distributed as dist
 
 
-def partition_clips(lengths, world_size):
-    """Longest-processing-time greedy: clips sorted by frame count (ties by index), each
-    goes to the currently lightest rank.  Returns a list of index lists, one per rank.
-    Deterministic, so every rank computes the same partition without communicating."""
+# ms of ONE lock-step of tepose_amd.driver.run_clips (= one tepose_window_step call: pair projection, 2 recurrent launches per layer, layer-1
+# projections, collapsed tail, SMPL) against the number of clips still active, published architecture (L = 2, H = 1024), seqlen 6, 1 x MI355X --
+# measured points (profiles/r06_step_ms.json; bench.py `eval_driver.step_ms_table` re-measures them on the box it runs on); linear in between and beyond.
+DEFAULT_STEP_MS = {1: 0.093, 2: 0.100, 5: 0.118, 10: 0.135, 19: 0.159, 37: 0.217, 64: 0.30}
+
+
+class StepCost(object):
+    """step_ms(B): piecewise-linear through measured (active clips, ms per lock-step) points; a MODEL, not a measurement."""
+
+    def __init__(self, table=None):
+        pts = sorted((int(b), float(ms)) for b, ms in (table or DEFAULT_STEP_MS).items())
+        if not pts or pts[0][0] < 1:
+            raise ValueError('step-cost table needs points at B >= 1')
+        self.pts = pts
+
+    def __call__(self, B):
+        B = int(B)
+        if B <= 0:
+            return 0.0
+        p = self.pts
+        if len(p) == 1:
+            return p[0][1]
+        if B <= p[0][0]:
+            lo, hi = p[0], p[1]
+        elif B >= p[-1][0]:
+            lo, hi = p[-2], p[-1]
+        else:
+            k = max(i for i in range(len(p) - 1) if p[i][0] <= B)
+            lo, hi = p[k], p[k + 1]
+        ms = lo[1] + (hi[1] - lo[1]) * (B - lo[0]) / float(hi[0] - lo[0])
+        return max(ms, 0.5 * p[0][1])
+
+
+def lockstep_seconds(lengths, seqlen, step_ms):
+    """Predicted seconds of ONE rank advancing clips of these frame counts in lock-step (driver.run_clips; the reference's loop evaluate.py:247-269 and
+    trainer.py:313-344 per clip): lock-step j serves the clips that still have a window j, sum_j step_ms(active(j)).  Windows of a clip are serial, so this is
+    never below (longest clip's windows) x step_ms(1)."""
+    w = sorted((max(int(n) - int(seqlen) + 1, 0) for n in lengths), reverse=True)
+    total, prev = 0.0, 0
+    # w[k] windows are served by k + 1 or more clips: steps w[k+1] .. w[k] - 1 have exactly k + 1 active clips
+    for k in range(len(w) - 1, -1, -1):
+        if w[k] > prev:
+            total += (w[k] - prev) * step_ms(k + 1)
+            prev = w[k]
+    return total / 1e3
+
+
+def partition_clips(lengths, world_size, step_ms=None, seqlen=6):
+    """Clips -> ranks; returns a list of index lists, one per rank.  Deterministic, so every rank computes the same partition without communicating.
+    step_ms=None (default; the synthetic weak-scaling bench): longest-processing-time greedy on FRAME totals -- clips sorted by frame count (ties by
+    index), each goes to the currently lightest rank.
+    step_ms=StepCost / callable (the clip-sharded evaluation): the executor advances a rank's clips in LOCK-STEP, so a rank's time is
+    lockstep_seconds(its clips), dominated by its longest clip, not by its frame total.  Greedy by descending length on the predicted finish time: each
+    clip goes to the rank whose predicted time AFTER taking it is smallest (ties: fewer frames, lower rank); the frame-LPT partition is kept when the
+    model predicts no gain."""
     order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
     loads = [0] * world_size
     parts = [[] for _ in range(world_size)]
@@ -22,7 +73,32 @@ def partition_clips(lengths, world_size):
         r = min(range(world_size), key=lambda k: (loads[k], k))
         parts[r].append(i)
         loads[r] += int(lengths[i])
-    return parts
+    if step_ms is None or world_size <= 1:
+        return parts
+    cost = lambda p: lockstep_seconds([lengths[i] for i in p], seqlen, step_ms)
+    mine = [[] for _ in range(world_size)]
+    secs, frames = [0.0] * world_size, [0] * world_size
+    for i in order:
+        cand = [(cost(mine[r] + [i]), frames[r], r) for r in range(world_size)]
+        t, _, r = min(cand)
+        mine[r].append(i)
+        secs[r], frames[r] = t, frames[r] + int(lengths[i])
+    return mine if max(secs) < max(cost(p) for p in parts) else parts
+
+
+def predicted_scaling(lengths, seqlen, step_ms, worlds=(1, 2, 4, 8)):
+    """The cost model's view of clip-sharded evaluation (MODEL, not measurement): per world size the predicted makespan of the lock-step-aware
+    partition and of frame-LPT, plus the critical path no sharding can beat -- the longest clip alone on a GPU."""
+    w_max = max([max(int(n) - int(seqlen) + 1, 0) for n in lengths] + [0])
+    out = {'model': 'sum over lock-steps of step_ms(active clips); NOT a measurement', 'critical_path_seconds': w_max * step_ms(1) / 1e3,
+           'step_ms_points': [[b, ms] for b, ms in getattr(step_ms, 'pts', [])], 'predicted_seconds': {}, 'predicted_seconds_frame_lpt': {}}
+    for n in worlds:
+        for key, sm in (('predicted_seconds', step_ms), ('predicted_seconds_frame_lpt', None)):
+            parts = partition_clips(lengths, n, sm, seqlen)
+            out[key][str(n)] = max(lockstep_seconds([lengths[i] for i in p], seqlen, step_ms) for p in parts)
+    one = out['predicted_seconds']['1']
+    out['predicted_speedup'] = {k: (one / v if v > 0 else 1.0) for k, v in out['predicted_seconds'].items()}
+    return out
 
 
 def imbalance(lengths, parts):

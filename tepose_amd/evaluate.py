@@ -65,14 +65,15 @@ def clip_metric_record(model, clip_id, clip, pred_j3d, pred_verts, dataset='3dpw
 
 
 @torch.no_grad()
-def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='3dpw', rank=0, world=1):
+def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='3dpw', rank=0, world=1, step_ms=None):
     """clips: OrderedDict name -> dict(features[N,2048], joints3D[N,J,3], theta_pseu[N,85], pose, shape).
     Returns ([n_local_clips, 8] float64 record tensor, list of local clip indices)."""
     dev = next(model.parameters()).device
     T = int(seqlen)
     names = list(clips.keys())
     lengths = [len(clips[n]['features']) for n in names]
-    mine = D.partition_clips(lengths, world)[rank]
+    # the executor below advances a rank's clips in lock-step: partition on the lock-step cost model, not on frame totals (distributed.partition_clips)
+    mine = D.partition_clips(lengths, world, step_ms=step_ms if step_ms is not None else D.StepCost(), seqlen=T)[rank]
     mine = [i for i in mine if lengths[i] >= T]                       # evaluate.py:226-227
     if not mine:
         return torch.zeros(0, 8, dtype=torch.float64, device=dev), mine
@@ -90,6 +91,32 @@ def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='
             recs.append(rec)
     out = torch.stack(recs) if recs else torch.zeros(0, 8, dtype=torch.float64, device=dev)
     return out, mine
+
+
+@torch.no_grad()
+def measure_step_ms(model, seqlen, batches=(1, 2, 5, 10, 19, 37), steps=48, J_regressor=None):
+    """{active clips: ms per lock-step of run_clips} measured on this GPU: B synthetic clips of equal length advance `steps` windows in lock-step (what
+    distributed.StepCost interpolates; the committed default table came from this function)."""
+    import time
+    from . import synth
+    dev = next(model.parameters()).device
+    T = int(seqlen)
+    out = {}
+    for B in batches:
+        w = torch.from_numpy(synth.synthetic_windows(int(B), T - 1 + steps, 4242)).to(dev)
+        feats = [w[b, :, :2048].contiguous() for b in range(int(B))]
+        inits = [w[b, :T - 1, 2048:].contiguous() for b in range(int(B))]
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_clips(model, feats, inits, T, J_regressor=J_regressor, keep=('kp_3d', 'verts'))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps * 1e3
+            if rep and (best is None or dt < best):
+                best = dt
+        out[int(B)] = best
+    return out
 
 
 def gather_and_reduce(records):

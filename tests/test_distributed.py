@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tepose_amd.distributed import broadcast_blob, gather_records, imbalance, partition_clips
+from tepose_amd.distributed import (StepCost, broadcast_blob, gather_records, imbalance, lockstep_seconds, partition_clips,
+                                    predicted_scaling)
 
 
 def test_partition_is_a_balanced_exact_cover():
@@ -20,6 +21,42 @@ def test_partition_is_a_balanced_exact_cover():
         assert imbalance(lengths, parts) < 1.6
     assert partition_clips(lengths, 8) == partition_clips(list(lengths), 8)    # deterministic
     assert partition_clips([], 4) == [[], [], [], []]
+
+
+def test_lockstep_cost_model_and_the_partition_built_on_it():
+    """The evaluation executor (driver.run_clips) advances a rank's clips in LOCK-STEP (the reference's serial window loop per clip,
+    evaluate.py:247-269, run for all clips at once): a rank's time is sum_j step_ms(active clips at step j) -- set by its longest clip --
+    not its frame total.  The cost model, the partition that minimises its makespan, and the bound it implies for clip-sharding."""
+    from tepose_amd import synth
+    sc = StepCost({1: 0.1, 10: 0.15, 40: 0.3})
+    assert sc(1) == 0.1 and abs(sc(10) - 0.15) < 1e-12 and abs(sc(25) - 0.225) < 1e-12 and sc(80) > sc(40) and sc(0) == 0.0
+    T = 6
+    # one clip of 105 frames = 100 windows at step_ms(1); two equal clips: the same 100 steps at step_ms(2)
+    assert abs(lockstep_seconds([105], T, sc) - 100 * sc(1) / 1e3) < 1e-12
+    assert abs(lockstep_seconds([105, 105], T, sc) - 100 * sc(2) / 1e3) < 1e-12
+    # ragged: 10 steps with 3 active, 20 more with 2, 70 more with 1; clips shorter than the window contribute nothing
+    assert abs(lockstep_seconds([105, 35, 15, 3], T, sc) - (10 * sc(3) + 20 * sc(2) + 70 * sc(1)) / 1e3) < 1e-12
+    assert lockstep_seconds([], T, sc) == 0.0 and lockstep_seconds([4], T, sc) == 0.0
+    for seed, n in (('a', 37), ('b', 24), ('c', 9), ('d', 3)):
+        lens = [int(v) for v in (300 + 1500 * synth.uniform01('part/' + seed, n))]        # 3DPW-test-like clip lengths
+        full = StepCost()
+        for world in (1, 2, 4, 8):
+            new, old = partition_clips(lens, world, full, T), partition_clips(lens, world)
+            assert sorted(i for p in new for i in p) == list(range(n))                    # exact cover, empty ranks allowed
+            assert len(new) == world
+            mk = lambda parts: max(lockstep_seconds([lens[i] for i in p], T, full) for p in parts)
+            assert mk(new) <= mk(old) + 1e-12                                             # never worse than frame-LPT under the model
+            assert mk(new) >= (max(lens) - T + 1) * full(1) / 1e3 - 1e-12                 # never below the critical path
+        assert partition_clips(lens, 4, full, T) == partition_clips(list(lens), 4, full, T)   # deterministic: every rank computes it alone
+    # what the model says about BASELINE config 4 (3DPW-test-like: 37 clips, longest ~1800 frames): the longest clip's serial chain bounds the
+    # speed-up of clip sharding far below the GPU count -- only the synthetic weak-scaling line (independent windows) can show >= 6x
+    lens = [int(v) for v in (300 + 1500 * synth.uniform01('evalclips', 37))]
+    ps = predicted_scaling(lens, T, StepCost())
+    assert ps['predicted_seconds']['8'] >= ps['critical_path_seconds'] - 1e-12
+    assert 1.0 < ps['predicted_speedup']['8'] < 2.5
+    assert ps['predicted_seconds']['8'] <= ps['predicted_seconds_frame_lpt']['8'] + 1e-12
+    assert 'NOT a measurement' in ps['model']
+    assert partition_clips([], 4, StepCost(), T) == [[], [], [], []]
 
 
 def _free_port():

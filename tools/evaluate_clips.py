@@ -30,7 +30,7 @@ from tepose_amd import synth  # noqa: E402
 from tepose_amd.config import EVAL_SEQLEN, eval_db_paths, update_cfg  # noqa: E402
 from tepose_amd.data import (load_base_data, load_eval_db, load_generator_state_dict, split_db_into_clips,  # noqa: E402
                              synthetic_eval_db)
-from tepose_amd.distributed import imbalance, partition_clips  # noqa: E402
+from tepose_amd.distributed import StepCost, imbalance, partition_clips, predicted_scaling  # noqa: E402
 from tepose_amd.evaluate import evaluate_clips, gather_and_reduce, gather_rank_stats  # noqa: E402
 from tepose_amd.smpl import SMPL  # noqa: E402
 from tepose_amd.testing import build_model  # noqa: E402
@@ -217,7 +217,10 @@ def main():
         frames = int(sum(len(c['features']) for c in clips.values()))
         lens = [len(c['features']) for c in clips.values()]
         out = {'clips': len(clips), 'frames': frames, 'seqlen': T, 'n_gpus': world, 'seconds': float(el.item()),
-               'imbalance_max_over_mean_rank_frames': imbalance(lens, partition_clips(lens, world)),
+               'imbalance_max_over_mean_rank_frames': imbalance(lens, partition_clips(lens, world, StepCost(), T)),
+               # the lock-step cost model's view (MODEL, not measurement): a rank's time is its longest clip's chain of window steps, so clip-sharding a
+               # database whose longest clip dominates cannot scale like the clip count -- predicted makespans for 1 / 2 / 4 / 8 GPUs and the floor
+               'lockstep_cost_model': predicted_scaling(lens, T, StepCost()),
                'per_rank': stats,      # seconds, clips, frames and longest clip (= serial window chain) of every rank
                'frames_per_s': frames / float(el.item()), 'metrics_mm': res,
                'data': 'real' if plan['real'] else 'synthetic db + random-init weights (metric values are meaningless)',

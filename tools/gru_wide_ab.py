@@ -1,4 +1,5 @@
-"""Same-box A/B of the fused GRU step: gru_step16_kernel<true> (128 x 192 tiles, two workgroups per CU, barriers) against gru_step16w_kernel (256 x 192
+"""(Needs the experiment wired in: see the header of tools/micro/gru_step16w_experiment.hip; record: profiles/r06_gru_bigtile.txt.)
+Same-box A/B of the fused GRU step: gru_step16_kernel<true> (128 x 192 tiles, two workgroups per CU, barriers) against gru_step16w_kernel (256 x 192
 tiles on the barrier-free pipeline, one persistent workgroup per CU; TEPOSE_GRU_WIDE=1).  Per batch: bit-identity of the encoder features, then the
 recurrent part per forward (hipEvents around every layer's step sequence: tepose_profile_read_gru) and the whole encoder, interleaved A B A B.
 

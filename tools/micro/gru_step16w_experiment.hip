@@ -1,3 +1,7 @@
+// EXPERIMENT, measured and dropped (profiles/r06_gru_bigtile.txt): not part of the library build.  To reproduce: copy to tepose_amd/csrc/gru_step16w.hip, add it to
+// __graft_entry__.SOURCES, declare gru_step16w_ok / launch_gru_step16w in common.h and call launch_gru_step16w(b, s, gm) from api.hip's `step` lambda where
+// plan.planes_state && B % 256 == 0 (commit "gru_step16w: fused GRU step on the barrier-free pipeline" has that wiring; tools/gru_wide_ab.py, tools/gru_wide_pmc.sh drive it).
+//
 // The fused GRU cell step of large batches on the BARRIER-FREE pipeline with a 256-row tile (round 6).
 //
 // Reference math (lib/models/tepose.py:53-64,73-76 = torch.nn.GRU, gates r, z, n), as gru_step16.hip:
@@ -236,20 +240,28 @@ __global__ void __launch_bounds__(512) gru_step16w_kernel(H3SBatch batch, int ti
       }
       const float inv_ss = 1.f / batch.state_scale;
       const unsigned sp = (unsigned)te * 32u + (unsigned)((((ge >> 1) ^ (te >> 3)) & 1) * 16 + (ge & 1) * 8);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
+      // operands of one row tile: 6 KB of gate pre-activations (blocked: this lane's 16 bytes at lane * 16 of every KB block) + this lane's 4 units of the
+      // hi and lo state planes.  Software-pipelined by hand: row tile i + 1 is requested BEFORE row tile i is computed and stored (left to itself hipcc
+      // keeps every row tile's loads behind the previous one's stores -- they may alias -- and exposes the load latency four times per tile)
+      f32x4w G[2][6];
+      h16x4w QH[2][2], QL[2][2];
+      auto load_rt = [&](int i, int bf) __attribute__((always_inline)) {
         const int rt = (tm0 + wm * 16 * MT + i * 16) >> 4;
-        const int row = rt * 16 + te;
-        f32x4w gr[2], gz[2], gn[2];
-        h16x4w qh[2], ql[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const float* gq = d.gi + (long)rt * d.gi_blk + gi_blk_block(0, jb + u * 16) + le * 4;
-          gr[u] = *(const f32x4w*)gq; gz[u] = *(const f32x4w*)(gq + 256); gn[u] = *(const f32x4w*)(gq + 512);
+          G[bf][u * 3 + 0] = *(const f32x4w*)gq; G[bf][u * 3 + 1] = *(const f32x4w*)(gq + 256); G[bf][u * 3 + 2] = *(const f32x4w*)(gq + 512);
           const long po = (long)((jb >> 4) + u) * a.a_kst + (long)rt * 256;
-          qh[u] = *(const h16x4w*)((const char*)(a.Ah + po) + sp);
-          ql[u] = *(const h16x4w*)((const char*)(a.Al + po) + sp);
+          QH[bf][u] = *(const h16x4w*)((const char*)(a.Ah + po) + sp);
+          QL[bf][u] = *(const h16x4w*)((const char*)(a.Al + po) + sp);
         }
+      };
+      load_rt(0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int bf = i & 1;
+        if (i + 1 < MT) load_rt(i + 1, bf ^ 1);
+        const int row = tm0 + wm * 16 * MT + i * 16 + te;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int j = jb + u * 16 + 4 * ge;
@@ -257,11 +269,11 @@ __global__ void __launch_bounds__(512) gru_step16w_kernel(H3SBatch batch, int ti
           _Float16 hh[4], ll[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float hp = ((float)qh[u][c] + (float)ql[u][c]) * inv_ss;       // exact: 11 + 11 bits, power-of-two scale
+            const float hp = ((float)QH[bf][u][c] + (float)QL[bf][u][c]) * inv_ss;       // exact: 11 + 11 bits, power-of-two scale
             const float hr = acc[i][0 + u][c] * a.inv_scale, hz = acc[i][2 + u][c] * a.inv_scale, hn = acc[i][4 + u][c] * a.inv_scale;
-            const float rg = s16w_sigmoid(gr[u][c] + (hr + br[u][c]));
-            const float zg = s16w_sigmoid(gz[u][c] + (hz + bz[u][c]));
-            const float ng = s16w_tanh(gn[u][c] + rg * (hn + bn[u][c]));
+            const float rg = s16w_sigmoid(G[bf][u * 3 + 0][c] + (hr + br[u][c]));
+            const float zg = s16w_sigmoid(G[bf][u * 3 + 1][c] + (hz + bz[u][c]));
+            const float ng = s16w_tanh(G[bf][u * 3 + 2][c] + rg * (hn + bn[u][c]));
             v[c] = (1.f - zg) * ng + zg * hp;
             const float sv = v[c] * batch.state_scale;
             hh[c] = (_Float16)sv;
