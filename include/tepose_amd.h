@@ -69,6 +69,17 @@ void tepose_destroy(tepose_model* m);
  * (profiles/rNN_traffic_*.json) describes the running binary only if it names the same symbols; bench.py marks it stale
  * otherwise.  The string lives as long as the handle.                                                                    */
 const char* tepose_kernel_info(const tepose_model* m);
+/* Options are PER HANDLE (no global mutable state).  tepose_create reads the environment ONCE into the handle: the numerics / family
+ * knobs (TEPOSE_EXACT_FP32, TEPOSE_LARGE_BATCH_KERNELS, TEPOSE_GRU_STATE, TEPOSE_COLLAPSE_REGRESSOR, TEPOSE_PERSISTENT, ...) and every launch
+ * threshold (csrc/common.h `Options`: SKINNY_MAX_M, SKINNY_H3_MAX_M, SPLIT_MIN_M, SPLIT_FEW_MAX_ROWS, SEQ_MAX_M, SEQ_GRAN_MAX_M, REG_SEQ_MAX_N,
+ * SMPL_SMALL_MAX_N, L1_SKINNY_MAX_ROWS, G0_MID_MIN_ROWS, G0_SKINNY_MAX_M, S16_GM, GRU_GM, H3_TILE64, ASSUME_CUS, ...; plus S_MIN_B,
+ * BLEND16_MIN_N, GI_BLK, SEQ_SPIN_LIMIT).  Nothing in the library reads a threshold from the environment afterwards, and no launcher keeps
+ * process-wide state: two handles of one process may differ.  tepose_set_option changes one integer option of THIS handle by name (with or
+ * without the TEPOSE_ prefix); it is refused with TEPOSE_E_STATE once anything has been packed (workspace sizes and packed planes depend on
+ * the options) and with TEPOSE_E_ARG for an unknown name.  tepose_get_option returns the current value (-1: unknown name).  The handle-less
+ * test entry points (tepose_gemm_f32, tepose_gemm_h3_f32) take the environment's values at each call.                                   */
+int tepose_set_option(tepose_model* m, const char* name, long value);
+long tepose_get_option(const tepose_model* m, const char* name);
 /* The whole kernel selection of an eval forward of B windows x T frames on this handle, family by family ("input=...;projection=...;gi0_layout=...;
  * gru_step=...;gru_first=...;projection_l1=...;gi1_layout=...;tail_regressor=...;smpl=..."), as the launch code itself decides it (csrc/api.hip
  * select_kernels: the ONE place where batch classes are told apart).  A pure host function of the handle's knobs (environment at creation: TEPOSE_EXACT_FP32,
@@ -189,7 +200,7 @@ int tepose_forward(const tepose_model* m, const float* x, int B, int T, const vo
  * does, it is reported the same way (NaN in the output, status word of the forward's workspace = 4, the handle's fault word), never
  * as a plausible result with rc 0.  Large batches are not synchronised by the library: the next entry point on the handle refuses
  * with TEPOSE_E_TIMEOUT, tepose_forward_status / tepose_status answer after their synchronisation.  tepose_set_persistent does not
- * affect this kernel (TEPOSE_MFMA16=5 selects the barrier form).                                                */
+ * affect this kernel.                                                                                          */
 int tepose_forward_status(tepose_model* m, void* workspace, void* stream);
 int tepose_status(tepose_model* m, void* stream);
 int tepose_status_peek(const tepose_model* m);

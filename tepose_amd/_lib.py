@@ -22,7 +22,7 @@ SYMBOLS = [
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
     'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
     'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_fault_code', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
-    'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info', 'tepose_select_kernels', 'tepose_debug_set_test_fault', 'tepose_debug_kernel_errors',
+    'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info', 'tepose_select_kernels', 'tepose_set_option', 'tepose_get_option', 'tepose_debug_set_test_fault', 'tepose_debug_kernel_errors',
 ]
 
 _lib = None
@@ -135,6 +135,9 @@ def load():
     lib.tepose_kernel_info.restype = c_char_p
     lib.tepose_kernel_info.argtypes = [c_void_p]
     lib.tepose_select_kernels.restype = c_char_p
+    lib.tepose_set_option.argtypes = [c_void_p, c_char_p, ctypes.c_long]
+    lib.tepose_get_option.argtypes = [c_void_p, c_char_p]
+    lib.tepose_get_option.restype = ctypes.c_long
     lib.tepose_select_kernels.argtypes = [c_void_p, c_int, c_int]
     info = (lib.tepose_build_info() or b'').decode()
     if 'packed_fp32=off' not in info:

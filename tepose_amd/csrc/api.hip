@@ -4,6 +4,7 @@
 #include "../../include/tepose_amd.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <new>
@@ -74,10 +75,11 @@ struct tepose_model {
   SmplOff smpl{};
   int maxdepth = 0;
   int lbs_sparse = 0;                           // skin-weight table has <= 4 non-zeros per vertex
-  bool split = true;                            // batches of more than split_min_m() rows run their matmuls on the fp16x3 split kernels
+  bool split = true;                            // batches of more than m->opt.split_min_m rows run their matmuls on the fp16x3 split kernels
   bool split_env = true;                        // what the environment asked for; `split` also needs every packed weight inside
   bool enc_range_ok = true, reg_range_ok = true, smpl_range_ok = true;   // the fp16 range (|w| < 2^15), checked at pack time
   int s_min_b = 640;                            // scaled-format recurrent path from this batch size
+  Options opt;                                  // every launch threshold (common.h Options): from the environment at tepose_create, tepose_set_option before packing
   // fault channel of the persistent kernels (gru_seq.hip, reg_seq.hip): one word of pinned host memory that a kernel
   // whose bounded wait expired writes with system scope; sticky until tepose_status() reads it
   unsigned* fault = nullptr;
@@ -400,7 +402,7 @@ struct EncWs {
 inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32; }
 // floats of the granule buffers: [3 directions][2 buffers][16 rows][Hp] uint64, only where the persistent kernel can run
 inline size_t seq_gran_words(const tepose_model* m, int B) {
-  return (m->split && B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
+  return (m->split && B <= gru_seq_gran_rows(m->opt) && m->Hp % 256 == 0 && m->Hp <= 1024) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
 }
 inline size_t sync_zero_bytes(const tepose_model* m, int B) {      // counters + granules: the block a forward clears
   return align_up(sync_words(m) * sizeof(unsigned), 256) + seq_gran_words(m, B) * sizeof(float);
@@ -413,7 +415,7 @@ inline unsigned* sync_reg_status(const tepose_model* m, unsigned* sy) { return s
 void carve_encoder(const tepose_model* m, int B, int T, Carver& c, EncWs& w) {
   const size_t Hp = m->Hp, BT = (size_t)B * T;
   const int L = m->L;
-  const bool h3 = m->split && B > split_min_m();
+  const bool h3 = m->split && B > m->opt.split_min_m;
   const size_t Bs = h3 ? (size_t)round_up(B, 16) : (size_t)B, BTs = Bs * T;
   w.Bs = Bs;
   w.sync = (unsigned*)c.f(sync_words(m));
@@ -466,7 +468,7 @@ struct RegWs {
 };
 
 // regressor / SMPL side of the kernel selection (select_kernels below computes the same two predicates for its description)
-inline bool reg_split_for(const tepose_model* m, int N) { return m->split && N > split_min_m(); }
+inline bool reg_split_for(const tepose_model* m, int N) { return m->split && N > m->opt.split_min_m; }
 inline bool blend16_for(const tepose_model* m, int N) { return reg_split_for(m, N) && m->large_scaled && N >= m->blend16_min_n; }
 
 void carve_regressor(const tepose_model* m, int N, Carver& c, RegWs& w) {
@@ -510,7 +512,7 @@ GemmArgs gemm(const float* A, long lda, const float* W, int Kp, float* C, long l
 
 // C = (A W^T + bias + addend) * scale on the split-precision kernel: A as blocked planes, W = blocked planes of a
 // packed [Np][Kp] blob matrix (hi plane, then lo plane); `out`: also write C as planes (the next product's A)
-int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long ldc, const float* bias, int M, int N,
+int h3_mm(const tepose_model* m, const Planes& A, const float* w_planes, int Np, int Kp, float* C, long ldc, const float* bias, int M, int N,
           const float* addend, long ldadd, float scale, const Planes* out, hipStream_t s, const float* row_scale = nullptr) {
   H3Batch b{};
   const half_t* wh = (const half_t*)w_planes;
@@ -524,9 +526,9 @@ int h3_mm(const Planes& A, const float* w_planes, int Np, int Kp, float* C, long
   // makes 162 tiles of the big kernel
   // (and any product with <= 256 columns -- the stacked decoders -- at every M: 2 column tiles of the big kernel
   // would use 64 CUs)
-  if ((M <= skinny_max_m() && !(N > 4096 && Kp < 512)) || N <= 256) return (int)launch_skinny_gemm_h3(p, s);
+  if ((M <= m->opt.skinny_max_m && !(N > 4096 && Kp < 512)) || N <= 256) return (int)launch_skinny_gemm_h3(p, s, m->opt);
   b.n = 1;
-  return (int)launch_gemm_h3(b, s);
+  return (int)launch_gemm_h3(b, s, m->opt);
 }
 
 // v_posed = v_template + shapedirs beta + posedirs^T pose_feature as one GEMM, K = 224
@@ -535,20 +537,20 @@ int blend_shapes(const tepose_model* m, const RegWs& w, int N, hipStream_t s) {
   if (w.blend16) {
     // large batches: K = 224 is 7 pairs of K-tiles -- on the one-workgroup-per-tile kernel every tile pays pipeline fill, drain and a 128 KB store burst
     // (0.40 ms for 677 MB of output); the persistent barrier-free kernel streams the next tile's stages under the finished tile's stores
-    CK(launch_split_rows(w.pf, kBlendK, N, kBlendK, kBlendK, N, 1, w.pf16h, w.pf16l, w.pfrs, s));
+    CK(launch_split_rows(w.pf, kBlendK, N, kBlendK, kBlendK, N, 1, w.pf16h, w.pf16l, w.pfrs, s, m->opt));
     const half_t* sh = (const half_t*)(Bl + m->blendW_s);
     H3SArgs a{w.pf16h, w.pf16l, (long)N * 16, sh, sh + (size_t)kBlendN * kBlendK, (long)kBlendN * 16, kBlendK, w.vposed, (long)kVertLd,
               nullptr, 1.f / m->blend_sc, N, 3 * kNV, w.pfrs};
     if (w.sync) a.status = sync_reg_status(m, w.sync);
     a.fault = m->fault;
-    return (int)launch_gemm_h3s(a, s, 1);
+    return (int)launch_gemm_h3s(a, s, m->opt, 1);
   }
   if (w.split) {      // the prep kernel wrote the pose-feature planes next to the fp32 rows
-    return h3_mm(w.pfP, Bl + m->blendW_p, kBlendN, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV, nullptr, 0, 0.f,
+    return h3_mm(m, w.pfP, Bl + m->blendW_p, kBlendN, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV, nullptr, 0, 0.f,
                  nullptr, s);
   }
   GemmArgs gv = gemm(w.pf, kBlendK, Bl + m->smpl.blendW, kBlendK, w.vposed, kVertLd, nullptr, N, 3 * kNV);
-  return (int)launch_gemm(gv, s);
+  return (int)launch_gemm(gv, s, m->opt);
 }
 
 }  // namespace
@@ -581,10 +583,6 @@ namespace {
 // (the predicates used to be spread over encoder_fwd_impl / encoder_core / carve_regressor as conjunctions of knob bits.)
 // Pure host function of (handle knobs, L, Hp, B, T): no device call, so tests/test_dispatch.py pins every class boundary on a machine without a GPU
 // (tepose_select_kernels).  The launch code below consumes these fields; nothing else decides a kernel family.
-inline int l1_skinny_max_rows() {
-  static const int v = [] { const char* e = getenv("TEPOSE_L1_SKINNY_MAX_ROWS"); return e ? atoi(e) : 192; }();
-  return v;
-}
 struct KernelPlan {
   bool h3 = false;            // split-precision kernels (split-mode handle, B > TEPOSE_SPLIT_MIN_M); else the exact-fp32 kernels of gemm.hip / skinny.hip
   bool scaled = false;        // large batch: recurrent-state planes in the scaled format, layer >= 1 projections and cell steps on the scaled-plane kernels
@@ -600,13 +598,13 @@ KernelPlan select_kernels(const tepose_model* m, int B, int T, bool assume_ready
   KernelPlan k;
   const int L = m->L, Hp = m->Hp;
   const long BT = (long)B * T;
-  k.h3 = m->split && B > split_min_m();
+  k.h3 = m->split && B > m->opt.split_min_m;
   k.scaled = k.h3 && m->large_scaled && B >= m->s_min_b;
   k.gblk = k.scaled && m->gi_blk && Hp % 32 == 0;
   k.planes_state = k.gblk && m->state_planes && B % 128 == 0;
   // layer-0 projection
   k.g0big = k.h3 && m->large_scaled && L >= 2 && BT >= 8192;
-  static const int g0mid_min = [] { const char* e = getenv("TEPOSE_G0_MID_MIN_ROWS"); return e ? atoi(e) : 512; }();
+  const int g0mid_min = m->opt.g0_mid_min_rows;
   k.g0mid = k.h3 && m->large_scaled && L >= 2 && !k.g0big && BT >= g0mid_min && BT > 128 && (9 * Hp) % 288 == 0;
   if (k.g0mid) {   // whichever tile shape needs less time in whole rounds of the 256 CUs (a 128 x 288 tile takes ~2.1x a 128 x 128 one)
     const long rt = (BT + 127) / 128;
@@ -615,17 +613,17 @@ KernelPlan select_kernels(const tepose_model* m, int B, int T, bool assume_ready
   }
   // frame-major + blocked layer-0 gate pre-activations: the same condition as gblk, plus whole row tiles per frame
   k.g0blk = k.g0big && k.gblk && B % 16 == 0;
-  static const int g0_skinny_max = [] { const char* e = getenv("TEPOSE_G0_SKINNY_MAX_M"); return e ? atoi(e) : 128; }();
+  const int g0_skinny_max = m->opt.g0_skinny_max_m;
   k.g0skinny = k.h3 && !k.g0big && !k.g0mid && BT <= g0_skinny_max;
   // recurrent part of small batches
   const bool persist = assume_ready ? m->persist : persist_on(m);
   const bool seq_ok = k.h3 && !k.scaled && persist;
-  k.seq3 = seq_ok && gru_seq_ok(3, B, Hp, T);
-  k.seq2 = seq_ok && gru_seq_ok(2, B, Hp, T);
-  k.step_skinny = k.h3 && !k.scaled && B <= skinny_h3_max_m();
+  k.seq3 = seq_ok && gru_seq_ok(3, B, Hp, T, m->opt);
+  k.seq2 = seq_ok && gru_seq_ok(2, B, Hp, T, m->opt);
+  k.step_skinny = k.h3 && !k.scaled && B <= m->opt.skinny_h3_max_m;
   // regressor / SMPL
   k.reg_split = reg_split_for(m, B);
-  k.reg_seq = k.reg_split && B <= reg_seq_max_n() && persist;
+  k.reg_seq = k.reg_split && B <= (m->opt.reg_seq_max_n > 64 ? 64 : m->opt.reg_seq_max_n) && persist;
   k.blend16 = blend16_for(m, B);
   return k;
 }
@@ -636,22 +634,22 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   const int L = m->L;
   const long BT = (long)B * T;
   std::string s = "input=";
-  s += !k.h3 ? "pad_input_kernel" : (BT <= split_few_max_rows() && !k.g0blk) ? "split_rows_few_kernel" : "split_rows_kernel";
+  s += !k.h3 ? "pad_input_kernel" : (BT <= m->opt.split_few_max_rows && !k.g0blk) ? "split_rows_few_kernel" : "split_rows_kernel";
   s += ";projection=";
-  s += !k.h3 ? (BT <= skinny_max_m() ? "skinny_gemm_kernel" : "gemm_f32_kernel")
+  s += !k.h3 ? (BT <= m->opt.skinny_max_m ? "skinny_gemm_kernel" : "gemm_f32_kernel")
        : k.g0big ? "gemm_h3s_persist16c_kernel<0>" : k.g0mid ? "gemm_h3s_kernel<1, 3, 4, 3, 4>" : k.g0skinny ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel";
   s += std::string(";gi0_layout=") + (k.g0blk ? "frame_major_blocked" : "row_major");
   const bool seq_l0 = L == 1 ? k.seq2 : k.seq3;
   s += ";gru_step=";
-  s += !k.h3 ? (B <= skinny_max_m() ? "skinny_gru_kernel" : "gru_step_kernel")
+  s += !k.h3 ? (B <= m->opt.skinny_max_m ? "skinny_gru_kernel" : "gru_step_kernel")
        : k.scaled ? (k.planes_state && k.g0blk ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>")
-       : seq_l0 ? (B <= gru_seq_gran_max_m() && m->Hp % 256 == 0 && m->Hp <= 1024 ? "gru_seq_kernel(granules)" : "gru_seq_kernel")
+       : seq_l0 ? (B <= gru_seq_gran_rows(m->opt) && m->Hp % 256 == 0 && m->Hp <= 1024 ? "gru_seq_kernel(granules)" : "gru_seq_kernel")
        : k.step_skinny ? "skinny_gru_h3_kernel" : "gemm_h3_kernel<GRU>";
   s += ";gru_first=";
   s += !k.h3 ? "gru_step_kernel" : (seq_l0 ? "(in gru_seq_kernel)" : (k.scaled && m->Hp % 128 == 0 ? "gru_first16_kernel" : "gru_first_kernel"));
   if (L >= 2) {
     s += ";projection_l1=";
-    s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= l1_skinny_max_rows() ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
+    s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= m->opt.l1_skinny_max_rows ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
     s += std::string(";gi1_layout=") + (k.gblk ? "blocked" : "row_major");
     if (k.scaled) s += std::string(";gru_step_l1=") + (k.planes_state ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>");
   }
@@ -681,6 +679,7 @@ void refresh_kernel_info(tepose_model* m) {
 
 // numerics / dispatch knobs, read once per handle at creation (both model kinds)
 static void read_env_knobs(tepose_model* m) {
+  m->opt = options_from_env();                      // the launch thresholds (common.h Options)
   const char* e = getenv("TEPOSE_EXACT_FP32");      // 1: keep every product on the exact-fp32 MFMA
   m->split = m->split_env = !(e && atoi(e) != 0);
   e = getenv("TEPOSE_LARGE_BATCH_KERNELS");         // scaled (default) | twoacc
@@ -898,6 +897,34 @@ int tepose_forward_status(tepose_model* m, void* workspace, void* stream) {
   return TEPOSE_E_TIMEOUT;
 }
 
+// One named option of this handle (common.h Options + the handle's own batch thresholds), before anything is packed: workspace sizes and the packed
+// planes depend on them.  name = the environment variable's, with or without the TEPOSE_ prefix.
+int tepose_set_option(tepose_model* m, const char* name, long value) {
+  if (!m || !name) return TEPOSE_E_ARG;
+  if (m->enc_packed || m->reg_packed || m->smpl_packed || m->vibe_packed) return TEPOSE_E_STATE;
+  const char* n = strncmp(name, "TEPOSE_", 7) == 0 ? name + 7 : name;
+  if (int* f = option_field(m->opt, n)) *f = (int)value;
+  else if (strcmp(n, "S_MIN_B") == 0) m->s_min_b = (int)value;
+  else if (strcmp(n, "BLEND16_MIN_N") == 0) m->blend16_min_n = (int)value;
+  else if (strcmp(n, "GI_BLK") == 0) m->gi_blk = (int)value;
+  else if (strcmp(n, "SEQ_SPIN_LIMIT") == 0) { if (value <= 0) return TEPOSE_E_ARG; m->spin_limit = (unsigned)value; }
+  else return TEPOSE_E_ARG;
+  refresh_kernel_info(m);
+  return 0;
+}
+
+long tepose_get_option(const tepose_model* m, const char* name) {
+  if (!m || !name) return -1;
+  const char* n = strncmp(name, "TEPOSE_", 7) == 0 ? name + 7 : name;
+  Options o = m->opt;
+  if (const int* f = option_field(o, n)) return *f;
+  if (strcmp(n, "S_MIN_B") == 0) return m->s_min_b;
+  if (strcmp(n, "BLEND16_MIN_N") == 0) return m->blend16_min_n;
+  if (strcmp(n, "GI_BLK") == 0) return m->gi_blk;
+  if (strcmp(n, "SEQ_SPIN_LIMIT") == 0) return (long)m->spin_limit;
+  return -1;
+}
+
 int tepose_fault_code(const tepose_model* m) {
   if (!m) return TEPOSE_E_ARG;
   const unsigned live = m->fault ? __atomic_load_n(m->fault, __ATOMIC_RELAXED) : 0u;
@@ -920,8 +947,8 @@ int tepose_debug_set_test_fault(tepose_model* m, unsigned bits) {
 
 int tepose_uses_persistent(const tepose_model* m, int B, int T) {
   if (!m || B < 1) return 0;
-  if (!persist_on(m) || !m->split || B <= split_min_m()) return 0;
-  const int cap = gru_seq_max_m() > reg_seq_max_n() ? gru_seq_max_m() : reg_seq_max_n();
+  if (!persist_on(m) || !m->split || B <= m->opt.split_min_m) return 0;
+  const int cap = (m->opt.seq_max_m > 64 ? 64 : m->opt.seq_max_m) > (m->opt.reg_seq_max_n > 64 ? 64 : m->opt.reg_seq_max_n) ? (m->opt.seq_max_m > 64 ? 64 : m->opt.seq_max_m) : (m->opt.reg_seq_max_n > 64 ? 64 : m->opt.reg_seq_max_n);
   (void)T;
   return B <= cap ? 1 : 0;
 }
@@ -1128,7 +1155,7 @@ int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N,
   int ldin = kFeat;
   for (int l = 0; l < L; ++l) {
     GemmArgs g = gemm(in, ldin, Bl + m->vibe[l].wih, ldin, G, (long)D * H3, Bl + m->vibe[l].bih, (int)BN, D * H3);
-    CK(launch_gemm(g, s));
+    CK(launch_gemm(g, s, m->opt));
     float* So = S[l & 1];
     for (int t = 0; t < N; ++t) {
       GruArgs a{};
@@ -1141,7 +1168,7 @@ int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N,
         q.hprev = So + (long)tp * D * Hp + (long)d * Hp; q.ldh = (long)N * D * Hp;
         q.hout = So + (long)td * D * Hp + (long)d * Hp; q.ldo = (long)N * D * Hp;
       }
-      CK(launch_gru_step(a, s));
+      CK(launch_gru_step(a, s, m->opt));
     }
     in = So; ldin = D * Hp;
   }
@@ -1150,7 +1177,7 @@ int tepose_vibe_encoder_fwd(const tepose_model* m, const float* x, int B, int N,
   GemmArgs g = gemm(in, ldin, Bl + m->vlin_w, ldin, feat, kFeat, Bl + m->vlin_b, (int)BN, kFeat);
   g.relu_a = 1;
   if (use_residual) { g.addend = x; g.ldadd = kFeat; }
-  CK(launch_gemm(g, s));
+  CK(launch_gemm(g, s, m->opt));
   return 0;
 }
 
@@ -1409,7 +1436,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
                   float* out, int M) -> int {
     if (!h3) {
       GemmArgs g = gemm(in, K, Bl + w_f32, K, out, H3, Bl + bias, M, H3);
-      return (int)launch_gemm(g, s);
+      return (int)launch_gemm(g, s, m->opt);
     }
     if (sf) {
       const EncWs::View v = w.view16(in);
@@ -1422,17 +1449,17 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       a.fault = m->fault;
       a.inject = (m->test_fault >> 2) & 1u;
       a.c_blk_hp = gblk ? Hp : 0;
-      return (int)launch_gemm_h3s(a, s);
+      return (int)launch_gemm_h3s(a, s, m->opt);
     }
     const EncWs::View v = w.view(in);
     if (!v.hi) return (int)hipErrorInvalidValue;
     Planes A; A.hi = v.hi; A.lo = v.lo; A.kst = v.kst;
-    return h3_mm(A, Bl + w_planes, (int)n128, K, out, (long)H3, Bl + bias, M, H3, nullptr, 0, 0.f, nullptr, s);
+    return h3_mm(m, A, Bl + w_planes, (int)n128, K, out, (long)H3, Bl + bias, M, H3, nullptr, 0, 0.f, nullptr, s);
   };
   // one GRU step of up to 3 directions: fused fp32 kernel; or the split product with the cell update in its
   // epilogue (first step: h = 0, element-wise kernel)
   auto step = [&](const GruArgs& a, const size_t (&whh_planes)[3], const DirW* const (&dw)[3]) -> int {
-    if (!h3) return (int)launch_gru_step(a, s);
+    if (!h3) return (int)launch_gru_step(a, s, m->opt);
     if (sf) {
       H3SBatch b{};
       GateBatch gb{};
@@ -1464,7 +1491,8 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       // wrote them frame-major + blocked (g0blk; not from the driver's cache ring).  One decision per layer: every step of a layer runs the same kernel.
       bool planes = plan.planes_state;
       for (int d = 0; d < a.ndir; ++d) planes = planes && a.d[d].gi_blk != 0;
-      return (int)launch_gru_step16(b, s, planes);
+      planes = planes && gru_step16_planes_ok(b);          // (a misaligned view or a ragged tile the plan did not foresee: the general instantiation, not an error)
+      return (int)launch_gru_step16(b, s, planes, m->opt.gru_gm);
     }
     H3Batch b{};
     GateBatch gb{};
@@ -1517,7 +1545,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       const int Mf = top ? B : MT;         // the top layer's forward direction of gru_rec consumes one step only
       if (h3 && !scaled_fmt) {
         // the three products of a layer in as few launches as their shapes allow (each alone under-fills the chip:
-        // 64-192 workgroups): width-first kernel for <= skinny_max_m() rows, 128/256-row tiles above
+        // 64-192 workgroups): width-first kernel for <= m->opt.skinny_max_m rows, 128/256-row tiles above
         const EncWs::View vf = w.view(inf), vr = w.view(inr);
         if (!vf.hi || !vr.hi) return (int)hipErrorInvalidValue;
         auto mk = [&](const EncWs::View& v, int K, size_t w_planes, size_t bias, float* out, int M) {
@@ -1538,7 +1566,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
         // kernel is flat at ~35 us up to a round of the chip, the width-first one costs ~12-16 us per pass (222 rows: 48.7 -> 37 us; 150 rows: stays)
         for (H3Args& a : pa) {
           const long real_rows = a.M == MT ? (long)B * T : (long)a.M;
-          if (a.M <= skinny_max_m() && real_rows <= l1_skinny_max_rows()) {
+          if (a.M <= m->opt.skinny_max_m && real_rows <= m->opt.l1_skinny_max_rows) {
             // width-first kernel: only the B real rows of every 16-row-padded time slab (B = 1: 16 rows instead of 256)
             if (a.M == MT && Bs != B) { a.M = B * T; a.grp_rows = B; a.grp_stride = (int)Bs; }
             sk.p[sk.n++] = a;
@@ -1547,11 +1575,11 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
           else {                           // a big product of another shape: its own launch
             H3Batch one{};
             one.p[0] = a; one.n = 1;
-            CK(launch_gemm_h3(one, s));
+            CK(launch_gemm_h3(one, s, m->opt));
           }
         }
-        if (big.n) CK(launch_gemm_h3(big, s));
-        if (sk.n) CK(launch_skinny_gemm_h3_batch(sk, s));
+        if (big.n) CK(launch_gemm_h3(big, s, m->opt));
+        if (sk.n) CK(launch_skinny_gemm_h3_batch(sk, s, m->opt));
       } else {
       CK((hipError_t)proj(inf, Hp, m->fwd[l].wih, m->fwd[l].wih_p, m->fwd[l].wih_s, m->fwd[l].wih_scale, m->fwd[l].bih,
                           w.gf, MT));
@@ -1655,7 +1683,7 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
             sq.x_roff = (unsigned)((size_t)(Hp / 32) * w.tailA.kst);
             tail_planes_done = true;
           }
-          CK(launch_gru_seq(sq, s));
+          CK(launch_gru_seq(sq, s, m->opt));
         }
         continue;
       }
@@ -1689,33 +1717,33 @@ int encoder_core(const tepose_model* m, const G0Src& src, int B, int T, int is_t
       CK(launch_split_planes(w.ytop, 2 * Hp, B, 2 * Hp, 2 * Hp, B, w.tailR.hi, w.tailR.lo, s, 1));
     }
     if (!is_train && xs_out && m->tail_collapsed) {
-      CK((hipError_t)h3_mm(w.tailA, Bl + m->mt_p, 256, 3 * Hp, xs_out, kState, Bl + m->kt, B, kState, nullptr, 0, 0.f,
+      CK((hipError_t)h3_mm(m, w.tailA, Bl + m->mt_p, 256, 3 * Hp, xs_out, kState, Bl + m->kt, B, kState, nullptr, 0, 0.f,
                            nullptr, s));
     } else if (!is_train) {
       // (y_fwd + y_rec) / 2 = ([relu(h_fwd) | relu(y_rec0)] [W_lf | W_lr]^T + b_lf + b_lr) / 2: one product, K = 3Hp
       // (b_lr rides in as an addend row with stride 0)
-      CK((hipError_t)h3_mm(w.tailA, Bl + m->wlfr_p, kFeat, 3 * Hp, feat, kFeat, Bl + m->blf, B, kFeat, Bl + m->blr, 0,
+      CK((hipError_t)h3_mm(m, w.tailA, Bl + m->wlfr_p, kFeat, 3 * Hp, feat, kFeat, Bl + m->blf, B, kFeat, Bl + m->blr, 0,
                            0.5f, feat_planes, s));
     } else {
-      CK((hipError_t)h3_mm(w.tailF, Bl + m->wlf_p, kFeat, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat, nullptr, 0,
+      CK((hipError_t)h3_mm(m, w.tailF, Bl + m->wlf_p, kFeat, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat, nullptr, 0,
                            0.f, nullptr, s));
-      CK((hipError_t)h3_mm(w.tailR, Bl + m->wlr_p, kFeat, 2 * Hp, feat + kFeat, 2 * kFeat, Bl + m->blr, B, kFeat,
+      CK((hipError_t)h3_mm(m, w.tailR, Bl + m->wlr_p, kFeat, 2 * Hp, feat + kFeat, 2 * kFeat, Bl + m->blr, B, kFeat,
                            nullptr, 0, 0.f, nullptr, s));
     }
   } else if (!is_train) {
     GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, w.y1, kFeat, Bl + m->blf, B, kFeat);
     g1.relu_a = 1;
-    CK(launch_gemm(g1, s));
+    CK(launch_gemm(g1, s, m->opt));
     GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat, kFeat, Bl + m->blr, B, kFeat);
     g2.relu_a = 1; g2.addend = w.y1; g2.ldadd = kFeat; g2.scale = 0.5f;
-    CK(launch_gemm(g2, s));
+    CK(launch_gemm(g2, s, m->opt));
   } else {
     GemmArgs g1 = gemm(hlast, Hp, Bl + m->wlf, Hp, feat, 2 * kFeat, Bl + m->blf, B, kFeat);
     g1.relu_a = 1;
-    CK(launch_gemm(g1, s));
+    CK(launch_gemm(g1, s, m->opt));
     GemmArgs g2 = gemm(w.ytop, 2 * Hp, Bl + m->wlr, 2 * Hp, feat + kFeat, 2 * kFeat, Bl + m->blr, B, kFeat);
     g2.relu_a = 1;
-    CK(launch_gemm(g2, s));
+    CK(launch_gemm(g2, s, m->opt));
   }
   return 0;
 }
@@ -1818,7 +1846,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
   // (the forward's first kernel also clears its sync region -- arrival counters, granules, STATUS words -- so that a give-up of the
   // layer-0 projection (barrier-free kernel, gemm_h3s16c.hip) is not wiped by a clearing that comes after it)
   (void)zero_sync;
-  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, (void*)w.sync, w.sync ? sync_zero_bytes(m, B) : 0,
+  if (h3) CK(launch_split_rows(x, kInput, BT, kInput, kInputP, BT, g0s ? 1 : 0, xh, xl, w.rs, s, m->opt, (void*)w.sync, w.sync ? sync_zero_bytes(m, B) : 0,
                                g0blk ? T : 0));
   else CK(launch_pad_input(x, w.xp, BT, s));
   if (!h3 && w.sync) CK(hipMemsetAsync(w.sync, 0, sync_zero_bytes(m, B), s));
@@ -1845,7 +1873,7 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       a.c_blk_hp = g0blk ? Hp : 0;
       // (the barrier-free 256 x 256 kernel loses on mid-size batches: 1024 rows are 144 of its tiles -- 0.138 against 0.119 ms, profiles/r05_mid_rows_gemm.txt)
       if (g0mid) CK(launch_gemm_h3s_mid(a, s));
-      else CK(launch_gemm_h3s(a, s, 0));
+      else CK(launch_gemm_h3s(a, s, m->opt, 0));
     } else if (h3) {
       H3Batch b{};
       b.p[0] = H3Args{xh, xl, BT * 32, w0h, w0l, (long)rows0 * 32, kInputP, w.g0, (long)ld0, Bl + m->bih0, (int)BT,
@@ -1854,11 +1882,11 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
       b.n = 1;
       // few rows (live stream, a handful of clips): the width-first kernel streams the 79 MB of W_ih planes with
       // N / 48 = 192 workgroups instead of 72 tiles of 128 rows
-      if (plan.g0skinny) CK(launch_skinny_gemm_h3(b.p[0], s));
-      else CK(launch_gemm_h3(b, s));
+      if (plan.g0skinny) CK(launch_skinny_gemm_h3(b.p[0], s, m->opt));
+      else CK(launch_gemm_h3(b, s, m->opt));
     } else {
       GemmArgs g = gemm(w.xp, kInputP, Bl + m->wih0, kInputP, w.g0, ld0, Bl + m->bih0, (int)BT, ld0);
-      CK(launch_gemm(g, s));
+      CK(launch_gemm(g, s, m->opt));
     }
     if (m->prof) {
       CK(hipEventRecord(mm->ev[mm->ev_used + 1], s));
@@ -1870,16 +1898,16 @@ int encoder_fwd_impl(const tepose_model* m, const float* x, int B, int T, int is
     if (h3) {
       H3Batch b{};
       // frames T-1 of every window as compact planes; W rows 6Hp.. of the stacked layer-0 block
-      CK(launch_split_rows(x + (long)(T - 1) * kInput, (long)T * kInput, B, kInput, kInputP, B, 0, w.x0h, w.x0l, w.rs0, s));
+      CK(launch_split_rows(x + (long)(T - 1) * kInput, (long)T * kInput, B, kInput, kInputP, B, 0, w.x0h, w.x0l, w.rs0, s, m->opt));
       b.p[0] = H3Args{w.x0h, w.x0l, (long)B * 32, w0h + (size_t)6 * Hp * 32, w0l + (size_t)6 * Hp * 32,
                       (long)rows0 * 32, kInputP, w.g0c, (long)H3, Bl + m->bih0 + 6 * Hp, B, H3};
       b.p[0].row_scale = w.rs0;
       b.n = 1;
-      CK(launch_gemm_h3(b, s));
+      CK(launch_gemm_h3(b, s, m->opt));
     } else {
       GemmArgs g = gemm(w.xp + (long)(T - 1) * kInputP, (long)T * kInputP, Bl + m->wih0 + (size_t)6 * Hp * kInputP,
                         kInputP, w.g0c, H3, Bl + m->bih0 + 6 * Hp, B, H3);
-      CK(launch_gemm(g, s));
+      CK(launch_gemm(g, s, m->opt));
     }
   }
 
@@ -1900,7 +1928,7 @@ size_t tepose_project_frames_workspace_bytes(const tepose_model* m, int B) {
   if (!m || B < 1) return 0;
   const size_t xbytes = align_up((size_t)B * kInputP * sizeof(float), 256);
   // padded fp32 rows, plus their hi / lo planes and per-row scales when the product runs on the split-precision kernel
-  return (m->split && B > split_min_m()) ? 2 * xbytes + 512 + align_up((size_t)B * sizeof(float), 256) : xbytes;
+  return (m->split && B > m->opt.split_min_m) ? 2 * xbytes + 512 + align_up((size_t)B * sizeof(float), 256) : xbytes;
 }
 
 int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld, const float* theta, long theta_ld,
@@ -1912,19 +1940,19 @@ int tepose_project_frames(const tepose_model* m, const float* feat, long feat_ld
   float* xp = (float*)workspace;
   CK(launch_pad_rows(feat, feat_ld, theta, theta_ld, xp, B, s));
   const size_t xbytes = align_up((size_t)B * kInputP * sizeof(float), 256);
-  if (m->split && B > split_min_m()) {   // split-precision product, same numerics as tepose_forward's
+  if (m->split && B > m->opt.split_min_m) {   // split-precision product, same numerics as tepose_forward's
     Planes P;
     P.hi = (half_t*)((char*)workspace + xbytes);
     P.lo = (half_t*)((char*)workspace + xbytes + xbytes / 2);
     P.kst = (long)B * 32;
     float* rs = (float*)((char*)workspace + 2 * xbytes + 512);
-    CK(launch_split_rows(xp, kInputP, B, kInputP, kInputP, B, 0, P.hi, P.lo, rs, s));
-    CK((hipError_t)h3_mm(P, m->blob + m->wih0_p, round_up(9 * m->Hp, 128), kInputP, out, out_ld, m->blob + m->bih0, B,
+    CK(launch_split_rows(xp, kInputP, B, kInputP, kInputP, B, 0, P.hi, P.lo, rs, s, m->opt));
+    CK((hipError_t)h3_mm(m, P, m->blob + m->wih0_p, round_up(9 * m->Hp, 128), kInputP, out, out_ld, m->blob + m->bih0, B,
                          9 * m->Hp, nullptr, 0, 0.f, nullptr, s, rs));
     return 0;
   }
   GemmArgs g = gemm(xp, kInputP, m->blob + m->wih0, kInputP, out, out_ld, m->blob + m->bih0, B, 9 * m->Hp);
-  CK(launch_gemm(g, s));
+  CK(launch_gemm(g, s, m->opt));
   return 0;
 }
 
@@ -1958,8 +1986,8 @@ int project_frame_pair_impl(const tepose_model* m, const float* feat_prev, const
   if (ws_bytes < tepose_project_frames_workspace_bytes(m, 2 * B)) return TEPOSE_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int M = 2 * B;
-  const bool h3 = m->split && B > split_min_m();       // (B, not 2 B: the same arithmetic class as tepose_project_frames at this B)
-  if (!h3 || M > skinny_max_m()) {            // exact-fp32 products / more rows than the width-first kernel takes: the two products one after the other
+  const bool h3 = m->split && B > m->opt.split_min_m;       // (B, not 2 B: the same arithmetic class as tepose_project_frames at this B)
+  if (!h3 || M > m->opt.skinny_max_m) {            // exact-fp32 products / more rows than the width-first kernel takes: the two products one after the other
     int rc = tepose_project_frames(m, feat_prev, feat_ld, theta_prev, theta_ld, B, out_prev, out_prev_ld, workspace, ws_bytes, stream);
     if (rc) return rc;
     return tepose_project_frames(m, feat_new, feat_ld, nullptr, 0, B, out_new, out_new_ld, workspace, ws_bytes, stream);
@@ -1971,7 +1999,7 @@ int project_frame_pair_impl(const tepose_model* m, const float* feat_prev, const
   // the split kernel gathers the 2 B rows itself (features | theta, features | zeros): no padded fp32 copy, one launch instead of three
   const RowPairSrc pr{feat_prev, theta_prev, feat_new, feat_ld, theta_ld, B};
   const bool z = zero && zero_bytes && zero_bytes % 16 == 0;
-  CK(launch_split_rows(nullptr, 0, M, kInput, kInputP, M, 0, hi, lo, rs, s, z ? zero : nullptr, z ? zero_bytes : 0, 0, &pr));
+  CK(launch_split_rows(nullptr, 0, M, kInput, kInputP, M, 0, hi, lo, rs, s, m->opt, z ? zero : nullptr, z ? zero_bytes : 0, 0, &pr));
   if (zeroed) *zeroed = z;
   const int Np = round_up(9 * m->Hp, 128);
   const half_t* wh = (const half_t*)(m->blob + m->wih0_p);
@@ -1981,7 +2009,7 @@ int project_frame_pair_impl(const tepose_model* m, const float* feat_prev, const
   p.C = out_prev; p.ldc = out_prev_ld; p.bias = m->blob + m->bih0; p.M = M; p.N = 9 * m->Hp;
   p.row_scale = rs;
   p.C2 = out_new; p.ldc2 = out_new_ld; p.c_split = B;
-  CK(launch_skinny_gemm_h3(p, s));
+  CK(launch_skinny_gemm_h3(p, s, m->opt));
   return 0;
 }
 
@@ -2053,7 +2081,7 @@ int forward_cached_impl(const tepose_model* m, const float* ring_base, int ring,
   if (c.cur > rest_bytes) return TEPOSE_E_WORKSPACE;
   const int ld0 = 9 * m->Hp;
   G0Src src{ring_base, ld0, clip_stride, first_slot, ring, newest, newest_ld, newest + 6 * m->Hp, newest_ld};
-  const bool col = m->tail_collapsed && m->split && B > split_min_m();
+  const bool col = m->tail_collapsed && m->split && B > m->opt.split_min_m;
   int rc = encoder_core(m, src, B, T, 0, feat, w, s, nullptr, sync_zeroed, col ? feat : nullptr);
   if (rc) return rc;
   return regressor_impl(m, feat, B, 3, nullptr, nullptr, nullptr, jreg_packed, theta, verts, kp_3d, kp_2d, rotmat, rest,
@@ -2101,7 +2129,7 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   } else if (m->reg_collapsed && w.split_fc && n_iter == 3 && !init_pose && !init_shape && !init_cam) {
     // the three iterations from the model's own initial state as ONE product: xs = feat Mf^T + k0
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
-    CK((hipError_t)h3_mm(w.featP, Bl + m->mf_p, 256, kFeat, w.xs, kState, Bl + m->k0, N, kState, nullptr, 0, 0.f, nullptr, s));
+    CK((hipError_t)h3_mm(m, w.featP, Bl + m->mf_p, 256, kFeat, w.xs, kState, Bl + m->k0, N, kState, nullptr, 0, 0.f, nullptr, s));
   } else if (select_kernels(m, N, 1).reg_seq) {
     // small batches: the whole FC loop in one persistent launch (reg_seq.hip)
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
@@ -2122,31 +2150,31 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
     CK(launch_reg_seq(ra, s));
   } else if (w.split_fc) {
     if (!feat_planes_ready) CK(launch_split_planes(feat, kFeat, N, kFeat, kFeat, N, w.featP.hi, w.featP.lo, s));
-    CK((hipError_t)h3_mm(w.featP, Bl + m->w1a_p, 1024, kFeat, w.base, 1024, Bl + m->b1, N, 1024, nullptr, 0, 0.f,
+    CK((hipError_t)h3_mm(m, w.featP, Bl + m->w1a_p, 1024, kFeat, w.base, 1024, Bl + m->b1, N, 1024, nullptr, 0, 0.f,
                          nullptr, s));
     CK(init_state(Bl + m->init, init_pose, init_shape, init_cam, w.xs, N, s));
     CK(launch_split_planes(w.xs, kState, N, kState, kState, N, w.xsP.hi, w.xsP.lo, s));
     for (int it = 0; it < n_iter; ++it) {
-      CK((hipError_t)h3_mm(w.xsP, Bl + m->w1b_p, 1024, kState, w.h1, 1024, nullptr, N, 1024, w.base, 1024, 0.f,
+      CK((hipError_t)h3_mm(m, w.xsP, Bl + m->w1b_p, 1024, kState, w.h1, 1024, nullptr, N, 1024, w.base, 1024, 0.f,
                            &w.h1P, s));
-      CK((hipError_t)h3_mm(w.h1P, Bl + m->w2_p, 1024, 1024, w.h2, 1024, Bl + m->b2, N, 1024, nullptr, 0, 0.f,
+      CK((hipError_t)h3_mm(m, w.h1P, Bl + m->w2_p, 1024, 1024, w.h2, 1024, Bl + m->b2, N, 1024, nullptr, 0, 0.f,
                            &w.h2P, s));
-      CK((hipError_t)h3_mm(w.h2P, Bl + m->wdec_p, 256, 1024, w.xs, kState, Bl + m->bdec, N, kState, w.xs, kState,
+      CK((hipError_t)h3_mm(m, w.h2P, Bl + m->wdec_p, 256, 1024, w.xs, kState, Bl + m->bdec, N, kState, w.xs, kState,
                            0.f, &w.xsP, s));
     }
   } else {
     GemmArgs gb = gemm(feat, kFeat, Bl + m->w1a, kFeat, w.base, 1024, Bl + m->b1, N, 1024);
-    CK(launch_gemm(gb, s));
+    CK(launch_gemm(gb, s, m->opt));
     CK(init_state(Bl + m->init, init_pose, init_shape, init_cam, w.xs, N, s));
     for (int it = 0; it < n_iter; ++it) {
       GemmArgs g1 = gemm(w.xs, kState, Bl + m->w1b, kState, w.h1, 1024, nullptr, N, 1024);
       g1.addend = w.base; g1.ldadd = 1024;
-      CK(launch_gemm(g1, s));
+      CK(launch_gemm(g1, s, m->opt));
       GemmArgs g2 = gemm(w.h1, 1024, Bl + m->w2, 1024, w.h2, 1024, Bl + m->b2, N, 1024);
-      CK(launch_gemm(g2, s));
+      CK(launch_gemm(g2, s, m->opt));
       GemmArgs g3 = gemm(w.h2, 1024, Bl + m->wdec, 1024, w.xs, kState, Bl + m->bdec, N, kState);
       g3.addend = w.xs; g3.ldadd = kState;
-      CK(launch_gemm(g3, s));
+      CK(launch_gemm(g3, s, m->opt));
     }
   }
   SmplConsts sc{};
@@ -2156,7 +2184,7 @@ int regressor_impl(const tepose_model* m, const float* feat, int N, int n_iter, 
   sc.depth = (const int*)(Bl + m->smpl.depth); sc.maxdepth = m->maxdepth;
   sc.xr_ptr = (const int*)(Bl + m->smpl.xr_ptr); sc.xr_idx = (const int*)(Bl + m->smpl.xr_idx);
   sc.xr_val = Bl + m->smpl.xr_val;
-  if (smpl_small_ok(sc, N)) {     // a window or a few: prep + blend shapes + skinning as one launch (smpl.hip)
+  if (smpl_small_ok(sc, N, m->opt)) {     // a window or a few: prep + blend shapes + skinning as one launch (smpl.hip)
     CK(launch_smpl_small(sc, 0, w.xs, kState, w.xs + kNPose, kState, w.xs + 154, kState, N, w.amat, w.posed, rotmat, theta,
                          verts, s));
   } else {
@@ -2250,7 +2278,7 @@ int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, cons
   carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
-  if (smpl_small_ok(sc, N)) {
+  if (smpl_small_ok(sc, N, m->opt)) {
     CK(launch_smpl_small(sc, pose2rot ? 1 : 2, pose, pose2rot ? 72 : 216, betas, 10, nullptr, 0, N, w.amat, w.posed, nullptr,
                          nullptr, verts, s));
   } else {
@@ -2288,7 +2316,7 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
   carve_regressor(m, N, c, w);
   if (c.cur > ws_bytes) return TEPOSE_E_WORKSPACE;
   SmplConsts sc = smpl_consts(m);
-  if (smpl_small_ok(sc, N)) {
+  if (smpl_small_ok(sc, N, m->opt)) {
     CK(launch_smpl_small(sc, 1, theta + 3, kTheta, theta + 75, kTheta, nullptr, 0, N, w.amat, nullptr, nullptr, nullptr, verts, s));
     return 0;
   }
@@ -2337,12 +2365,13 @@ int tepose_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const
   // TEPOSE_H3S=1 (read per call: this is the test / bench entry): the scaled-plane barrier-free kernel of gemm_h3s16c.hip, operand scales for
   // the ranges of tools/h3_loop.py / h3_bench.py and tests/test_gpu_stress.py; TEPOSE_H3S=mid: the 128 x 288-tile kernel of gemm_h3s.hip (N % 288 == 0)
   const char* pe = getenv("TEPOSE_H3S");
+  const Options opt = options_from_env();          // no handle here: the environment's thresholds, read per call (test / bench entry)
   if (pe && pe[0] && std::string(pe) != "0" && std::string(pe).rfind("skinny", 0) != 0 && ws_bytes >= gemm_h3s_ws_bytes(M, N, K)) {
-    CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, bias, std::string(pe) == "mid" ? 1 : 0));
+    CK(launch_gemm_h3s_f32(A, lda, W, ldw, C, ldc, M, N, K, 256.f, 16384.f, workspace, (hipStream_t)stream, opt, bias, std::string(pe) == "mid" ? 1 : 0));
     return 0;
   }
   // TEPOSE_H3S=skinny: the width-first kernel of skinny_h3.hip on the same planes, at any M (tools/mid_rows_gemm_bench.py)
-  CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream, pe && std::string(pe) == "skinny" ? 1 : 0));
+  CK(launch_gemm_h3_f32(A, lda, W, ldw, bias, C, ldc, M, N, K, workspace, (hipStream_t)stream, opt, pe && std::string(pe) == "skinny" ? 1 : 0));
   return 0;
 }
 
@@ -2361,7 +2390,7 @@ int tepose_gemm_f32(const float* A, long lda, const float* W, long ldw, const fl
   CK((hipError_t)pack(W, ldw, N, K, wp, round_up(N, 128), K, 0, 0, 0, 1, s));
   GemmArgs g = gemm(A, lda, wp, K, C, ldc, bias, M, N);
   g.relu_a = relu_a;
-  CK(launch_gemm(g, s));
+  CK(launch_gemm(g, s, options_from_env()));       // no handle here: the environment's thresholds, read per call (test / bench entry)
   return 0;
 }
 

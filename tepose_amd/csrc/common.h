@@ -30,6 +30,39 @@ constexpr int kVertLd = 20672;  // row stride of the v_posed scratch (>= 20670, 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---------------------------------------------------------------- per-handle options
+// Every launch threshold of the library.  A handle owns ONE Options object: tepose_create fills it from the environment (options_from_env, the only
+// place the library reads TEPOSE_* threshold variables), tepose_set_option(m, "NAME", value) changes a field before anything is packed, and every
+// launcher that consults a threshold takes the handle's object as an argument -- no function-local static, no process-wide state: two handles of one
+// process can differ (SURVEY.md 8b "no global mutable state").  Defaults = the measured best.
+struct Options {
+  int skinny_max_m = 768;            // TEPOSE_SKINNY_MAX_M: rows at or below which the width-first fp32 kernels (skinny.hip) win over 128-row tiles (measured crossover)
+  int skinny_max_m_gemm = -1;        // TEPOSE_SKINNY_MAX_M_GEMM: the same for plain products only (-1: skinny_max_m)
+  int split_min_m = 0;               // TEPOSE_SPLIT_MIN_M: rows ABOVE which a split-mode handle runs its matmuls on the fp16x3 kernels (round 2: they win at every batch size)
+  int skinny_h3_max_m = 128;         // TEPOSE_SKINNY_H3_MAX_M: rows up to which a split-mode GRU step uses the width-first kernel of skinny_h3.hip
+  int gemm_half_max_blocks = 1024;   // TEPOSE_GEMM_HALF_MAX_BLOCKS: 64-row tiles of gemm_f32_kernel while 128-row tiles would make at most this many blocks
+  int split_few_max_rows = 1024;     // TEPOSE_SPLIT_FEW_MAX_ROWS: rows up to which launch_split_rows runs one workgroup per row (222 rows 12.3 -> 5 us, 1024 rows 13 -> 8)
+  int h3_tile = 0;                   // TEPOSE_H3_TILE: A/B, force a tile shape of gemm_h3_kernel (64 / 192 / 256)
+  int h3_tile64 = 1;                 // TEPOSE_H3_TILE64: 0 = never pick 64-row tiles (A/B)
+  int s16_gm = 8;                    // TEPOSE_S16_GM: row tiles per XCD group of the barrier-free projection's walk (layer-0 projection ms at 2 / 4 / 8 / 16 / 32: 10.92 / 10.82 / 10.74 / 11.37 / 12.37)
+  int gru_gm = 4;                    // TEPOSE_GRU_GM: the same for the fused step (recurrent ms per forward at 1 / 2 / 4 / 8 / 16 / 32: 11.31 / 11.27 / 11.22 / 11.41 / 11.41 / 11.77)
+  int seq_gran_max_m = 4;            // TEPOSE_SEQ_GRAN_MAX_M: rows up to which the persistent recurrent kernel hands its state over as tagged granules (B = 1 -14 %, 4 -5 %, 8 +20 %)
+  int seq_max_m = 64;                // TEPOSE_SEQ_MAX_M: rows up to which a layer's T steps run as ONE persistent launch (0: never)
+  int reg_seq_max_n = 64;            // TEPOSE_REG_SEQ_MAX_N: the same for the persistent FC-loop kernel
+  int assume_cus = 0;                // TEPOSE_ASSUME_CUS: plan as if the device had this many CUs (planning without a device: tests/test_dispatch.py)
+  int skinny_narrow64 = 1;           // TEPOSE_SKINNY_NARROW64, TEPOSE_SKINNY_MT1, TEPOSE_SKINNY_NT1_BELOW, TEPOSE_SKINNY_W8: block shapes of the width-first
+  int skinny_mt1 = 1;                //   split kernel for narrow products (skinny_h3.hip launch_skinny_gemm_h3_batch)
+  int skinny_nt1_below = 96;
+  int skinny_w8 = 1;
+  int smpl_small_max_n = 4;          // TEPOSE_SMPL_SMALL_MAX_N: persons up to which prep + blend shapes + skinning run as one launch
+  int l1_skinny_max_rows = 192;      // TEPOSE_L1_SKINNY_MAX_ROWS: real rows up to which a layer >= 1 projection runs on the width-first kernel
+  int g0_mid_min_rows = 512;         // TEPOSE_G0_MID_MIN_ROWS: rows from which the layer-0 projection may take the 128 x 288 tiles
+  int g0_skinny_max_m = 128;         // TEPOSE_G0_SKINNY_MAX_M: rows up to which the layer-0 projection runs on the width-first kernel
+  unsigned long long seq_stamp_ptr = 0;   // TEPOSE_SEQ_STAMP_PTR: device buffer for the per-step time stamps of a -DTEPOSE_SEQ_STAMPS build (tools/seq_stamps.py)
+};
+Options options_from_env();          // gemm.hip
+int* option_field(Options& o, const char* name);   // "SKINNY_MAX_M" (or "TEPOSE_SKINNY_MAX_M") -> &o.skinny_max_m; nullptr: no such option
+
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 // C[M,N] = epi( A[M,Kp] * W[Np,Kp]^T ), fp32 operands, fp32 MFMA accumulate.
 struct GemmArgs {
@@ -42,7 +75,7 @@ struct GemmArgs {
   int M, N;
   int relu_a;                    // apply max(0,.) to A on the fly
 };
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s, const Options& o);
 
 // One GRU cell step for up to 3 independent directions in one launch:
 //   gh = hprev * Whh^T ; r,z,n gate math ; hout = (1-z)*n + z*hprev      (torch.nn.GRU)
@@ -64,12 +97,10 @@ struct GruArgs {
   int M, Hp;
   int first;                     // h_{-1} = 0: skip the matmul
 };
-hipError_t launch_gru_step(const GruArgs& a, hipStream_t s);
-// small-M variants (skinny.hip); the launchers above dispatch to them when M <= skinny_max_m()
+hipError_t launch_gru_step(const GruArgs& a, hipStream_t s, const Options& o);
+// small-M variants (skinny.hip); the launchers above dispatch to them when M <= Options::skinny_max_m
 hipError_t launch_skinny_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_skinny_gru(const GruArgs& a, hipStream_t s);
-int skinny_max_m();
-int split_min_m();
 
 // ---------------------------------------------------------------- misc.hip
 // dst[np][kp] (row-major [Np][Kp]) = src[rowmap(np)][colmap(kp)] or 0.
@@ -127,7 +158,7 @@ hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pos
                                  const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
                                  hipStream_t s, void* pf_hi = nullptr, void* pf_lo = nullptr, long pf_kst = 0);
 // measurement only: blend shapes + skinning as one wave per person
-bool smpl_small_ok(const SmplConsts& c, int N);
+bool smpl_small_ok(const SmplConsts& c, int N, const Options& o);
 hipError_t launch_smpl_small(const SmplConsts& c, int mode, const float* pose, int pose_ld, const float* betas, int betas_ld,
                              const float* cam, int cam_ld, int N, float* Amat, float* posed, float* rotmat, float* theta,
                              float* verts, hipStream_t s);
@@ -224,16 +255,15 @@ __host__ __device__ inline long gi_blk_offset(long row, int gate, int unit, long
 }
 struct H3Batch { H3Args p[3]; GateDir gate[3]; int n; int Hp; };
 // up to 3 independent products of the same M, N, Kp in one launch
-hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s);
+hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s, const Options& o);
 // recurrent product with the GRU cell update fused into the epilogue: W planes in the gate-interleaved tile
 // order (ROW_GATES_TILED), p[d].C unused, gate[d] describes the cell operands / outputs
 hipError_t launch_gru_h3(const H3Batch& b, hipStream_t s);
 // the same step for small M (skinny_h3.hip): width-first blocks, K split over the waves, operands streamed to VGPRs
 hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s);
-hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s);
+hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s, const Options& o);
 struct H3ArgsBatch { H3Args p[3]; int n; };                       // independent products (own M, N, K) in one launch
-hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s);
-int skinny_h3_max_m();
+hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s, const Options& o);
 // gru_seq.hip: all T cell steps of one layer (up to 3 directions) in one persistent launch for M <= 64 rows, W_hh
 // planes stationary in registers.  Per (direction, step): where the step's gate pre-activations come from and where
 // its new state goes (fp32 + the planes view, as GateDir); step t reads the planes step t-1 wrote.
@@ -287,12 +317,10 @@ struct RegSeqArgs {
   unsigned* fault; unsigned spin_limit; unsigned inject;      // as GruSeqArgs
   int N, n_iter;
 };
-int reg_seq_max_n();
 hipError_t launch_reg_seq(const RegSeqArgs& a, hipStream_t s);
-bool gru_seq_ok(int ndir, int M, int Hp, int T);
-int gru_seq_max_m();
-int gru_seq_gran_max_m();
-hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s);
+bool gru_seq_ok(int ndir, int M, int Hp, int T, const Options& o);
+int gru_seq_gran_rows(const Options& o);        // min(Options::seq_gran_max_m, the kernel's granule capacity)
+hipError_t launch_gru_seq(const GruSeqArgs& a, hipStream_t s, const Options& o);
 // first cell step of a direction (h = 0: no product), writing the same outputs
 struct GateBatch { GateDir d[3]; };
 hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s, int scaled16 = 0);
@@ -308,15 +336,14 @@ hipError_t launch_split_planes(const float* src, long ld, long rows, int K, int 
 // (hi = fp16(v), lo = fp16(v - hi)), else the blocked [K/32][R][32] format (lo = fp16((v - hi) * 2^11)).
 // zero / zero_bytes (multiple of 16): the kernel also clears that block -- the forward's arrival counters and granules,
 // when this is the forward's first kernel (saves the memset node).
-int split_few_max_rows();              // rows up to which launch_split_rows runs one workgroup per row (TEPOSE_SPLIT_FEW_MAX_ROWS, 1024)
 // optional gathered source of launch_split_rows (the clip driver's two per-step projections as one product): row r < B = features f0[r] | theta th0[r],
 // row r >= B = features f1[r - B] | zeros -- what two launch_pad_rows calls would have written to a padded buffer first (evaluate.py:248-252)
 struct RowPairSrc { const float* f0; const float* th0; const float* f1; long fld, thld; long B; };
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
-                             float* row_scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0,
+                             float* row_scale, hipStream_t s, const Options& o, void* zero = nullptr, size_t zero_bytes = 0,
                              int permT = 0, const RowPairSrc* pair = nullptr);   // permT = T: source rows [B][T] -> plane rows / row_scale frame-major (t * B + b)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
-                              long ldc, int M, int N, int K, void* ws, hipStream_t s, int kind = 0);
+                              long ldc, int M, int N, int K, void* ws, hipStream_t s, const Options& o, int kind = 0);
 size_t gemm_h3_ws_bytes(int M, int N, int K);
 // gemm_h3s.hip: single accumulator, 256 x 256 tiles, scaled planes in the [K/16][R][16] layout:
 // element (row, k) of an [R x Kp] matrix (Kp multiple of 16), value v stored as hi = fp16(v p), lo = fp16(v p - hi)
@@ -341,16 +368,16 @@ struct H3SArgs {
   int c_blk_hp = 0;                      // != 0 (= Hp): C is a [rows][3 Hp] gate pre-activation matrix, written in the blocked layout (gi_blk_offset)
 };
 struct H3SBatch { H3SArgs p[3]; GateDir gate[3]; int n; int Hp; float state_scale; };   // state_scale: scale of the
-hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag = 1);   // every plain scaled-plane product of large batches (tag 0: the layer-0 projection: own kernel symbol for profiles)
+hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, const Options& o, int tag = 1);   // every plain scaled-plane product of large batches (tag 0: the layer-0 projection: own kernel symbol for profiles)
 bool gemm_h3s16_ok(const H3SArgs& a);
-hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag);  // gemm_h3s16c.hip: persistent, no workgroup barriers in the K loop
+hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag, int gm);  // gemm_h3s16c.hip: persistent, no workgroup barriers in the K loop
 unsigned h3s16c_read_err();
 void h3s16c_warm();                    // allocates the current device's debug error counter (tepose_set_blob: never inside a stream capture)
 // gru_step16.hip: the fused GRU cell step of large batches; planes = the instantiation that takes its cell operands through the LDS-DMA stream and
 // rebuilds h_{t-1} from the state planes (full tiles + blocked layouts only: gru_step16_planes_ok)
 bool gru_step16_ok(const H3SBatch& b);
 bool gru_step16_planes_ok(const H3SBatch& b);
-hipError_t launch_gru_step16(const H3SBatch& b, hipStream_t s, bool planes);
+hipError_t launch_gru_step16(const H3SBatch& b, hipStream_t s, bool planes, int gm);
 unsigned* h3s16c_err_of_device();      // the current device's debug counter of give-ups of the barrier-free kernels (nullptr: none)
 bool gemm_h3s_mid_ok(const H3SArgs& a);
 hipError_t launch_gemm_h3s_mid(const H3SArgs& a, hipStream_t s);   // 128 x 288 tiles, N % 288 == 0
@@ -359,7 +386,7 @@ hipError_t launch_split_planes16(const float* src, long ld, long rows, int K, in
 hipError_t launch_absmax(const float* src, size_t n, float* out, hipStream_t s);
 size_t gemm_h3s_ws_bytes(int M, int N, int K);
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
-                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias = nullptr,
+                               int K, float pA, float pW, void* ws, hipStream_t s, const Options& o, const float* bias = nullptr,
                                int mid = 0);   // mid: the 128 x 288-tile kernel (N % 288 == 0) instead of the barrier-free persistent one
 
 }  // namespace tepose

@@ -15,7 +15,9 @@
 // must stay lane-linear for LDS-DMA), which makes every ds_read_b128 conflict-free.
 #include "common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace tepose {
 
@@ -235,54 +237,49 @@ __global__ void __launch_bounds__(256, WMF == 2 ? TEPOSE_GEMM_OCC : 3) gemm_f32_
   }
 }
 
-// Rows at or below which the width-first kernels of skinny.hip win over 128-row tiles
-// (measured crossover; TEPOSE_SKINNY_MAX_M overrides it for experiments).
-int skinny_max_m() {
-  static const int v = [] {
-    const char* e = getenv("TEPOSE_SKINNY_MAX_M");
-    return e ? atoi(e) : 768;
-  }();
-  return v;
+// The one table of option names (common.h Options): environment variable TEPOSE_<NAME> at tepose_create, tepose_set_option(m, "<NAME>", v) afterwards.
+namespace {
+struct OptName { const char* name; int Options::*field; };
+const OptName kOptNames[] = {
+    {"SKINNY_MAX_M", &Options::skinny_max_m}, {"SKINNY_MAX_M_GEMM", &Options::skinny_max_m_gemm}, {"SPLIT_MIN_M", &Options::split_min_m},
+    {"SKINNY_H3_MAX_M", &Options::skinny_h3_max_m}, {"GEMM_HALF_MAX_BLOCKS", &Options::gemm_half_max_blocks},
+    {"SPLIT_FEW_MAX_ROWS", &Options::split_few_max_rows}, {"H3_TILE", &Options::h3_tile}, {"H3_TILE64", &Options::h3_tile64}, {"S16_GM", &Options::s16_gm},
+    {"GRU_GM", &Options::gru_gm}, {"SEQ_GRAN_MAX_M", &Options::seq_gran_max_m}, {"SEQ_MAX_M", &Options::seq_max_m}, {"REG_SEQ_MAX_N", &Options::reg_seq_max_n},
+    {"ASSUME_CUS", &Options::assume_cus}, {"SKINNY_NARROW64", &Options::skinny_narrow64}, {"SKINNY_MT1", &Options::skinny_mt1},
+    {"SKINNY_NT1_BELOW", &Options::skinny_nt1_below}, {"SKINNY_W8", &Options::skinny_w8}, {"SMPL_SMALL_MAX_N", &Options::smpl_small_max_n},
+    {"L1_SKINNY_MAX_ROWS", &Options::l1_skinny_max_rows}, {"G0_MID_MIN_ROWS", &Options::g0_mid_min_rows}, {"G0_SKINNY_MAX_M", &Options::g0_skinny_max_m},
+};
+}  // namespace
+
+int* option_field(Options& o, const char* name) {
+  if (!name) return nullptr;
+  if (strncmp(name, "TEPOSE_", 7) == 0) name += 7;
+  for (const OptName& n : kOptNames)
+    if (strcmp(n.name, name) == 0) return &(o.*(n.field));
+  return nullptr;
 }
 
-// Rows above which a split-mode handle runs its matmuls on the fp16x3 kernels of gemm_h3.hip (measured
-// crossover against the fp32 skinny kernels, ms per forward at T = 16, split vs fp32: B = 1 0.55 vs 0.54, B = 4
-// 0.66 vs 0.62, B = 8 0.59 vs 0.67, B = 16 0.63 vs 0.79, B = 32 0.77 vs 1.09, B = 64 1.10 vs 1.59, B = 768 4.7 vs 10.7)
-int split_min_m() {
-  static const int v = [] {
-    const char* e = getenv("TEPOSE_SPLIT_MIN_M");
-    return e ? atoi(e) : 0;     // round 2: the split kernels win at every batch size (B = 1: 0.48 vs 0.55 ms per forward)
-  }();
-  return v;
+// the environment's view of the options, read when a handle is created (and by the handle-less test entry points, per call)
+Options options_from_env() {
+  Options o;
+  char var[64];
+  for (const OptName& n : kOptNames) {
+    snprintf(var, sizeof(var), "TEPOSE_%s", n.name);
+    const char* e = getenv(var);
+    if (e) o.*(n.field) = atoi(e);
+  }
+  const char* e = getenv("TEPOSE_SEQ_STAMP_PTR");
+  o.seq_stamp_ptr = e ? strtoull(e, nullptr, 0) : 0ull;
+  return o;
 }
 
-// Rows up to which a split-mode GRU step uses the width-first kernel of skinny_h3.hip instead of 64/128-row tiles
-int skinny_h3_max_m() {
-  static const int v = [] {
-    const char* e = getenv("TEPOSE_SKINNY_H3_MAX_M");
-    return e ? atoi(e) : 128;
-  }();
-  return v;
-}
-
-static int skinny_max_m_gemm() {
-  static const int v = [] {
-    const char* e = getenv("TEPOSE_SKINNY_MAX_M_GEMM");
-    return e ? atoi(e) : skinny_max_m();
-  }();
-  return v;
-}
-
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s, const Options& o) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (a.M <= skinny_max_m_gemm()) return launch_skinny_gemm(a, s);
+  if (a.M <= (o.skinny_max_m_gemm >= 0 ? o.skinny_max_m_gemm : o.skinny_max_m)) return launch_skinny_gemm(a, s);
   const int tilesN = (a.N + 127) / 128;
   // 64-row tiles (3 blocks per CU) when 128-row tiles would not fill the 512 block slots twice:
-  // finer quantisation for the mid-size batches (TEPOSE_GEMM_HALF_MAX_BLOCKS overrides the bound)
-  static const int half_max_blocks = [] {
-    const char* e = getenv("TEPOSE_GEMM_HALF_MAX_BLOCKS");
-    return e ? atoi(e) : 1024;      // measured: +4-6 % at B = 64-128, +4.5 % at B = 1024, neutral at B = 8192
-  }();
+  // finer quantisation for the mid-size batches (measured: +4-6 % at B = 64-128, +4.5 % at B = 1024, neutral at B = 8192)
+  const int half_max_blocks = o.gemm_half_max_blocks;
   const int tiles128 = (a.M + 127) / 128;
   if (tiles128 * tilesN <= half_max_blocks) {
     const int tilesM = (a.M + 63) / 64;
@@ -383,9 +380,9 @@ __global__ void __launch_bounds__(256, TEPOSE_GRU_OCC) gru_step_kernel(GruArgs a
   }
 }
 
-hipError_t launch_gru_step(const GruArgs& a, hipStream_t s) {
+hipError_t launch_gru_step(const GruArgs& a, hipStream_t s, const Options& o) {
   if (a.M <= 0 || a.ndir <= 0) return hipSuccess;
-  if (a.M <= skinny_max_m()) return launch_skinny_gru(a, s);
+  if (a.M <= o.skinny_max_m) return launch_skinny_gru(a, s);
   const int tilesM = (a.M + BM - 1) / BM, tilesJ = a.Hp / 64;
   dim3 grid(tilesM * tilesJ, a.ndir), block(256);
   hipLaunchKernelGGL(gru_step_kernel, grid, block, 0, s, a, tilesM, tilesJ);

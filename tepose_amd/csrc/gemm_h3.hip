@@ -249,21 +249,16 @@ __global__ void __launch_bounds__(256) split_rows_few_kernel(const float* __rest
   }
 }
 
-int split_few_max_rows() {
-  // (one workgroup per row up to 1024 rows: 222 rows 12.3 -> 5 us, 1024 rows 13 -> 8; the 8-rows-per-block kernel is for bandwidth, from a few thousand rows)
-  static const int v = [] { const char* e = getenv("TEPOSE_SPLIT_FEW_MAX_ROWS"); return e ? atoi(e) : 1024; }();
-  return v;
-}
-
 hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp, long R, int fmt16, void* hi, void* lo,
-                             float* row_scale, hipStream_t s, void* zero, size_t zero_bytes, int permT, const RowPairSrc* pair) {
+                             float* row_scale, hipStream_t s, const Options& o, void* zero, size_t zero_bytes, int permT, const RowPairSrc* pair) {
+  // (one workgroup per row up to Options::split_few_max_rows rows; the 8-rows-per-block kernel is for bandwidth, from a few thousand rows)
   if (rows <= 0) return hipSuccess;
   const RowPairSrc pr = pair ? *pair : RowPairSrc{};
   if (pair && (permT || !pr.f0 || !pr.f1 || !pr.th0 || K <= kFeat)) return hipErrorInvalidValue;
-  if (permT && (rows % permT != 0 || rows <= split_few_max_rows())) return hipErrorInvalidValue;
+  if (permT && rows % permT != 0) return hipErrorInvalidValue;
   if (zero_bytes % 16 != 0) return hipErrorInvalidValue;
   if (Kp > 64 * 2 * 17 || Kp > kRowsLd || (Kp & 31)) return hipErrorInvalidValue;        // the [., 2144] input rows
-  if (rows <= split_few_max_rows() && Kp <= 4096) {
+  if (rows <= o.split_few_max_rows && Kp <= 4096 && !permT) {      // (the frame-major permutation lives in the 8-rows-per-block kernel: whatever the threshold says)
     if (fmt16)
       hipLaunchKernelGGL((split_rows_few_kernel<true>), dim3((unsigned)rows), dim3(256), 0, s, src, ld, rows, K, Kp, R,
                          (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), pr);
@@ -735,7 +730,7 @@ __global__ void __launch_bounds__(128 * NWM) gemm_h3_kernel(H3Batch batch, int t
 
 // test / bench entry: fp32 A[M,K], W[N,K] -> planes in `ws` -> C (K multiple of 32)
 hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
-                              long ldc, int M, int N, int K, void* ws, hipStream_t s, int kind) {
+                              long ldc, int M, int N, int K, void* ws, hipStream_t s, const Options& o, int kind) {
   const int Np = round_up(N, 128);
   const long Ra = M, Rw = Np;
   char* p = (char*)ws;
@@ -751,15 +746,15 @@ hipError_t launch_gemm_h3_f32(const float* A, long lda, const float* W, long ldw
   b.p[0] = H3Args{(const half_t*)Ah, (const half_t*)Al, Ra * 32, (const half_t*)Wh, (const half_t*)Wl, Rw * 32, K,
                   C, ldc, bias, M, N};
   b.n = 1;
-  if (kind) return launch_skinny_gemm_h3(b.p[0], s);      // test / bench entry: the width-first kernel at any M
-  return launch_gemm_h3(b, s);
+  if (kind) return launch_skinny_gemm_h3(b.p[0], s, o);      // test / bench entry: the width-first kernel at any M
+  return launch_gemm_h3(b, s, o);
 }
 
 // 256 x 128 block tile, 3-stage ring of 48 KB stages
-hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
+hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s, const Options& o) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   const int tilesM = (b.p[0].M + 255) / 256, tilesN = (b.p[0].N + 127) / 128;
-  static const int tile_dbg = [] { const char* e = getenv("TEPOSE_H3_TILE"); return e ? atoi(e) : 0; }();   // A/B: force a tile shape
+  const int tile_dbg = o.h3_tile;   // A/B: force a tile shape
   if (tile_dbg == 64) {
     const int tm = (b.p[0].M + 63) / 64;
     hipLaunchKernelGGL((gemm_h3_kernel<1, 2, 3, false, false, 2>), dim3(tm * tilesN, b.n), dim3(256), 0, s, b, tm, tilesN);
@@ -780,7 +775,7 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s) {
     // ... and 64-row tiles (4 waves, 72 KB ring: two workgroups per CU) where they need fewer rounds of the chip.  Measured per round at K = 2144
     // (profiles/r05_mid_rows_gemm.txt): a 128-row tile 47 us, one workgroup per CU; a 64-row tile 33 us, and 33 us x workgroups / 256 once they share
     // CUs.  444 x 9216: 97.8 -> 62.8 us; 128 x 9216: 44.9 -> 34.4; 288 x 3072: 44.0 -> 33.2; 1024 x 3072 stays (49.2 against 53.0).
-    static const int t64 = [] { const char* e = getenv("TEPOSE_H3_TILE64"); return e ? atoi(e) : 1; }();     // 0: never (A/B)
+    const int t64 = o.h3_tile64;     // 0: never (A/B)
     const int tm64 = (b.p[0].M + 63) / 64;
     const double w128 = (double)tm * tilesN * b.n, w64 = (double)tm64 * tilesN * b.n;
     // (more than one 64-row workgroup per CU: the first sharing costs 1.55 rounds whatever the count -- 288 workgroups 51.8 us, 384: 53.0, 504: 62.8)

@@ -267,9 +267,9 @@ __global__ void __launch_bounds__(64 * NWM * NWN) gemm_h3s_kernel(H3SBatch batch
   }
 }
 
-hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, int tag) {   // every plain scaled-plane product of large batches: the barrier-free persistent kernel
+hipError_t launch_gemm_h3s(const H3SArgs& a, hipStream_t s, const Options& o, int tag) {   // every plain scaled-plane product of large batches: the barrier-free persistent kernel
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  return launch_gemm_h3s16c(a, s, tag);
+  return launch_gemm_h3s16c(a, s, tag, o.s16_gm);
 }
 
 // Mid-size products (a few hundred to a few thousand rows) whose N is a multiple of 288 -- the stacked layer-0 block, 9 Hp
@@ -292,7 +292,7 @@ size_t gemm_h3s_ws_bytes(int M, int N, int K) {
 
 // test / bench entry: fp32 A[M,K], W[N,K] (no bias) -> scaled planes in ws -> C; pA / pW: power-of-two operand scales
 hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
-                               int K, float pA, float pW, void* ws, hipStream_t s, const float* bias, int mid) {
+                               int K, float pA, float pW, void* ws, hipStream_t s, const Options& o, const float* bias, int mid) {
   const int Kp = round_up(K, 16), Np = round_up(N, 256);
   char* p = (char*)ws;
   _Float16* Ah = (_Float16*)p; p += align_up((size_t)M * Kp * 2, 256);
@@ -305,7 +305,7 @@ hipError_t launch_gemm_h3s_f32(const float* A, long lda, const float* W, long ld
   if ((e = launch_split_planes16(W, ldw, N, K, Kp, Np, pW, Wh, Wl, s)) != hipSuccess) return e;
   H3SArgs a{Ah, Al, (long)M * 16, Wh, Wl, (long)Np * 16, Kp, C, ldc, bias, 1.f / (pA * pW), M, N};
   if (mid) return launch_gemm_h3s_mid(a, s);
-  return launch_gemm_h3s(a, s);
+  return launch_gemm_h3s(a, s, o);
 }
 
 }  // namespace tepose

@@ -345,14 +345,13 @@ void h3s16c_warm() {
 
 bool gemm_h3s16_ok(const H3SArgs& a) { return a.Kp % 32 == 0 && a.Kp >= 64; }
 
-hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag) {
+hipError_t launch_gemm_h3s16c(const H3SArgs& a, hipStream_t s, int tag, int gm_opt) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (!gemm_h3s16_ok(a)) return hipErrorInvalidValue;
   const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
   const int nt = tilesM * tilesN;
-  // row tiles per XCD group of the walk (the 32 workgroups of an XCD take GM x 32 / GM tiles at a time); layer-0 projection, ms at GM = 2 / 4 / 8 / 16 / 32:
-  // 10.92 / 10.82 / 10.74 / 11.37 / 12.37 (round 4)
-  static const int gm = [] { const char* e = getenv("TEPOSE_S16_GM"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 32 ? v : 8; }();
+  // row tiles per XCD group of the walk (the 32 workgroups of an XCD take GM x 32 / GM tiles at a time; Options::s16_gm)
+  const int gm = gm_opt >= 1 && gm_opt <= 32 ? gm_opt : 8;
   unsigned* err = h3s16c_err_of_device();
   if (tag == 0) hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<0>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, err);
   else hipLaunchKernelGGL(gemm_h3s_persist16c_kernel<1>, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, a, tilesM, tilesN, gm, err);

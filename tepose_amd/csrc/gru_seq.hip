@@ -484,56 +484,40 @@ static hipError_t launch_mt(const GruSeqArgs& a, dim3 grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-int gru_seq_gran_max_m() {
-  static const int v = [] {
-    const char* e = getenv("TEPOSE_SEQ_GRAN_MAX_M");   // rows up to which the state travels as tagged granules (0: never)
-    const int x = e ? atoi(e) : 4;                     // measured: B = 1 -14 %, B = 4 -5 %, B = 8 +20 % per forward
-    return x > (int)kSeqGranRows ? (int)kSeqGranRows : x;
-  }();
-  return v;
-}
+// rows up to which the state travels as tagged granules (Options::seq_gran_max_m, at most the kernel's granule capacity; 0: never)
+int gru_seq_gran_rows(const Options& o) { return o.seq_gran_max_m > (int)kSeqGranRows ? (int)kSeqGranRows : o.seq_gran_max_m; }
 
-int gru_seq_max_m() {
-  static const int v = [] {
-    const char* e = getenv("TEPOSE_SEQ_MAX_M");      // 0 disables the persistent recurrent kernel (A/B runs)
-    const int x = e ? atoi(e) : 64;
-    return x > 64 ? 64 : x;
-  }();
-  return v;
-}
-
-static int device_cus() {
-  static const int cus = [] {
-    const char* e = getenv("TEPOSE_ASSUME_CUS");     // planning on a machine without a device (tests/test_dispatch.py, tepose_select_kernels)
-    if (e && atoi(e) > 0) return atoi(e);
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n;
-  }();
-  return cus;
+// CUs of the current device (Options::assume_cus > 0: planning on a machine without one -- tests/test_dispatch.py, tepose_select_kernels).  A device
+// property, not configuration: asked once per device.
+static int device_cus(const Options& o) {
+  if (o.assume_cus > 0) return o.assume_cus;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  static int cached[64] = {};
+  if (dev >= 0 && dev < 64 && __atomic_load_n(&cached[dev], __ATOMIC_RELAXED) > 0) return __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (dev >= 0 && dev < 64) __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+  return n;
 }
 
 // usable for this layer shape on this device?  Every workgroup must be resident at once (one per CU).
-bool gru_seq_ok(int ndir, int M, int Hp, int T) {
-  const int cus = device_cus();
-  return M >= 1 && M <= gru_seq_max_m() && T >= 2 && T <= kSeqMaxT && Hp % 256 == 0 && Hp <= 1024 && ndir >= 1 &&
+bool gru_seq_ok(int ndir, int M, int Hp, int T, const Options& o) {
+  const int cus = device_cus(o);
+  const int max_m = o.seq_max_m > 64 ? 64 : o.seq_max_m;
+  return M >= 1 && M <= max_m && T >= 2 && T <= kSeqMaxT && Hp % 256 == 0 && Hp <= 1024 && ndir >= 1 &&
          ndir <= 3 && ndir * (Hp / 16) <= cus;
 }
 
-hipError_t launch_gru_seq(const GruSeqArgs& a0, hipStream_t s) {
+hipError_t launch_gru_seq(const GruSeqArgs& a0, hipStream_t s, const Options& o) {
   GruSeqArgs a = a0;
 #ifdef TEPOSE_SEQ_STAMPS
-  {
-    const char* e = getenv("TEPOSE_SEQ_STAMP_PTR");     // device buffer of 3 * kSeqMaxT * 8 uint64 (tools/seq_stamps.py)
-    a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
-  }
+  a.stamps = (unsigned long long*)o.seq_stamp_ptr;        // device buffer of 3 * kSeqMaxT * 8 uint64 (tools/seq_stamps.py)
 #else
   a.stamps = nullptr;
 #endif
-  if (!gru_seq_ok(a.ndir, a.M, a.Hp, a.T)) return hipErrorInvalidValue;
+  if (!gru_seq_ok(a.ndir, a.M, a.Hp, a.T, o)) return hipErrorInvalidValue;
   dim3 grid(a.Hp / 16, 1, a.ndir);
-  if (a.M <= gru_seq_gran_max_m() && a.gran) return launch_gran(a, grid, s);
+  if (a.M <= gru_seq_gran_rows(o) && a.gran) return launch_gran(a, grid, s);
   if (a.M <= 16) return launch_mt<1>(a, grid, s);
   if (a.M <= 32) return launch_mt<2>(a, grid, s);
   if (a.M <= 48) return launch_mt<3>(a, grid, s);      // 33..48 rows (37 clips in lock-step): three tiles -- a quarter less state through the L2 port per step

@@ -366,13 +366,12 @@ bool gru_step16_planes_ok(const H3SBatch& b) {
   return true;
 }
 
-hipError_t launch_gru_step16(const H3SBatch& b, hipStream_t s, bool planes) {
+hipError_t launch_gru_step16(const H3SBatch& b, hipStream_t s, bool planes, int gm_opt) {
   if (b.n <= 0 || b.p[0].M <= 0) return hipSuccess;
   if (!gru_step16_ok(b) || (planes && !gru_step16_planes_ok(b))) return hipErrorInvalidValue;
   const int tm = (b.p[0].M + 127) / 128, tj = b.Hp / 64;
-  // tile rows per XCD group (TEPOSE_GRU_GM): the 64 workgroups resident on an XCD cover GM row tiles x 64 / GM unit tiles of one direction
-  // (recurrent ms per forward at GM = 1 / 2 / 4 / 8 / 16 / 32: 11.31 / 11.27 / 11.22 / 11.41 / 11.41 / 11.77, round 4)
-  static const int gm = [] { const char* e = getenv("TEPOSE_GRU_GM"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+  // tile rows per XCD group (Options::gru_gm): the 64 workgroups resident on an XCD cover GM row tiles x 64 / GM unit tiles of one direction
+  const int gm = gm_opt >= 1 && gm_opt <= 64 ? gm_opt : 4;
   if (planes) hipLaunchKernelGGL((gru_step16_kernel<true>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj, gm);
   else hipLaunchKernelGGL((gru_step16_kernel<false>), dim3(tm * tj, b.n), dim3(256), 0, s, b, tm, tj, gm);
   return hipGetLastError();

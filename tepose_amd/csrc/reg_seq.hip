@@ -275,15 +275,6 @@ __global__ void __launch_bounds__(512) reg_seq_kernel(RegSeqArgs a) {
   }
 }
 
-int reg_seq_max_n() {
-  static const int v = [] {
-    const char* e = getenv("TEPOSE_REG_SEQ_MAX_N");      // 0 disables the persistent regressor kernel (A/B runs)
-    const int x = e ? atoi(e) : 64;
-    return x > 64 ? 64 : x;
-  }();
-  return v;
-}
-
 hipError_t launch_reg_seq(const RegSeqArgs& a, hipStream_t s) {
   if (a.N < 1 || a.N > 64) return hipErrorInvalidValue;
   if (a.N <= 16) hipLaunchKernelGGL((reg_seq_kernel<1>), dim3(64), dim3(512), 0, s, a);

@@ -277,27 +277,17 @@ __global__ void __launch_bounds__(64 * NW) skinny_gemm_h3_kernel(H3ArgsBatch bat
   }
 }
 
-static bool narrow64() {
-  static const bool v = [] { const char* e = getenv("TEPOSE_SKINNY_NARROW64"); return e ? atoi(e) != 0 : true; }();
-  return v;
-}
-
-static bool mt1_rows16() {
-  static const bool v = [] { const char* e = getenv("TEPOSE_SKINNY_MT1"); return e ? atoi(e) != 0 : true; }();
-  return v;
-}
-
-hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
+hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s, const Options& o) {
   int maxM = 0, maxN = 0;
   for (int i = 0; i < b.n; ++i) { maxM = b.p[i].M > maxM ? b.p[i].M : maxM; maxN = b.p[i].N > maxN ? b.p[i].N : maxN; }
   if (b.n <= 0 || maxM <= 0 || maxN <= 0) return hipSuccess;
   const int nt = (maxN + 47) / 48;
-  static const int nt1_max = [] { const char* e = getenv("TEPOSE_SKINNY_NT1_BELOW"); return e ? atoi(e) : 96; }();
+  const int nt1_max = o.skinny_nt1_below;
   {
     // narrow products (the collapsed regressor product: 160 columns = 10 blocks of 16; the 2048-column tail linears at <= 16 rows): a CU takes in ~50 GB/s,
     // so the launch lasts as long as its busiest block's bytes -- one 16-row tile per block (W re-read per row tile from L2, A never clamped-and-repeated)
     // puts them on rows x more CUs: 64 rows x 160 x 3072 on 40 blocks of 392 KB instead of 10 of 960 KB
-    const bool mt1 = mt1_rows16();
+    const bool mt1 = o.skinny_mt1 != 0;
     const int blocks16 = (maxN + 15) / 16 * b.n, rowtiles = (maxM + 15) / 16;
     if (mt1 && nt * b.n < nt1_max && blocks16 * rowtiles <= 256) {
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<1, 1, 8, 4>), dim3((maxN + 15) / 16, rowtiles, b.n), dim3(512), 0, s, b);
@@ -306,15 +296,15 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
   }
   if (maxM <= 32 && nt * b.n < nt1_max) {          // few rows, narrow product: 16-column blocks put a weight stream on 3x the CUs
     // (<= 128 such blocks -- the 2048-column tail linears: 8 waves split K, twice the weight bytes in flight per CU)
-    static const bool w8 = [] { const char* e = getenv("TEPOSE_SKINNY_W8"); return e ? atoi(e) != 0 : true; }();
+    const bool w8 = o.skinny_w8 != 0;
     if (w8 && (maxN + 15) / 16 * b.n <= 128)
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 8, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
     else
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<2, 1, 4, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(256), 0, s, b);
-  } else if (maxM <= 64 && maxM > 32 && nt * b.n < 96 && narrow64()) {
+  } else if (maxM <= 64 && maxM > 32 && nt * b.n < 96 && o.skinny_narrow64 != 0) {
     // (as above: <= 128 blocks -- the collapsed regressor product, N = 160: 10 blocks -- split K over 8 waves: the block's chain of dependent weight
     // chunks halves)
-    static const bool w8 = [] { const char* e = getenv("TEPOSE_SKINNY_W8"); return e ? atoi(e) != 0 : true; }();
+    const bool w8 = o.skinny_w8 != 0;
     if (w8 && (maxN + 15) / 16 * b.n <= 128)
       hipLaunchKernelGGL((skinny_gemm_h3_kernel<4, 1, 8, 4>), dim3((maxN + 15) / 16, 1, b.n), dim3(512), 0, s, b);
     else
@@ -323,7 +313,7 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
     // row tiles dealt evenly over the fewest passes of <= 4 tiles: a block never loads a clamped-and-repeated tile beyond the last one of the batch
     // (74 rows = 5 tiles: 3 + 2 instead of 4 + 1 and three repeats; 16 rows: 1 tile instead of 2)
     const int tiles = (maxM + 15) / 16, passes = (tiles + 3) / 4;
-    const int mt = mt1_rows16() ? (tiles + passes - 1) / passes : (maxM <= 32 ? 2 : 4);
+    const int mt = o.skinny_mt1 != 0 ? (tiles + passes - 1) / passes : (maxM <= 32 ? 2 : 4);
     const dim3 grid(nt, (tiles + mt - 1) / mt, b.n);
     if (mt <= 1) hipLaunchKernelGGL((skinny_gemm_h3_kernel<1>), grid, dim3(256), 0, s, b);
     else if (mt == 2) hipLaunchKernelGGL((skinny_gemm_h3_kernel<2>), grid, dim3(256), 0, s, b);
@@ -333,10 +323,10 @@ hipError_t launch_skinny_gemm_h3_batch(const H3ArgsBatch& b, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s) {
+hipError_t launch_skinny_gemm_h3(const H3Args& a, hipStream_t s, const Options& o) {
   H3ArgsBatch b{};
   b.p[0] = a; b.n = 1;
-  return launch_skinny_gemm_h3_batch(b, s);
+  return launch_skinny_gemm_h3_batch(b, s, o);
 }
 
 hipError_t launch_skinny_gru_h3(const H3Batch& b, hipStream_t s) {

@@ -531,6 +531,15 @@ class Engine:
         txt = (self.lib.tepose_kernel_info(self.handle) or b'').decode()
         return dict(kv.split('=', 1) for kv in txt.split(';') if '=' in kv) if txt else {}
 
+    def set_option(self, name, value):
+        """One integer option of THIS handle (include/tepose_amd.h tepose_set_option; e.g. 'S_MIN_B', 'SKINNY_H3_MAX_M'); refused once anything is packed."""
+        _lib.check(self.lib.tepose_set_option(self.handle, str(name).encode(), int(value)), 'tepose_set_option(%s)' % name)
+        self._uses_persistent.clear()
+        self._ws_need.clear()
+
+    def get_option(self, name):
+        return int(self.lib.tepose_get_option(self.handle, str(name).encode()))
+
     def select_kernels(self, B, T):
         """The kernel selection of an eval forward of B windows x T frames on this handle, family -> kernel symbol / layout (the C library's own
         dispatch function: csrc/api.hip select_kernels).  No device needed."""

@@ -112,3 +112,55 @@ def test_kernel_info_is_the_cfg_c_selection():
             "k, s = e.kernel_info(), e.select_kernels(8192, 16)\nassert k == {'projection': s['projection'], 'gru_step': s['gru_step']}, (k, s)\nprint('ok')" % ROOT)
     out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TEPOSE_ASSUME_CUS='256'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
+
+
+def test_options_are_per_handle_not_per_process():
+    """SURVEY 8b "no global mutable state" (VERDICT r5 item 7): two handles of ONE process with different thresholds select different kernels; a handle
+    created later does not see another handle's options; the environment is read at tepose_create only."""
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+from tepose_amd.engine import Engine
+from tepose_amd import _lib
+a, b = Engine(2, 1024), Engine(2, 1024)
+assert a.get_option('S_MIN_B') == 640 and a.get_option('TEPOSE_SKINNY_H3_MAX_M') == 128 and a.get_option('NO_SUCH') == -1
+b.set_option('S_MIN_B', 2048)
+b.set_option('TEPOSE_SKINNY_H3_MAX_M', 64)
+b.set_option('SEQ_MAX_M', 16)
+os.environ['TEPOSE_S_MIN_B'] = '4096'                 # after creation: nobody re-reads it ...
+out = {'a': [a.select_kernels(640, 16)['gru_step'], a.select_kernels(100, 16)['gru_step'], a.select_kernels(32, 16)['gru_step']],
+       'b': [b.select_kernels(640, 16)['gru_step'], b.select_kernels(100, 16)['gru_step'], b.select_kernels(32, 16)['gru_step']]}
+c = Engine(2, 1024)                                   # ... except the next tepose_create
+out['c'] = [c.select_kernels(640, 16)['gru_step'], c.get_option('S_MIN_B'), c.get_option('SEQ_MAX_M')]
+out['a_after'] = [a.get_option('S_MIN_B'), a.get_option('SEQ_MAX_M')]
+rc = _lib.load().tepose_set_option(a.handle, b'NO_SUCH_OPTION', 1)
+out['unknown_rc'] = rc
+print(json.dumps(out))
+""" % ROOT
+    e = dict(os.environ, TEPOSE_ASSUME_CUS='256')
+    for k in ('TEPOSE_S_MIN_B', 'TEPOSE_SKINNY_H3_MAX_M', 'TEPOSE_SEQ_MAX_M'):
+        e.pop(k, None)
+    import json
+    out = subprocess.run([sys.executable, '-c', code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r['a'] == ['gru_step16_kernel<true>', 'skinny_gru_h3_kernel', 'gru_seq_kernel']
+    assert r['b'] == ['gemm_h3_kernel<GRU>', 'gemm_h3_kernel<GRU>', 'skinny_gru_h3_kernel']       # S_MIN_B 2048 | SKINNY_H3_MAX_M 64 | SEQ_MAX_M 16
+    assert r['c'] == ['gemm_h3_kernel<GRU>', 4096, 64] and r['a_after'] == [640, 64]
+    assert r['unknown_rc'] == -1
+
+
+def test_no_launcher_reads_the_environment():
+    """No function-local static (or any other code outside tepose_create's options_from_env / read_env_knobs and the handle-less test entry points)
+    reads a TEPOSE_* variable: grep of the sources."""
+    import glob
+    import re
+    hits = []
+    for f in sorted(glob.glob(os.path.join(ROOT, 'tepose_amd', 'csrc', '*'))):
+        src = open(f).read()
+        for mo in re.finditer(r'getenv\(', src):
+            line = src.count('\n', 0, mo.start()) + 1
+            hits.append((os.path.basename(f), line, src.splitlines()[line - 1].strip()))
+    allowed = [h for h in hits if h[0] == 'gemm.hip' or (h[0] == 'api.hip' and ('read_env' in h[2] or 'TEPOSE_H3S' in h[2] or re.match(r'(const char\* )?e = getenv', h[2])))]
+    assert hits == allowed, [h for h in hits if h not in allowed]
+    assert not [h for h in hits if 'static' in h[2]], hits
