@@ -1,7 +1,8 @@
 """Probe for the "GEMM || cell update on two streams" idea: does an HBM-streaming element-wise kernel on a
 second stream run BESIDE the step kernel's K loops, or do the two meet in the CU's vector-memory path as the fused update does?
-Run with a timing-only build whose step kernel has no cell update (tools/build_abl.sh gemm_h3s16 TEPOSE_G16_ABL g16abl 64;
-TEPOSE_AMD_LIB=build/abl/lib_g16abl64.so) and with the shipped library:
+Round 5 ran it with a timing-only build whose step kernel had no cell update (an ablation macro of gemm_h3s16.hip, a file that no longer exists: the record
+is profiles/r05_split_probe.txt; HEAD has no such switch -- to repeat the probe, stub the update loop of csrc/gru_step16.hip in a private build and point
+TEPOSE_AMD_LIB at it) and with the shipped library:
     python tools/gru_split_probe.py [B]
 Prints, per configuration: the library's own hipEvent times of the layer-0 projection and of the recurrent part of one encoder
 forward, alone and with a stream of torch.add(a, b, out=c) launches (3 x 100 MB each: the bytes a split-off update kernel of one
