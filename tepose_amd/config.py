@@ -109,3 +109,28 @@ def eval_db_paths(cfg, dataset, db_dir='data/preprocessed_data', render=False):
     else:
         raise ValueError('Wrong target dataset %r (3dpw | h36m | mpii3d)' % dataset)
     return osp.join(db_dir, stem + '_db.pt'), osp.join(db_dir, stem + '_pseudotheta.pt')
+
+
+# What the reference publishes for this path (mm; accel in mm/s^2): asset/wpw.png (Table 1) and asset/wopw.png (Table 2) of the reference checkout,
+# referenced at README.md:86-87; window T + 1 = 6 frames, 2-layer GRU, hidden 1024.  Keyed by (config TITLE, evaluate.py --dataset).
+PUBLISHED_METRICS = {
+    ('repr_wpw_3dpw_model', '3dpw'): {'mpjpe_pa': 52.3, 'mpjpe': 84.6, 'mpvpe': 100.3, 'accel_err': 11.4},
+    ('repr_wpw_h36m_mpii3d_model', 'mpii3d'): {'mpjpe_pa': 63.1, 'mpjpe': 96.2, 'accel_err': 16.7},
+    ('repr_wpw_h36m_mpii3d_model', 'h36m'): {'mpjpe_pa': 47.1, 'mpjpe': 68.6, 'accel_err': 12.1},
+    ('repr_wopw_3dpw_model', '3dpw'): {'mpjpe_pa': 56.1, 'mpjpe': 93.9, 'mpvpe': 115.9, 'accel_err': 11.7},
+    ('repr_wopw_mpii3d_model', 'mpii3d'): {'mpjpe_pa': 62.9, 'mpjpe': 99.5, 'accel_err': 17.2},
+    ('repr_wopw_h36m_model', 'h36m'): {'mpjpe_pa': 41.2, 'mpjpe': 61.6, 'accel_err': 12.0},
+}
+
+
+def published_row(cfg_title, dataset):
+    """The published accuracy row for an experiment config and evaluation set, or None."""
+    return PUBLISHED_METRICS.get((cfg_title, dataset))
+
+
+def compare_with_published(measured, cfg_title, dataset):
+    """{metric: {'measured', 'published', 'diff'}} for the metrics both have (evaluate.py:461's keys); None without a published row."""
+    row = published_row(cfg_title, dataset)
+    if row is None or not measured:
+        return None
+    return {k: {'measured': float(measured[k]), 'published': v, 'diff': float(measured[k]) - v} for k, v in row.items() if k in measured}

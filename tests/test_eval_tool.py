@@ -134,3 +134,58 @@ def test_the_tool_source_reads_no_synthetic_table_in_real_mode():
     assert 'synth.' not in real
     main = src[src.index('def main'):]
     assert "synth.synthetic_smpl" not in main and "smpl_np['J_regressor_h36m']" not in main
+
+
+def test_check_mode_reports_real_data_readiness(tmp_path, capsys):
+    """`tools/evaluate_clips.py --check`: found / missing licence-gated files (reference README.md:21-25,37-62) with their shapes, the
+    published row the run will be compared with; exit code 0 only when everything a real-data run needs is there.  Fabricated files, CPU only."""
+    import joblib
+    import json
+    from tepose_amd.config import compare_with_published, published_row
+    from tepose_amd.data import synthetic_eval_db
+    T = _tool()
+    db, pse = synthetic_eval_db([7, 9], seed=3)
+    joblib.dump(db, tmp_path / '3dpw_test_db.pt')
+    joblib.dump(pse, tmp_path / '3dpw_test_pseudotheta.pt')
+    smpl_np = synth.synthetic_smpl(0)
+    write_base_data(tmp_path / 'base', smpl_np, synth.synthetic_mean_params(0))
+    write_checkpoint(tmp_path / 'tepose.pth.tar', synth.synthetic_state_dict(1, 64, 2), prefix='module.')
+    write_checkpoint(tmp_path / 'vibe.pth.tar', synth.synthetic_vibe_state_dict(1, 64, 3))
+    write_cfg(tmp_path / 'c.yaml', 'repr_wpw_3dpw_model', 1, 64, pretrained=str(tmp_path / 'tepose.pth.tar'))
+    argv = ['--check', '--cfg', str(tmp_path / 'c.yaml'), '--dataset', '3dpw', '--base-data', str(tmp_path / 'base'), '--db-dir', str(tmp_path),
+            '--vibe-ckpt', str(tmp_path / 'vibe.pth.tar')]
+    rep = T.readiness_report(T.parse_args(argv))
+    assert rep['ready'] and not rep['missing'] and not rep['unreadable'] and rep['cfg_title'] == 'repr_wpw_3dpw_model'
+    assert rep['published'] == {'mpjpe_pa': 52.3, 'mpjpe': 84.6, 'mpvpe': 100.3, 'accel_err': 11.4}          # BASELINE.md section 1, row 1
+    by = {os.path.basename(str(f['path'])): f for f in rep['files']}
+    assert by['J_regressor_h36m.npy']['shape'] == [17, 6890] and by['J_regressor_extra.npy']['shape'] == [9, 6890]
+    assert by['smpl_mean_params.npz']['arrays'] == {'pose': [144], 'shape': [10], 'cam': [3]}
+    assert by['SMPL_NEUTRAL.pkl']['arrays']['v_template'] == [6890, 3]
+    assert by['3dpw_test_db.pt']['clips'] == 2 and by['3dpw_test_db.pt']['frames'] == 16 and by['3dpw_test_db.pt']['arrays']['features'] == [16, 2048]
+    assert by['3dpw_test_pseudotheta.pt']['shape'] == [16, 85]
+    assert by['tepose.pth.tar']['tensors'] > 20 and abs(by['tepose.pth.tar']['performance'] - 51.2) < 1e-9
+    # through main(): one JSON line, exit code 0
+    import sys
+    old = sys.argv
+    sys.argv = ['evaluate_clips.py'] + argv
+    try:
+        with pytest.raises(SystemExit) as e:
+            T.main()
+    finally:
+        sys.argv = old
+    assert e.value.code == 0
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])['ready'] is True
+    # something missing / of the wrong shape: named, exit code 1
+    os.remove(tmp_path / '3dpw_test_pseudotheta.pt')
+    np.save(tmp_path / 'base' / 'J_regressor_extra.npy', np.zeros((9, 100), dtype=np.float32))
+    rep = T.readiness_report(T.parse_args(argv))
+    assert not rep['ready'] and rep['missing'] == [str(tmp_path / '3dpw_test_pseudotheta.pt')]
+    assert rep['unreadable'] == [str(tmp_path / 'base' / 'J_regressor_extra.npy')]
+    # nothing on disk at all (this container): every licence-gated default path is listed as missing
+    rep = T.readiness_report(T.parse_args(['--check', '--dataset', 'mpii3d', '--base-data', str(tmp_path / 'nowhere'), '--db-dir', str(tmp_path / 'nowhere')]))
+    assert not rep['ready'] and len(rep['missing']) >= 7 and any('mpii3d_val_scale12_db.pt' in p for p in rep['missing'] if p)
+    # the comparison a real-data run prints
+    assert published_row('repr_wopw_h36m_model', 'h36m') == {'mpjpe_pa': 41.2, 'mpjpe': 61.6, 'accel_err': 12.0}
+    cmp = compare_with_published({'mpjpe': 84.9, 'mpjpe_pa': 52.3, 'accel_err': 11.0, 'mpvpe': 100.0}, 'repr_wpw_3dpw_model', '3dpw')
+    assert abs(cmp['mpjpe']['diff'] - 0.3) < 1e-9 and cmp['mpjpe_pa']['diff'] == 0.0 and cmp['mpvpe']['published'] == 100.3
+    assert compare_with_published({'mpjpe': 1.0}, 'some_other_title', '3dpw') is None

@@ -1,4 +1,5 @@
-"""GPU: bounded randomised parity sweep (the CI form of tests/_fuzz_parity.py): fixed seed, ~40 random (L, H, B, T)
+"""GPU: bounded randomised parity sweep (the CI form of tests/_fuzz_parity.py; runs LAST with what is left of the suite's wall-clock budget, 6 .. 22 s:
+tests/conftest.py): fixed seed, up to 30 random (L, H, B, T)
 models / batches spanning every kernel family and dispatch threshold, HIP path vs the fp64 oracle -- encoder features in
 both modes for every configuration, the full forward for B <= 300 -- plus a handful of H = 1024 cases at the batch sizes
 BASELINE.json's configs use (64) and at the scaled-format thresholds (2048, 4096)."""
@@ -37,7 +38,7 @@ def _check(L, H, B, T, seed, smpl_np, J, full):
     return e1, e2, e3
 
 
-def test_random_configurations_against_fp64_oracle():
+def test_random_configurations_against_fp64_oracle(fuzz_budget_s):
     rng = np.random.RandomState(20261003)
     smpl_np = synth.synthetic_smpl(0)
     J = torch.from_numpy(smpl_np['J_regressor_h36m'])
@@ -53,10 +54,10 @@ def test_random_configurations_against_fp64_oracle():
         e1, e2, e3 = _check(L, H, B, T, seed, smpl_np, J, full=B <= 300)
         assert max(e1, e2) < 2e-5 and e3 < 1e-4, (L, H, B, T, seed, e1, e2, e3)
         worst, n = max(worst, e1, e2, e3), n + 1
-        if time.time() - t0 > 22:                       # bounded: CI budget, the sweep order is deterministic
-            break
-    assert n >= 12, n
-    print('fuzz: %d configurations, worst abs error %.2e, %.0f s' % (n, worst, time.time() - t0))
+        if time.time() - t0 > fuzz_budget_s:            # bounded by what is left of the suite's wall-clock budget (tests/conftest.py: 6 .. 22 s; runs last);
+            break                                       # the sweep order is deterministic: a shorter budget runs a prefix
+    assert n >= 6, n
+    print('fuzz: %d configurations, worst abs error %.2e, %.0f s of a %.0f s budget' % (n, worst, time.time() - t0, fuzz_budget_s))
 
 
 @pytest.mark.parametrize('B,T', [(64, 16), (2048, 2), (37, 6), (128, 4), (640, 3)])

@@ -6,6 +6,10 @@
         --base-data data/base_data --db-dir data/preprocessed_data --vibe-ckpt data/vibe_data/vibe_model_wo_3dpw.pth.tar
     python tools/evaluate_clips.py --db <x_db.pt> --pseudotheta <x_pseudotheta.pt> --base-data data/base_data \
         --ckpt <tepose.pth.tar> --vibe-ckpt <vibe.pth.tar> [--layers 2 --hidden 1024]
+    python tools/evaluate_clips.py --check --cfg configs/repr_wpw_3dpw_model.yaml --dataset 3dpw --base-data data/base_data \
+        --db-dir data/preprocessed_data --vibe-ckpt data/vibe_data/vibe_model_wo_3dpw.pth.tar
+        # real-data readiness, no GPU: which licence-gated files (reference README.md:21-25,37-62) are there, their shapes, what is
+        # missing, and the published row a run on them will be compared with
 
 Real data (`--db` / `--db-dir`): every table comes from the user's files as in the reference -- `J_regressor_h36m.npy`,
 `smpl_mean_params.npz`, `SMPL_NEUTRAL.pkl`, `J_regressor_extra.npy` from `--base-data` (evaluate.py:109,130-135), the
@@ -27,7 +31,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tepose_amd import synth  # noqa: E402
-from tepose_amd.config import EVAL_SEQLEN, eval_db_paths, update_cfg  # noqa: E402
+from tepose_amd.config import EVAL_SEQLEN, compare_with_published, eval_db_paths, published_row, update_cfg  # noqa: E402
 from tepose_amd.data import (load_base_data, load_eval_db, load_generator_state_dict, split_db_into_clips,  # noqa: E402
                              synthetic_eval_db)
 from tepose_amd.distributed import StepCost, imbalance, partition_clips, predicted_scaling  # noqa: E402
@@ -58,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument('--vibe-hidden', type=int, default=None)
     ap.add_argument('--as-rank', type=int, default=-1, help='debug: process the share of this rank of --of-world in ONE process')
     ap.add_argument('--of-world', type=int, default=2)
+    ap.add_argument('--check', action='store_true', help='real-data readiness report (CPU only, one JSON line): found / missing files with their shapes, '
+                    'the published row a run will be compared with; exit code 0 = everything a real-data run needs is there')
     ap.add_argument('--force-dist', action='store_true', help='world size 1: still initialise the process group (nccl = RCCL) and '
                     'run the barrier / all_reduce / gathers, so that the N-GPU collectives execute on a 1-GPU box')
     return ap.parse_args(argv)
@@ -102,6 +108,78 @@ def resolve_plan(args):
     return plan
 
 
+def _describe_file(path, kind):
+    """{'path', 'exists', ...shapes} of one input file, read on the CPU; a file that exists but does not parse says so in 'error'."""
+    d = {'path': str(path) if path else None, 'kind': kind, 'exists': bool(path) and os.path.isfile(str(path))}
+    if not d['exists']:
+        return d
+    d['bytes'] = os.path.getsize(str(path))
+    try:
+        if kind == 'npy':
+            d['shape'] = list(np.load(str(path), mmap_mode='r').shape)
+        elif kind == 'npz':
+            z = np.load(str(path))
+            d['arrays'] = {k: list(z[k].shape) for k in z.files}
+        elif kind == 'smpl_pkl':
+            from tepose_amd.smpl import load_smpl_pkl
+            d['arrays'] = {k: list(np.asarray(v).shape) for k, v in load_smpl_pkl(str(path)).items()}
+        elif kind == 'db':
+            import joblib
+            db = joblib.load(str(path))
+            if isinstance(db, dict):
+                d['arrays'] = {k: list(np.asarray(v).shape) for k, v in db.items()}
+                if 'vid_name' in db:
+                    d['clips'] = int(len(np.unique(np.asarray(db['vid_name']))))
+                    d['frames'] = int(len(db['vid_name']))
+            else:
+                d['shape'] = list(np.asarray(db).shape)
+        elif kind == 'checkpoint':
+            from tepose_amd.data import load_checkpoint
+            ck = load_checkpoint(str(path))
+            sd = ck['gen_state_dict'] if 'gen_state_dict' in ck else ck
+            d['tensors'] = len(sd)
+            d['parameters'] = int(sum(int(np.prod(tuple(v.shape))) for v in sd.values() if hasattr(v, 'shape')))
+            if 'performance' in ck:
+                d['performance'] = float(ck['performance'])
+    except Exception as e:                                         # noqa: BLE001 -- the report names the problem instead of dying on it
+        d['error'] = '%s: %s' % (type(e).__name__, e)
+    return d
+
+
+def readiness_report(args):
+    """What a real-data run of this tool needs (the licence-gated downloads of the reference's README.md:21-25,37-62) against what is on disk.  CPU only."""
+    cfg = update_cfg(args.cfg) if args.cfg and os.path.isfile(args.cfg) else None
+    files = []
+    if args.cfg:
+        files.append({'path': args.cfg, 'kind': 'cfg', 'exists': os.path.isfile(args.cfg), 'title': cfg.TITLE if cfg else None})
+    base = args.base_data or 'data/base_data'
+    files += [_describe_file(os.path.join(base, 'J_regressor_h36m.npy'), 'npy'), _describe_file(os.path.join(base, 'J_regressor_extra.npy'), 'npy'),
+              _describe_file(os.path.join(base, 'smpl_mean_params.npz'), 'npz'), _describe_file(os.path.join(base, 'SMPL_NEUTRAL.pkl'), 'smpl_pkl')]
+    db = pse = None
+    if args.db:
+        db, pse = args.db, args.pseudotheta
+    elif args.dataset == 'h36m' and cfg is None:
+        files.append({'path': None, 'kind': 'db', 'exists': False, 'error': '--dataset h36m needs --cfg: the database name depends on the config TITLE (evaluate.py:149-155)'})
+    else:
+        db, pse = eval_db_paths(cfg if cfg else update_cfg_default(), args.dataset, args.db_dir or 'data/preprocessed_data')
+    if db:
+        files += [_describe_file(db, 'db'), _describe_file(pse, 'db')]
+    ckpt = args.ckpt or (cfg.TRAIN.PRETRAINED if cfg and cfg.TRAIN.PRETRAINED else None)
+    files += [_describe_file(ckpt, 'checkpoint'), _describe_file(args.vibe_ckpt or 'data/vibe_data/vibe_model_wo_3dpw.pth.tar', 'checkpoint')]
+    want = {'J_regressor_h36m.npy': [17, 6890], 'J_regressor_extra.npy': [9, 6890]}
+    for f in files:
+        w = want.get(os.path.basename(str(f.get('path'))))
+        if w and f.get('exists') and f.get('shape') != w:
+            f['error'] = 'shape %s, want %s' % (f.get('shape'), w)
+    missing = [f['path'] for f in files if not f.get('exists')]
+    broken = [f['path'] for f in files if f.get('exists') and f.get('error')]
+    title = cfg.TITLE if cfg else None
+    return {'ready': not missing and not broken, 'dataset': args.dataset, 'cfg_title': title, 'files': files, 'missing': missing, 'unreadable': broken,
+            'published': published_row(title, args.dataset),
+            'note': 'published = the reference\'s own accuracy row for this config / evaluation set (BASELINE.md section 1; asset/wpw.png, asset/wopw.png); a real-data '
+                    'run prints it next to the measured metrics with the differences'}
+
+
 def update_cfg_default():
     from tepose_amd.config import get_cfg_defaults
     return get_cfg_defaults()
@@ -125,6 +203,10 @@ def load_assets(plan):
 
 def main():
     args = parse_args()
+    if args.check:
+        rep = readiness_report(args)
+        print(json.dumps(rep))
+        raise SystemExit(0 if rep['ready'] else 1)
     plan = resolve_plan(args)
     plan['seq'] = args.seq
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the first HIP call (dmabuf IPC only on this pool)
@@ -225,6 +307,9 @@ def main():
                'frames_per_s': frames / float(el.item()), 'metrics_mm': res,
                'data': 'real' if plan['real'] else 'synthetic db + random-init weights (metric values are meaningless)',
                'tables': assets['source'], 'arch': {'layers': plan['layers'], 'hidden': plan['hidden'], 'cfg': plan['cfg_title']}}
+        if plan['real']:
+            # the reference's own accuracy row for this config / evaluation set next to what was measured
+            out['vs_published'] = compare_with_published(res, plan['cfg_title'], args.dataset)
         if use_dist:
             out['dist_backend'] = dist.get_backend()
             out.update(bcast)
