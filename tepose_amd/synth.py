@@ -10,6 +10,7 @@ regenerates bit-identical weights without shipping any blob.
 
 Shapes follow SURVEY.md Appendix B (state-dict keys) and A.4 (SMPL tables).
 """
+import functools
 import math
 from collections import OrderedDict
 
@@ -157,12 +158,19 @@ def regressor_param_shapes():
 
 
 def synthetic_state_dict(n_layers=2, hidden=1024, seed=0, dec_gain=0.35):
-    """Weights at PyTorch-default scale: U(+-1/sqrt(H)) for GRU, U(+-1/sqrt(fan_in))
+    """(A pure function of its arguments: the last few results are memoised -- the published architecture's 64 M values take seconds to
+    hash -- and handed out as fresh copies, so callers may scale or overwrite what they get.)
+    Weights at PyTorch-default scale: U(+-1/sqrt(H)) for GRU, U(+-1/sqrt(fan_in))
     for Linear.  The decoders use `dec_gain`/sqrt(fan_in) instead of the
     reference's xavier gain 0.01 (spin.py:222-224) so the three regressor
     iterations move the pose by a visible amount and exercise rot6d/LBS with
     generic rotations.  Returns OrderedDict[str, np.float32 array] with the
     reference's key names, including the regressor buffers."""
+    return OrderedDict((k, v.copy()) for k, v in _state_dict_cached(int(n_layers), int(hidden), int(seed), float(dec_gain)).items())
+
+
+@functools.lru_cache(maxsize=3)
+def _state_dict_cached(n_layers, hidden, seed, dec_gain):
     sd = OrderedDict()
     H = hidden
     for key, shape in encoder_param_shapes(n_layers, H):

@@ -23,7 +23,8 @@ SHAPES = [(2, 1024, 2304, 3), (1, 320, 2050, 2), (2, 192, 2100, 3), (3, 512, 204
 def test_kernel_families_against_the_default_and_the_fp64_oracle(monkeypatch, knobs):
     from tepose_amd import _lib
     errs0 = int(_lib.load().tepose_debug_kernel_errors())            # process-wide counter (tests/test_gpu_status.py forces give-ups on purpose)
-    for L, H, B, T in SHAPES:
+    # (the two-accumulator family is the mid-batch default and has its own tests there: four of the six shapes are enough to pin it at large batches)
+    for L, H, B, T in (SHAPES if 'TEPOSE_GRU_STATE' in knobs else SHAPES[:3] + SHAPES[5:]):
         smpl_np = synth.synthetic_smpl(0)
         state = synth.synthetic_state_dict(L, H, 11)
         base, _, _ = build_model(L, H, seed=11, device='cuda', smpl_np=smpl_np, state=state)
