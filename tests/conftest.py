@@ -15,6 +15,16 @@ def pytest_configure(config):
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _cpu_threads():
+    """The fp64 oracle runs on the host: on the GPU boxes torch's intra-op pool defaults to one thread per core of a host whose CPU quota is far below its
+    core count, and the oversubscribed pool gets throttled (profiles/r05_eval_stalls.txt: 40 - 90 ms stalls).  A bounded pool is faster and steadier."""
+    import torch
+    n = int(os.environ.get('TEPOSE_TEST_CPU_THREADS', '16'))
+    torch.set_num_threads(max(1, min(n, os.cpu_count() or 1)))
+    yield
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
