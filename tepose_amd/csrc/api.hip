@@ -402,7 +402,7 @@ struct EncWs {
 inline size_t sync_words(const tepose_model* m) { return (size_t)m->L * 96 + 32 + 96 + 32; }
 // floats of the granule buffers: [3 directions][2 buffers][16 rows][Hp] uint64, only where the persistent kernel can run
 inline size_t seq_gran_words(const tepose_model* m, int B) {
-  return (m->split && B <= gru_seq_gran_rows(m->opt) && m->Hp % 256 == 0 && m->Hp <= 1024) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
+  return (m->split && B <= gru_seq_gran_rows(m->opt) && gru_seq_shape_ok(m->Hp)) ? (size_t)3 * 2 * kSeqGranRows * m->Hp * 2 : 0;
 }
 inline size_t sync_zero_bytes(const tepose_model* m, int B) {      // counters + granules: the block a forward clears
   return align_up(sync_words(m) * sizeof(unsigned), 256) + seq_gran_words(m, B) * sizeof(float);
@@ -634,7 +634,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   const int L = m->L;
   const long BT = (long)B * T;
   std::string s = "input=";
-  s += !k.h3 ? "pad_input_kernel" : (BT <= m->opt.split_few_max_rows && !k.g0blk) ? "split_rows_few_kernel" : "split_rows_kernel";
+  s += !k.h3 ? "pad_input_kernel" : split_rows_few_ok(BT, kInputP, k.g0blk ? T : 0, m->opt) ? "split_rows_few_kernel" : "split_rows_kernel";
   s += ";projection=";
   s += !k.h3 ? (BT <= m->opt.skinny_max_m ? "skinny_gemm_kernel" : "gemm_f32_kernel")
        : k.g0big ? "gemm_h3s_persist16c_kernel<0>" : k.g0mid ? "gemm_h3s_kernel<1, 3, 4, 3, 4>" : k.g0skinny ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel";
@@ -643,10 +643,10 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   s += ";gru_step=";
   s += !k.h3 ? (B <= m->opt.skinny_max_m ? "skinny_gru_kernel" : "gru_step_kernel")
        : k.scaled ? (k.planes_state && k.g0blk ? "gru_step16_kernel<true>" : "gru_step16_kernel<false>")
-       : seq_l0 ? (B <= gru_seq_gran_rows(m->opt) && m->Hp % 256 == 0 && m->Hp <= 1024 ? "gru_seq_kernel(granules)" : "gru_seq_kernel")
+       : seq_l0 ? (B <= gru_seq_gran_rows(m->opt) && gru_seq_shape_ok(m->Hp) ? "gru_seq_kernel(granules)" : "gru_seq_kernel")
        : k.step_skinny ? "skinny_gru_h3_kernel" : "gemm_h3_kernel<GRU>";
   s += ";gru_first=";
-  s += !k.h3 ? "gru_step_kernel" : (seq_l0 ? "(in gru_seq_kernel)" : (k.scaled && m->Hp % 128 == 0 ? "gru_first16_kernel" : "gru_first_kernel"));
+  s += !k.h3 ? "gru_step_kernel" : (seq_l0 ? "(in gru_seq_kernel)" : (k.scaled && gru_first16_shape_ok(m->Hp) ? "gru_first16_kernel" : "gru_first_kernel"));
   if (L >= 2) {
     s += ";projection_l1=";
     s += !k.h3 ? "gemm_f32_kernel" : k.scaled ? "gemm_h3s_persist16c_kernel<1>" : (BT <= m->opt.l1_skinny_max_rows ? "skinny_gemm_h3_kernel" : "gemm_h3_kernel");
@@ -657,7 +657,7 @@ std::string describe_plan(const tepose_model* m, int B, int T) {
   s += !k.reg_split ? "gemm_f32_kernel x (2 + 1 + 9)" : (m->tail_collapsed || !m->enc_packed) && m->collapse_env ? "collapsed: one product (skinny_gemm_h3_kernel / gemm_h3_kernel)"
        : k.reg_seq ? "reg_seq_kernel" : "gemm_h3_kernel loop";
   s += ";smpl=";
-  s += B <= 4 ? "smpl_small_kernel" : k.blend16 ? "smpl_prep_kernel+gemm_h3s_persist16c_kernel<1>+smpl_skin4_kernel" : k.reg_split ? "smpl_prep_kernel+gemm_h3_kernel+smpl_skin4_kernel"
+  s += (smpl_small_rows_ok(B, m->opt) && (m->lbs_sparse || !m->smpl_packed)) ? "smpl_small_kernel" : k.blend16 ? "smpl_prep_kernel+gemm_h3s_persist16c_kernel<1>+smpl_skin4_kernel" : k.reg_split ? "smpl_prep_kernel+gemm_h3_kernel+smpl_skin4_kernel"
        : "smpl_prep_kernel+gemm_f32_kernel+smpl_skin4_kernel";
   return s;
 }

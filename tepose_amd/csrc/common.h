@@ -60,6 +60,12 @@ struct Options {
   int g0_skinny_max_m = 128;         // TEPOSE_G0_SKINNY_MAX_M: rows up to which the layer-0 projection runs on the width-first kernel
   unsigned long long seq_stamp_ptr = 0;   // TEPOSE_SEQ_STAMP_PTR: device buffer for the per-step time stamps of a -DTEPOSE_SEQ_STAMPS build (tools/seq_stamps.py)
 };
+// Shape predicates shared by the launchers and by api.hip's describe_plan (tepose_select_kernels), so that the description cannot drift from what
+// launches: which input-split kernel, which first-step kernel, granule hand-off, the one-launch SMPL form (the last two additionally need
+// what only a packed handle / a launch knows: operand alignment, <= 4 skin weights per vertex).
+inline bool split_rows_few_ok(long rows, int Kp, int permT, const Options& o) { return rows <= o.split_few_max_rows && Kp <= 4096 && !permT; }
+inline bool gru_first16_shape_ok(int Hp) { return Hp % 128 == 0; }
+inline bool gru_seq_shape_ok(int Hp) { return Hp % 256 == 0 && Hp <= 1024; }
 Options options_from_env();          // gemm.hip
 int* option_field(Options& o, const char* name);   // "SKINNY_MAX_M" (or "TEPOSE_SKINNY_MAX_M") -> &o.skinny_max_m; nullptr: no such option
 
@@ -158,6 +164,7 @@ hipError_t launch_smpl_prep_pose(const SmplConsts& c, int mode, const float* pos
                                  const float* betas, int betas_ld, int N, float* pf, float* Amat, float* posed,
                                  hipStream_t s, void* pf_hi = nullptr, void* pf_lo = nullptr, long pf_kst = 0);
 // measurement only: blend shapes + skinning as one wave per person
+bool smpl_small_rows_ok(int N, const Options& o);        // the person-count half of smpl_small_ok (describe_plan: a handle whose tables are not packed yet)
 bool smpl_small_ok(const SmplConsts& c, int N, const Options& o);
 hipError_t launch_smpl_small(const SmplConsts& c, int mode, const float* pose, int pose_ld, const float* betas, int betas_ld,
                              const float* cam, int cam_ld, int N, float* Amat, float* posed, float* rotmat, float* theta,

@@ -258,7 +258,7 @@ hipError_t launch_split_rows(const float* src, long ld, long rows, int K, int Kp
   if (permT && rows % permT != 0) return hipErrorInvalidValue;
   if (zero_bytes % 16 != 0) return hipErrorInvalidValue;
   if (Kp > 64 * 2 * 17 || Kp > kRowsLd || (Kp & 31)) return hipErrorInvalidValue;        // the [., 2144] input rows
-  if (rows <= o.split_few_max_rows && Kp <= 4096 && !permT) {      // (the frame-major permutation lives in the 8-rows-per-block kernel: whatever the threshold says)
+  if (split_rows_few_ok(rows, Kp, permT, o)) {      // (the frame-major permutation lives in the 8-rows-per-block kernel: whatever the threshold says)
     if (fmt16)
       hipLaunchKernelGGL((split_rows_few_kernel<true>), dim3((unsigned)rows), dim3(256), 0, s, src, ld, rows, K, Kp, R,
                          (_Float16*)hi, (_Float16*)lo, row_scale, (uint4*)zero, (long)(zero_bytes / 16), pr);
@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(256) gru_first16_kernel(GateBatch gb, int M, i
 
 hipError_t launch_gru_first(const GateBatch& gb, int ndir, int M, int Hp, hipStream_t s, int scaled16) {
   if (M <= 0 || ndir <= 0) return hipSuccess;
-  if (scaled16 && Hp % 128 == 0) {
+  if (scaled16 && gru_first16_shape_ok(Hp)) {
     bool vec = true;
     for (int i = 0; i < ndir; ++i) {
       const GateDir& d = gb.d[i];

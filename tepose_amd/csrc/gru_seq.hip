@@ -504,7 +504,7 @@ static int device_cus(const Options& o) {
 bool gru_seq_ok(int ndir, int M, int Hp, int T, const Options& o) {
   const int cus = device_cus(o);
   const int max_m = o.seq_max_m > 64 ? 64 : o.seq_max_m;
-  return M >= 1 && M <= max_m && T >= 2 && T <= kSeqMaxT && Hp % 256 == 0 && Hp <= 1024 && ndir >= 1 &&
+  return M >= 1 && M <= max_m && T >= 2 && T <= kSeqMaxT && gru_seq_shape_ok(Hp) && ndir >= 1 &&
          ndir <= 3 && ndir * (Hp / 16) <= cus;
 }
 

@@ -569,10 +569,11 @@ __global__ void __launch_bounds__(256) smpl_small_kernel(SmplConsts c, int maxde
   }
 }
 
-bool smpl_small_ok(const SmplConsts& c, int N, const Options& o) {
+bool smpl_small_rows_ok(int N, const Options& o) {
   const int max_n = o.smpl_small_max_n < 0 ? 0 : (o.smpl_small_max_n > kSmallN ? kSmallN : o.smpl_small_max_n);
-  return c.lbs_sparse && N >= 1 && N <= max_n && 256 / kSmallVB >= N;
+  return N >= 1 && N <= max_n && 256 / kSmallVB >= N;
 }
+bool smpl_small_ok(const SmplConsts& c, int N, const Options& o) { return c.lbs_sparse && smpl_small_rows_ok(N, o); }
 
 // in: PrepIn-style source (mode 0: regressor state rows xs; 1: axis-angle; 2: rotation matrices)
 hipError_t launch_smpl_small(const SmplConsts& c, int mode, const float* pose, int pose_ld, const float* betas, int betas_ld,
