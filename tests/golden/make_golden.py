@@ -10,7 +10,7 @@ Two kinds of fixture:
 * model / function vectors: the reference's `lib.models.tepose.TePose`, `lib.models.spin.Regressor`,
   `lib.models.vibe.VIBE`, `lib.utils.geometry.*`, `lib.utils.eval_utils.*`, `lib.utils.smooth_pose.smooth_pose`
   imported from /root/reference and called on deterministic synthetic weights (tepose_amd.synth);
-* FLOW vectors (evaluation, autoregressive driver, trainer validation loop, metrics, slerp filter): the reference's
+* FLOW vectors (evaluation, autoregressive driver, demo live path, trainer validation loop, metrics, slerp filter): the reference's
   own STATEMENTS.  `evaluate.py` is parsed with `ast`; its top level (imports, helper defs) is executed as a module
   namespace and the body of its `if __name__ == "__main__":` block is compiled and executed in line-range slices
   (`RefScript.run`) in that namespace, after this generator has put the script's external inputs there (`parse_args`,
@@ -234,13 +234,17 @@ class _Probes(ast.NodeTransformer):
 
 
 class RefScript(object):
-    """A reference script as AST: top level (imports, defs) -> a module namespace; the `__main__` body in slices."""
+    """A reference script as AST: top level (imports, defs) -> a module namespace; the `__main__` body (or a function's body) in slices."""
 
-    def __init__(self, relpath):
+    def __init__(self, relpath, function=None):
+        """function=None: the statements of the `if __name__ == "__main__":` block; function='main': the body of that top-level def (demo.py)."""
         self.path = os.path.join(REF, relpath)
         tree = ast.parse(open(self.path).read(), self.path)
         self.top = [n for n in tree.body if not _is_main_guard(n)]
-        self.main = [n for n in tree.body if _is_main_guard(n)][0].body
+        if function is None:
+            self.main = [n for n in tree.body if _is_main_guard(n)][0].body
+        else:
+            self.main = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == function][0].body
 
     def namespace(self):
         ns = {'__name__': 'reference_script', '__file__': self.path}
@@ -478,6 +482,27 @@ def driver_case(EV, T_mod, name, L, H, N, T, seed_w, seed_x):
     print('wrote', name, len(calls))
 
 
+def demo_case(DM, T_mod, name, L, H, N, T, seed_w, seed_x):
+    """The live path of demo.py for one tracked person (BASELINE config 5): the `with torch.no_grad():` block of `main` (demo.py:209-262) executed from the
+    file -- VIBE over the tracklet's features, its first seq_len - 1 predictions as the theta history, then the sliding window of seq_len frames with theta
+    feedback (no J_regressor: 49 joints) -- in a namespace that holds what the lines above it would have left there: `dataloader` (one batch [1, N, 2048] of
+    pre-extracted features, demo.py:200-208), `has_keypoints`, `device`, the two models (the reference's classes at the case's size; demo.py:104-155 hard-codes
+    2 x 1024 and checkpoint paths), `seq_len`, `num_frames`."""
+    import lib.models.vibe as V_mod
+    model = load_synth(T_mod.TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='').eval(), synth.synthetic_state_dict(L, H, seed_w))
+    model_vibe = load_synth(V_mod.VIBE(seqlen=N, n_layers=L, hidden_size=H, add_linear=True, bidirectional=False, use_residual=True,
+                                       pretrained='').eval(), synth.synthetic_vibe_state_dict(L, H, seed_w + 1))
+    feats = torch.from_numpy(synth.synthetic_windows(1, N, seed_x)[:, :, :2048].copy())
+    ns = {'torch': torch, 'dataloader': [feats], 'has_keypoints': False, 'device': torch.device('cpu'), 'model': model, 'model_vibe': model_vibe,
+          'seq_len': T, 'num_frames': N}
+    DM.run(ns, 209, 262)
+    theta = torch.cat([ns['pred_cam'], ns['pred_pose'], ns['pred_betas']], dim=1)
+    assert theta.shape == (N, 85) and ns['pred_joints3d'].shape == (N, 49, 3) and ns['smpl_joints2d'].shape == (N, 49, 2)
+    save(name, meta=np.array([L, H, N, T, seed_w, seed_x], dtype=np.int64), theta=theta.numpy(), kp_3d=ns['pred_joints3d'].numpy(),
+         kp_2d=ns['smpl_joints2d'].numpy(), verts_sub=ns['pred_verts'].numpy()[:, ::53])
+    print('wrote', name, theta.shape)
+
+
 def padded_case(T_mod, name, L, H, lens, T, seed_w, seed_x):
     """The batched whole-clip validation loop: the reference's unbound `Trainer.validate` and `Trainer.evaluate`
     (lib/core/trainer.py:294-360, 437-503) called on a namespace object that carries what they read -- the reference
@@ -686,6 +711,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     EV = RefScript('evaluate.py')
+    DM = RefScript('demo.py', function='main')
     if not argv or 'eval' in argv or 'flows' in argv:
         # BASELINE config 4's three evaluation sets (evaluate.py:394-457 branches)
         eval_case(EV, T_mod, 'eval_mpii3d_L1H64_T5', 'mpii3d', 1, 64, 5, [13, 9, 8, 11, 12, 4, 10], 21, 31)
@@ -696,6 +722,8 @@ def main():
         driver_case(EV, T_mod, 'driver_L2H128_N40T6', 2, 128, 40, 6, 6, 555)
         driver_case(EV, T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
         padded_case(T_mod, 'padded_L2H128_T5', 2, 128, [23, 9, 17, 5], 5, 14, 700)
+        demo_case(DM, T_mod, 'demo_L2H128_N24T6', 2, 128, 24, 6, 16, 811)
+        demo_case(DM, T_mod, 'demo_L1H64_N9T8', 1, 64, 9, 8, 17, 812)
         metrics_case(EV)
         filter_cases(EV)
     if argv:

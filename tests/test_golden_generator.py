@@ -29,7 +29,7 @@ def _code_lines(path):
     return out
 
 
-@pytest.mark.parametrize('ref', ['evaluate.py', 'lib/core/trainer.py', 'lib/core/tester.py', 'lib/utils/smooth_pose.py',
+@pytest.mark.parametrize('ref', ['evaluate.py', 'demo.py', 'lib/core/trainer.py', 'lib/core/tester.py', 'lib/utils/smooth_pose.py',
                                  'lib/utils/eval_utils.py'])
 def test_generator_holds_no_run_of_reference_lines(ref):
     g, r = _code_lines(GEN), _code_lines(os.path.join(REF, ref))
@@ -47,7 +47,7 @@ def test_flow_fixtures_regenerate_bit_identically(tmp_path):
     p = subprocess.run([sys.executable, GEN, '--out', str(tmp_path), 'flows'], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     made = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.npz'))
-    assert len(made) == 9 and sum(f.startswith('eval_') for f in made) == 4, made
+    assert len(made) == 11 and sum(f.startswith('eval_') for f in made) == 4 and sum(f.startswith('demo_') for f in made) == 2, made
     for f in made:
         a, b = np.load(os.path.join(str(tmp_path), f)), np.load(os.path.join(ROOT, 'tests', 'golden', f))
         assert sorted(a.files) == sorted(b.files), f

@@ -171,3 +171,40 @@ def test_the_session_owns_its_workspace_and_survives_other_callers_on_the_model(
             assert torch.equal(ra[k], ref_a[k][j].cpu()), (k, j)
             assert torch.equal(rb[k], ref_b[k][j].cpu()), (k, j)
     assert sa._captured_for[0] == eng.packed_generation        # both graphs were re-captured against the re-packed blob
+
+
+@pytest.mark.parametrize('name', ['demo_L2H128_N24T6', 'demo_L1H64_N9T8'])
+def test_the_demo_flow_of_the_reference_on_the_device(name, smpl_np):
+    """BASELINE config 5 end to end as demo.py:209-262 runs it (the fixture is that block of the reference's file, executed): VIBE bootstrap over the
+    tracklet -> first seq_len - 1 predictions = theta history -> sliding window with theta feedback, no J_regressor (49 joints), kp_2d.  Here: the drop-in
+    VIBE, then the clip driver AND the frame-at-a-time StreamSession, every output of every frame within 1e-4 of the reference's."""
+    from tepose_amd.driver import run_clips
+    from tepose_amd.testing import build_model
+    from test_gpu_vibe import _build as build_vibe
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    L, H, N, T, seed_w, seed_x = [int(v) for v in g['meta']]
+    feats = torch.from_numpy(synth.synthetic_windows(1, N, seed_x)[:, :, :2048].copy())
+    vibe, _ = build_vibe(L, H, seed_w + 1, smpl_np)
+    with torch.no_grad():
+        boot = vibe(feats.cuda())[-1]                                           # demo.py:229: model_vibe(batch)[-1], J_regressor = None
+    for k, tol in (('theta', 1e-4), ('kp_3d', 1e-4), ('kp_2d', 1e-4)):
+        got = boot[k].reshape(N, -1, g[k].shape[-1])[:T - 1].cpu().numpy() if k != 'theta' else boot[k].reshape(N, 85)[:T - 1].cpu().numpy()
+        ref = g[k][:T - 1]
+        if k == 'theta':                                                        # axis-angle near pi is compared through the outputs it produces
+            assert np.abs(got[:, :3] - ref[:, :3]).max() < tol and np.abs(got[:, 75:] - ref[:, 75:]).max() < tol
+        else:
+            assert np.abs(got - ref).max() < tol, k
+    assert np.abs(boot['verts'].reshape(N, 6890, 3)[:T - 1, ::53].cpu().numpy() - g['verts_sub'][:T - 1]).max() < 1e-4
+    theta_init = boot['theta'].reshape(N, 85)[:T - 1].detach().clone()
+    model, _, _ = build_model(L, H, seed=seed_w, device='cuda', smpl_np=smpl_np, seqlen=T)
+    ref = run_clips(model, [feats[0].cuda()], [theta_init], T, keep=('theta', 'kp_3d', 'kp_2d', 'verts'))[0]
+    for k in ('kp_3d', 'kp_2d'):
+        assert np.abs(ref[k].cpu().numpy() - g[k][T - 1:]).max() < 1e-4, k
+    assert np.abs(ref['verts'].cpu().numpy()[:, ::53] - g['verts_sub'][T - 1:]).max() < 1e-4
+    th = ref['theta'].cpu().numpy()
+    assert np.abs(th[:, :3] - g['theta'][T - 1:, :3]).max() < 1e-4 and np.abs(th[:, 75:] - g['theta'][T - 1:, 75:]).max() < 1e-4
+    # frame at a time, as a live demo receives them: the same bits as the clip driver
+    w = np.concatenate([feats[0].numpy(), np.zeros((N, 85), np.float32)], axis=1)
+    got, ses = _stream_clip(model, w, theta_init.cpu().numpy(), T, None, keep=('theta', 'kp_3d', 'verts'))
+    for k in ('theta', 'kp_3d', 'verts'):
+        assert torch.equal(got[k], ref[k].cpu()), k

@@ -294,3 +294,21 @@ def test_oracle_padded_validation_batch_matches_reference_golden(smpl_np):
     assert np.abs(theta[:, 75:] - g['pred_theta'][:, 75:]).max() < 5e-5
     for c, n in enumerate(lens):
         assert np.abs(per[c]['kp_3d'].numpy() - g['pred_j3d_tsr'][c, T - 1:n]).max() < 5e-5
+
+
+@pytest.mark.parametrize('name', ['demo_L2H128_N24T6', 'demo_L1H64_N9T8'])
+def test_oracle_demo_flow_matches_reference_golden(name, smpl_np):
+    """BASELINE config 5's caller: demo.py:209-262 (its own statements, executed from the file by tests/golden/make_golden.py::demo_case) -- VIBE over the
+    tracklet, its first seq_len - 1 thetas as the history, then the sliding window with theta feedback, 49 joints, kp_2d."""
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    L, H, N, T, seed_w, seed_x = [int(v) for v in g['meta']]
+    feats = synth.synthetic_windows(1, N, seed_x)[:, :, :2048].copy()
+    boot = O.vibe_fwd(synth.synthetic_vibe_state_dict(L, H, seed_w + 1), smpl_np, feats, L)
+    for k in ('theta', 'kp_3d', 'kp_2d'):
+        assert (boot[k][:T - 1] - torch.from_numpy(g[k][:T - 1])).abs().max() < 2e-6, k
+    assert (boot['verts'][:T - 1, ::53] - torch.from_numpy(g['verts_sub'][:T - 1])).abs().max() < 2e-6
+    out = O.run_clip(synth.synthetic_state_dict(L, H, seed_w), smpl_np, feats[0], boot['theta'][:T - 1].numpy(), T, L)
+    assert out['theta'].shape[0] == N - T + 1
+    assert (out['theta'] - torch.from_numpy(g['theta'][T - 1:])).abs().max() < 2e-6
+    assert (out['kp_3d'] - torch.from_numpy(g['kp_3d'][T - 1:])).abs().max() < 2e-6
+    assert (out['verts'][:, ::53] - torch.from_numpy(g['verts_sub'][T - 1:])).abs().max() < 2e-6
