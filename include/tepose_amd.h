@@ -295,6 +295,9 @@ int tepose_smpl_verts_from_theta(const tepose_model* m, const float* theta, int 
  * verts[N,6890,3]; joints49[N,49,3] (may be NULL).  Needs tepose_pack_smpl only.          */
 int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, const float* betas, int N,
                     float* verts, float* joints49, void* workspace, size_t ws_bytes, void* stream);
+/* kp_3d[N,14,3] = (J_regressor_h36m verts[N,6890,3])[H36M_TO_J14]: the joints of given meshes as evaluate.py:289-291 regresses them in its
+ * --filter branch (slerp-smoothed rotations -> SMPL -> vertices -> these joints).  jreg_packed from tepose_pack_jreg; needs tepose_pack_smpl only. */
+int tepose_joints_from_verts(const tepose_model* m, const void* jreg_packed, const float* verts, int N, float* kp_3d, void* stream);
 /* MEASUREMENT ONLY (tools/smpl_per_person_bench.py): the same vertices as tepose_smpl_fwd(pose2rot=1)
  * with blend shapes + skinning done by one wavefront per person (BASELINE.json's sketch of the SMPL stage) instead of a
  * GEMM over 128-person tiles + a skinning kernel.  Never called by the product path.                                   */

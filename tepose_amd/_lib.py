@@ -20,7 +20,7 @@ SYMBOLS = [
     'tepose_pack_vibe_encoder', 'tepose_vibe_workspace_bytes', 'tepose_vibe_encoder_fwd',
     'tepose_metrics_joints', 'tepose_smpl_verts_from_theta', 'tepose_metrics_verts', 'tepose_smpl_fwd', 'tepose_filter_one_euro', 'tepose_filter_slerp', 'tepose_project_frames', 'tepose_project_frame_pair', 'tepose_window_step', 'tepose_forward_cached', 'tepose_profile_read_gru', 'tepose_profile_read_l1proj', 'tepose_gemm_h3_workspace_bytes', 'tepose_gemm_h3_f32',
     'tepose_regressor_fwd_init', 'tepose_rotmat_to_angle_axis', 'tepose_rot6d_to_rotmat',
-    'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person',
+    'tepose_project_frames_workspace_bytes', 'tepose_smpl_fwd_per_person', 'tepose_joints_from_verts',
     'tepose_status', 'tepose_forward_status', 'tepose_status_peek', 'tepose_fault_code', 'tepose_set_persistent', 'tepose_uses_persistent', 'tepose_build_info',
     'tepose_fp32_ranges', 'tepose_derive_planes', 'tepose_kernel_info', 'tepose_select_kernels', 'tepose_set_option', 'tepose_get_option', 'tepose_debug_set_test_fault', 'tepose_debug_kernel_errors',
 ]
@@ -123,6 +123,7 @@ def load():
     lib.tepose_fault_code.argtypes = [c_void_p]
     lib.tepose_set_persistent.argtypes = [c_void_p, c_int]
     lib.tepose_uses_persistent.argtypes = [c_void_p, c_int, c_int]
+    lib.tepose_joints_from_verts.argtypes = [c_void_p, fp, fp, c_int, fp, c_void_p]
     lib.tepose_profile_enable.argtypes = [c_void_p, c_int]
     lib.tepose_profile_read.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]
     lib.tepose_profile_read_gru.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int), POINTER(c_double)]

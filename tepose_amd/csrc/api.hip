@@ -2291,6 +2291,17 @@ int tepose_smpl_fwd(const tepose_model* m, int pose2rot, const float* pose, cons
   return 0;
 }
 
+// evaluate.py:289-291 (the --filter branch): the H36M regressor applied to given vertices, 14 LSP joints per person
+int tepose_joints_from_verts(const tepose_model* m, const void* jreg_packed, const float* verts, int N, float* kp_3d, void* stream) {
+  if (!m || !jreg_packed || !verts || !kp_3d || N < 1) return TEPOSE_E_ARG;
+  if (!m->smpl_packed) return TEPOSE_E_STATE;
+  SmplConsts sc = smpl_consts(m);
+  const int* p = (const int*)jreg_packed;
+  JregPacked jr{p, p + 32, (const float*)(p + 32 + 17 * kNV)};
+  CK(launch_smpl_joints(sc, &jr, verts, nullptr, nullptr, N, kp_3d, nullptr, (hipStream_t)stream));
+  return 0;
+}
+
 int tepose_smpl_fwd_per_person(const tepose_model* m, const float* pose, const float* betas, int N, float* verts,
                                void* workspace, size_t ws_bytes, void* stream) {
   if (!m || !pose || !betas || !verts || !workspace || N < 1) return TEPOSE_E_ARG;

@@ -430,6 +430,14 @@ class Engine:
                                             self._stream()), 'tepose_smpl_fwd')
         return verts, joints
 
+    def joints_from_verts(self, verts, J_regressor):
+        """verts [N,6890,3] (device) -> the 14 LSP joints of the H36M regressor [N,14,3] (evaluate.py:289-291)."""
+        N, dev = verts.shape[0], verts.device
+        _, jp = self.jreg(J_regressor, dev)
+        out = torch.empty((N, 14, 3), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.tepose_joints_from_verts(self.handle, jp, verts.data_ptr(), N, out.data_ptr(), self._stream()), 'tepose_joints_from_verts')
+        return out
+
     # ------------------------------------------------------------------ cached layer-0 projections
     @property
     def gate_width(self):

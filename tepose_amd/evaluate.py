@@ -65,8 +65,11 @@ def clip_metric_record(model, clip_id, clip, pred_j3d, pred_verts, dataset='3dpw
 
 
 @torch.no_grad()
-def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='3dpw', rank=0, world=1, step_ms=None):
+def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='3dpw', rank=0, world=1, step_ms=None, avg_filter=False):
     """clips: OrderedDict name -> dict(features[N,2048], joints3D[N,J,3], theta_pseu[N,85], pose, shape).
+    avg_filter: evaluate.py --filter (lines 273-291): per clip, the predicted rotations (bootstrap frames + window predictions) are slerp-smoothed
+    (smooth_pose_mat, ratio 0.3), SMPL re-posed with the predicted betas, and the evaluated joints are the H36M regressor's 14 joints of THAT mesh; MPVPE
+    keeps the unfiltered vertices, as the reference does (line 299).  Needs a J_regressor (the reference's branch indexes it: no mpii3d).
     Returns ([n_local_clips, 8] float64 record tensor, list of local clip indices)."""
     dev = next(model.parameters()).device
     T = int(seqlen)
@@ -80,12 +83,21 @@ def evaluate_clips(model, model_vibe, clips, seqlen, J_regressor=None, dataset='
     feats = [_to_device(clips[names[i]]['features'], dev) for i in mine]
     inits = [_to_device(clips[names[i]]['theta_pseu'], dev, T - 1) for i in mine]
     # bootstrap: VIBE over the first T frames of every clip, keep frames 0..T-2 (evaluate.py:233-245)
+    if avg_filter and J_regressor is None:
+        raise ValueError('avg_filter regresses the joints of the re-posed mesh with J_regressor (evaluate.py:289-291): give one')
     boot = model_vibe(torch.stack([f[:T] for f in feats]), J_regressor=J_regressor)[-1]
-    seq = run_clips(model, feats, inits, T, J_regressor=J_regressor, keep=('kp_3d', 'verts'))
+    seq = run_clips(model, feats, inits, T, J_regressor=J_regressor, keep=('kp_3d', 'verts', 'rotmat', 'theta') if avg_filter else ('kp_3d', 'verts'))
     recs = []
     for s, i in enumerate(mine):
         pred_j3d = torch.cat([boot['kp_3d'][s, :T - 1], seq[s]['kp_3d']], dim=0)
         pred_verts = torch.cat([boot['verts'][s, :T - 1], seq[s]['verts']], dim=0)
+        if avg_filter:                                                     # evaluate.py:273-291
+            from .filters import smooth_pose_mat
+            rot = torch.cat([boot['rotmat'][s, :T - 1].reshape(-1, 24, 3, 3), seq[s]['rotmat'].reshape(-1, 24, 3, 3)], dim=0).contiguous()
+            betas = torch.cat([boot['theta'][s, :T - 1, 75:], seq[s]['theta'][:, 75:]], dim=0).contiguous()
+            rot = smooth_pose_mat(rot, ratio=0.3)
+            mesh = model.regressor.smpl(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, 0:1], pose2rot=False).vertices
+            pred_j3d = model._engine.joints_from_verts(mesh.contiguous(), J_regressor)
         rec = clip_metric_record(model, i, clips[names[i]], pred_j3d, pred_verts, dataset)
         if rec is not None:
             recs.append(rec)

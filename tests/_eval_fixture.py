@@ -10,7 +10,9 @@ from tepose_amd.data import split_db_into_clips, synthetic_eval_db
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 CASES = {'eval_mpii3d_L1H64_T5': 'mpii3d', 'eval_h36m_L1H64_T5': 'h36m', 'eval_h36m14_L1H64_T4': 'h36m',
-         'eval_3dpw_L2H64_T6': '3dpw'}
+         'eval_3dpw_L2H64_T6': '3dpw',
+         # evaluate.py --filter (lines 273-291): the evaluated joints are those of the mesh re-posed with slerp-smoothed rotations
+         'eval_3dpw_filter_L2H64_T6': '3dpw', 'eval_h36m14_filter_L1H64_T4': 'h36m'}
 
 
 def load(name):
@@ -31,6 +33,7 @@ def load(name):
         per_clip[ci] = {k: g['clip%d_%s' % (ci, k)] for k in
                         ('raw_pred', 'mpjpe_all', 'pa_all', 'accel_all', 'pose_map', 'accel_map', 'has_accel', 'mpvpe')}
     return {'L': L, 'H': H, 'T': T, 'seed_w': seed_w, 'dataset': dataset, 'clips': clips, 'final': final,
+            'avg_filter': bool(int(g['avg_filter'])) if 'avg_filter' in g.files else False,
             'per_clip': per_clip, 'tot_num_pose': int(g['tot_num_pose']), 'joints': joints}
 
 

@@ -373,7 +373,7 @@ def eval_valid_i(name, lens):
     return out
 
 
-def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='repr_wpw_3dpw_model'):
+def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='repr_wpw_3dpw_model', avg_filter=False):
     """evaluate.py's `__main__` body on a synthetic database.  Executed from the file: lines 64-86 (options), 109-137
     (J_regressor, TePose from cfg + checkpoint file, SMPL swap), 141-166 (data paths), 168-462 (keyed clips, VIBE
     bootstrap, window loop, conversion / valid_i / pelvis / metrics, means).  NOT executed: 88-107 (a hard-coded 2 x 1024
@@ -387,7 +387,9 @@ def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='rep
     torch.save({'performance': 0.0, 'gen_state_dict': proto.state_dict()}, ckpt)
     cfg = CN(DEVICE='cpu', TITLE=title, MODEL=CN(TGRU=CN(NUM_LAYERS=L, HIDDEN_SIZE=H)), DATASET=CN(SEQLEN=T),
              TRAIN=CN(BATCH_SIZE=32, PRETRAINED=ckpt, PRETRAINED_REGRESSOR=''))
-    args = types.SimpleNamespace(dataset=dataset, seq='', render=False, render_plain=False, frame=0, plot=False, filter=False)
+    args = types.SimpleNamespace(dataset=dataset, seq='', render=False, render_plain=False, frame=0, plot=False, filter=bool(avg_filter))
+    if avg_filter:
+        _numpy1_for_transformations()
     n = len(db['vid_name'])
     db = dict(db, img_name=np.array(['frame_%06d.jpg' % i for i in range(n)]), bbox=np.zeros((n, 4), dtype=np.float32))
     ns = EV.namespace()
@@ -410,8 +412,8 @@ def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='rep
         def at(line):
             def f(ns):
                 ci = _Pbar.last.i
-                if line == 294:                                 # pred_j3ds = np.vstack(pred_j3ds): raw predictions, bootstrap rows first
-                    cur.clear()
+                if line in (291, 294):                          # 294: pred_j3ds = np.vstack(pred_j3ds), raw predictions, bootstrap rows first; 291: the --filter
+                    cur.clear()                                 # branch's joints of the re-posed mesh instead (only one of the two lines runs)
                     cur['raw_pred'] = np.array(ns['pred_j3ds'], dtype=np.float32, copy=True)
                 elif line == 418:                               # valid_map as the pose metrics use it
                     cur['pose_map'] = np.array(ns['valid_map'], dtype=np.int64, copy=True)
@@ -432,14 +434,14 @@ def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='rep
                     rec[ci] = dict(cur)
             return f
 
-        EV.run(ns, 168, 462, probes={l: at(l) for l in (294, 418, 437, 442, 457)})
+        EV.run(ns, 168, 462, probes={l: at(l) for l in (291, 294, 418, 437, 442, 457)})
     finally:
         os.chdir(cwd)
     assert sorted(rec) == _Pbar.last.done
     return ns, rec, calls
 
 
-def eval_case(EV, T_mod, name, dataset, L, H, T, lens, seed_w, seed_db, joints=49, invalid_frames=()):
+def eval_case(EV, T_mod, name, dataset, L, H, T, lens, seed_w, seed_db, joints=49, invalid_frames=(), avg_filter=False):
     """The reference's evaluation flow end to end on a synthetic `*_db.pt` (run_evaluate_script).  `dataset` is
     `args.dataset`: 'mpii3d' -> data_path '..mpii3d_val_scale12_db.pt' (49 -> 17 joints, valid_i, pelvis -3, no
     J_regressor), 'h36m', '3dpw' (+ MPVPE)."""
@@ -450,10 +452,10 @@ def eval_case(EV, T_mod, name, dataset, L, H, T, lens, seed_w, seed_db, joints=4
     if dataset == 'mpii3d':
         db['valid_i'] = np.concatenate(eval_valid_i(name, lens), axis=0)
     title = 'repr_wpw_h36m_mpii3d_model' if dataset == 'h36m' else 'repr_wpw_3dpw_model'
-    ns, per_clip, _ = run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title)
+    ns, per_clip, _ = run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title, avg_filter=avg_filter)
     final = {k: float(v) for k, v in ns['full_res'].items()}
     d = {'meta': np.array([L, H, T, seed_w, seed_db, joints] + list(lens), dtype=np.int64),
-         'invalid_frames': np.array(list(invalid_frames), dtype=np.int64),
+         'invalid_frames': np.array(list(invalid_frames), dtype=np.int64), 'avg_filter': np.array(int(bool(avg_filter))),
          'tot_num_pose': np.array(ns['tot_num_pose']), 'evaluated_clips': np.array(sorted(per_clip), dtype=np.int64),
          'final_keys': np.array(sorted(final)), 'final_values': np.array([final[k] for k in sorted(final)])}
     if dataset == 'mpii3d':
@@ -593,6 +595,26 @@ def vibe_case(name, L, H, B, N, seed_w, seed_x, bidirectional=False, add_linear=
     print('wrote', name, feat.shape, out['theta'].shape)
 
 
+class _Numpy1(object):
+    """The reference's bundled transformations.py calls numpy.array(x, copy=False), which meant "copy only if needed" in the NumPy 1.x it was written
+    for and raises in NumPy 2: give that module (only) the old meaning."""
+
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+    @staticmethod
+    def array(obj, *a, **k):
+        if k.get('copy', True) is False:
+            k.pop('copy')
+            return np.asarray(obj, *a, **k)
+        return np.array(obj, *a, **k)
+
+
+def _numpy1_for_transformations():
+    import lib.utils.slerp_filter_utils as SF
+    SF.numpy = _Numpy1()
+
+
 def metrics_case(EV):
     """The per-frame metric statements of evaluate.py:413-442 (tensor conversion, pelvis, MPVPE, MPJPE, PA-MPJPE, accel
     error) executed from the file on given prediction / target arrays; data_path selects the pelvis rule (line 420).
@@ -623,22 +645,7 @@ def filter_cases(EV):
     from lib.utils.smooth_pose import smooth_pose
     import lib.utils.slerp_filter_utils as SF
 
-    class _Numpy1(object):
-        """The reference's bundled transformations.py calls numpy.array(x, copy=False), which meant
-        "copy only if needed" in the NumPy 1.x it was written for and raises in NumPy 2: give that
-        module (only) the old meaning."""
-
-        def __getattr__(self, k):
-            return getattr(np, k)
-
-        @staticmethod
-        def array(obj, *a, **k):
-            if k.get('copy', True) is False:
-                k.pop('copy')
-                return np.asarray(obj, *a, **k)
-            return np.array(obj, *a, **k)
-
-    SF.numpy = _Numpy1()
+    _numpy1_for_transformations()
     pose = (synth.normal('flt/pose', (50, 24, 3), std=0.4) +
             0.3 * np.sin(np.arange(50, dtype=np.float32) / 6.0)[:, None, None]).astype(np.float32)
     hat = smooth_pose(pose, np.zeros((50, 10), dtype=np.float32), min_cutoff=0.004, beta=0.7)[1]
@@ -718,6 +725,9 @@ def main():
         eval_case(EV, T_mod, 'eval_h36m_L1H64_T5', 'h36m', 1, 64, 5, [9, 3, 12], 22, 32, invalid_frames=(2, 15, 23))
         eval_case(EV, T_mod, 'eval_h36m14_L1H64_T4', 'h36m', 1, 64, 4, [7, 10], 23, 33, joints=14)
         eval_case(EV, T_mod, 'eval_3dpw_L2H64_T6', '3dpw', 2, 64, 6, [10, 14, 6], 24, 34, invalid_frames=(0, 11))
+        # evaluate.py --filter (lines 273-291): slerp-smoothed rotations -> SMPL -> H36M joints of that mesh
+        eval_case(EV, T_mod, 'eval_3dpw_filter_L2H64_T6', '3dpw', 2, 64, 6, [10, 14, 6], 24, 34, invalid_frames=(0, 11), avg_filter=True)
+        eval_case(EV, T_mod, 'eval_h36m14_filter_L1H64_T4', 'h36m', 1, 64, 4, [7, 10], 23, 33, joints=14, avg_filter=True)
     if not argv or 'flows' in argv:
         driver_case(EV, T_mod, 'driver_L2H128_N40T6', 2, 128, 40, 6, 6, 555)
         driver_case(EV, T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)

@@ -84,19 +84,21 @@ def _fixture_models(fx):
     return model, vibe.cuda().eval(), smpl_np
 
 
-@pytest.mark.parametrize('case', ['eval_mpii3d_L1H64_T5', 'eval_h36m_L1H64_T5', 'eval_h36m14_L1H64_T4', 'eval_3dpw_L2H64_T6'])
+@pytest.mark.parametrize('case', ['eval_mpii3d_L1H64_T5', 'eval_h36m_L1H64_T5', 'eval_h36m14_L1H64_T4', 'eval_3dpw_L2H64_T6',
+                                  'eval_3dpw_filter_L2H64_T6', 'eval_h36m14_filter_L1H64_T4'])
 def test_dataset_branches_match_the_reference_flow(case):
     """BASELINE config 4's three evaluation sets end to end (VIBE bootstrap -> windows -> joint conversion -> valid_i filter
     -> pelvis -> metrics -> records -> frame-weighted means) against tests/golden/eval_*.npz = the reference's own
     evaluate.py flow run with its TePose / VIBE classes and eval_utils functions: mpii3d with J_regressor=None (49 joints ->
     mpii3d_test, pelvis = joint -3, valid_i holes, a clip without valid frames, one with a single valid frame), h36m with
-    49- and 14-joint targets and invalid db frames, 3dpw with MPVPE.  0.01 mm on every per-clip sum and the final means."""
+    49- and 14-joint targets and invalid db frames, 3dpw with MPVPE; `*_filter_*`: evaluate.py --filter (lines 273-291: slerp-smoothed rotations ->
+    SMPL -> the H36M joints of that mesh; MPVPE on the unfiltered vertices).  0.01 mm on every per-clip sum and the final means."""
     from _eval_fixture import load
     from tepose_amd.evaluate import clip_metric_record, evaluate_clips, gather_and_reduce
     fx = load(case)
     model, vibe, smpl_np = _fixture_models(fx)
     J = None if fx['dataset'] == 'mpii3d' else torch.from_numpy(smpl_np['J_regressor_h36m'])
-    recs, mine = evaluate_clips(model, vibe, fx['clips'], fx['T'], J_regressor=J, dataset=fx['dataset'])
+    recs, mine = evaluate_clips(model, vibe, fx['clips'], fx['T'], J_regressor=J, dataset=fx['dataset'], avg_filter=fx['avg_filter'])
     recs = recs.cpu()
     assert sorted(int(r[0]) for r in recs) == sorted(fx['per_clip'])            # same clips skipped as the reference
     assert int(recs[:, 1].sum()) == fx['tot_num_pose']

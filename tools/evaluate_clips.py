@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument('--vibe-hidden', type=int, default=None)
     ap.add_argument('--as-rank', type=int, default=-1, help='debug: process the share of this rank of --of-world in ONE process')
     ap.add_argument('--of-world', type=int, default=2)
+    ap.add_argument('--filter', action='store_true', help='evaluate.py --filter: slerp-smooth the predicted rotations per clip, re-pose SMPL, evaluate the '
+                    'joints of that mesh (evaluate.py:273-291); not for mpii3d (the reference\'s branch needs the J_regressor)')
     ap.add_argument('--check', action='store_true', help='real-data readiness report (CPU only, one JSON line): found / missing files with their shapes, '
                     'the published row a run will be compared with; exit code 0 = everything a real-data run needs is there')
     ap.add_argument('--force-dist', action='store_true', help='world size 1: still initialise the process group (nccl = RCCL) and '
@@ -285,9 +287,9 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     if args.as_rank >= 0:
-        recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=args.as_rank, world=args.of_world)
+        recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=args.as_rank, world=args.of_world, avg_filter=args.filter)
     else:
-        recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=rank, world=world)
+        recs, mine = evaluate_clips(model, vibe, clips, T, J_regressor=J, dataset=args.dataset, rank=rank, world=world, avg_filter=args.filter)
     torch.cuda.synchronize()
     mine_s = time.perf_counter() - t0
     el = torch.tensor([mine_s], device=dev, dtype=torch.float64)
@@ -304,7 +306,7 @@ def main():
                # database whose longest clip dominates cannot scale like the clip count -- predicted makespans for 1 / 2 / 4 / 8 GPUs and the floor
                'lockstep_cost_model': predicted_scaling(lens, T, StepCost()),
                'per_rank': stats,      # seconds, clips, frames and longest clip (= serial window chain) of every rank
-               'frames_per_s': frames / float(el.item()), 'metrics_mm': res,
+               'frames_per_s': frames / float(el.item()), 'metrics_mm': res, 'avg_filter': bool(args.filter),
                'data': 'real' if plan['real'] else 'synthetic db + random-init weights (metric values are meaningless)',
                'tables': assets['source'], 'arch': {'layers': plan['layers'], 'hidden': plan['hidden'], 'cfg': plan['cfg_title']}}
         if plan['real']:
