@@ -595,6 +595,79 @@ def vibe_case(name, L, H, B, N, seed_w, seed_x, bidirectional=False, add_linear=
     print('wrote', name, feat.shape, out['theta'].shape)
 
 
+def _affine_from_3_points(src, dst):
+    """cv2.getAffineTransform for the stand-in cv2 (the image has no OpenCV): the 2 x 3 matrix that maps three points onto three points.  Only
+    lib/data_utils/_img_utils.py's 2-D keypoint cropping reaches it -- a field the hot path never reads and no fixture stores."""
+    A = np.concatenate([np.asarray(src, dtype=np.float64), np.ones((3, 1))], axis=1)
+    return np.linalg.solve(A, np.asarray(dst, dtype=np.float64)).T
+
+
+def padded_ds_case(T_mod, name, L, H, lens, T, seed_w, seed_db):
+    """The trainer's validation pass from the database FILE on: `3dpw_test_db.pt` / `3dpw_test_pseudotheta.pt` (synthetic, joblib) -> the reference's
+    validation Dataset (lib/dataset/threedpw_test.py ThreeDPW_TEST: videos in order of first appearance, short ones dropped, zero padding to the longest,
+    float16 staging) -> torch DataLoader (one batch) -> the unbound Trainer.validate / Trainer.evaluate (lib/core/trainer.py:294-360, 437-503).  The
+    fixture keeps the batch the Dataset emitted (hot-path fields) next to the accumulators, so tepose_amd.data.padded_validation_batch is pinned to the
+    reference's loader and driver.validate_padded / metrics.trainer_evaluate to its loop."""
+    import joblib
+    import lib.core.trainer as TR
+    import lib.data_utils._img_utils as IU
+    import lib.dataset.threedpw_test as DS
+    from tepose_amd.data import synthetic_eval_db
+    db, pse = synthetic_eval_db(list(lens), seed=seed_db, joints=14)
+    n = len(db['vid_name'])
+    db = dict(db, joints2D=synth.normal('padds/j2d%d' % seed_db, (n, 14, 3), std=40.0) + 112.0, img_name=np.array(['f%06d.jpg' % i for i in range(n)]),
+              bbox=np.tile(np.array([112., 112., 180., 180.], dtype=np.float32), (n, 1)), frame_id=np.arange(n))
+    tmp = tempfile.mkdtemp(prefix='tepose_golden_')
+    joblib.dump(db, os.path.join(tmp, '3dpw_test_db.pt'))
+    joblib.dump(np.asarray(pse), os.path.join(tmp, '3dpw_test_pseudotheta.pt'))
+    DS.TePose_DB_DIR = tmp
+    IU.cv2.getAffineTransform = _affine_from_3_points
+    ds = DS.ThreeDPW_TEST(load_opt=None, set='test', seqlen=T, vidlen=max(lens), debug=False)
+    # (lib/dataset/loaders.py:121-126 builds DataLoader(valid_db, batch_size, shuffle=False) with the default collate, which in the torch of the reference's
+    # day zipped the per-item string lists -- instance_id, imgname: one entry per real frame -- down to the shortest; today's refuses ragged lists.  The hot
+    # path reads tensors only: collate those)
+    from torch.utils.data.dataloader import default_collate
+    tensors_only = lambda items: default_collate([{k: v for k, v in it.items() if k not in ('instance_id', 'imgname')} for it in items])
+    loader = torch.utils.data.DataLoader(ds, batch_size=len(ds), shuffle=False, num_workers=0, collate_fn=tensors_only)
+    batch = next(iter(loader))
+    model = load_synth(T_mod.TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='').eval(), synth.synthetic_state_dict(L, H, seed_w))
+    calls = []
+    model.register_forward_hook(lambda m, i, o: calls.append({k: o[-1][k].detach().clone() for k in ('theta', 'kp_3d', 'verts')}))
+    scal = {}
+    me = types.SimpleNamespace(generator=model, valid_loader=loader, device='cpu', seqlen=T, epoch=0,
+                               evaluation_accumulators=dict.fromkeys(['pred_j3d', 'target_j3d', 'target_theta', 'pred_verts',
+                                                                      'pred_j3d_tsr', 'target_j3d_tsr', 'vidlen_each']),
+                               writer=types.SimpleNamespace(add_scalar=lambda k, v, global_step=None: scal.__setitem__(k, float(v))))
+    TR.Trainer.validate(me)
+    acc = me.evaluation_accumulators
+    vidlen = batch['features'].shape[1]
+    assert len(calls) == vidlen - T + 1 == len(acc['pred_j3d'])
+    th, vs = [], []
+    for c, kept in zip(calls, acc['pred_j3d']):                   # which rows the trainer kept: read off its accumulators
+        rows, r = [], 0
+        for k in range(kept.shape[0]):
+            while not torch.equal(c['kp_3d'].view(-1, 14, 3)[r], kept[k]):
+                r += 1
+            rows.append(r)
+            r += 1
+        th.append(c['theta'].view(-1, 85)[rows].numpy().copy())
+        vs.append(c['verts'].view(-1, 6890, 3)[rows][:, ::53].numpy().copy())
+    pred_j3d = torch.cat(acc['pred_j3d'], dim=0).numpy().copy()
+    pred_j3d_tsr = torch.cat(acc['pred_j3d_tsr'], dim=0).numpy().copy()
+    pa = TR.Trainer.evaluate(me)
+    assert pa == scal['error/pa-mpjpe']
+    kept_lens = [int(v) for v in batch['vidlen_each'].view(-1).tolist()]
+    save(name, meta=np.array([L, H, T, seed_w, seed_db] + kept_lens, dtype=np.int64), db_lens=np.array(list(lens), dtype=np.int64),
+         features=batch['features'].numpy().astype(np.float16), theta=batch['theta'].numpy().astype(np.float16),
+         theta_pseu=batch['theta_pseu'].numpy().astype(np.float16), kp_3d=batch['kp_3d'].numpy().astype(np.float16),
+         vidlen_each=batch['vidlen_each'].numpy(), index=batch['index'].numpy(),
+         eval_mpjpe_pa_accel_accelerr=np.array([scal['error/mpjpe'], scal['error/pa-mpjpe'], scal['error/accel'], scal['error/accel_err']], dtype=np.float64),
+         eval_pve=np.array(scal['error/pve']), pred_j3d=pred_j3d, pred_theta=np.concatenate(th), pred_verts_sub=np.concatenate(vs), pred_j3d_tsr=pred_j3d_tsr)
+    for k in ('features', 'theta', 'theta_pseu', 'kp_3d'):           # float16 staging: the stored halves ARE the batch
+        assert np.array_equal(batch[k].numpy(), batch[k].numpy().astype(np.float16).astype(np.float32)), k
+    print('wrote', name, pred_j3d.shape, kept_lens, scal)
+
+
 class _Numpy1(object):
     """The reference's bundled transformations.py calls numpy.array(x, copy=False), which meant "copy only if needed" in the NumPy 1.x it was written
     for and raises in NumPy 2: give that module (only) the old meaning."""
@@ -732,6 +805,7 @@ def main():
         driver_case(EV, T_mod, 'driver_L2H128_N40T6', 2, 128, 40, 6, 6, 555)
         driver_case(EV, T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
         padded_case(T_mod, 'padded_L2H128_T5', 2, 128, [23, 9, 17, 5], 5, 14, 700)
+        padded_ds_case(T_mod, 'padded_ds_L1H64_T5', 1, 64, [21, 9, 3, 17, 12], 5, 15, 41)
         demo_case(DM, T_mod, 'demo_L2H128_N24T6', 2, 128, 24, 6, 16, 811)
         demo_case(DM, T_mod, 'demo_L1H64_N9T8', 1, 64, 9, 8, 17, 812)
         metrics_case(EV)

@@ -120,6 +120,23 @@ def test_padded_validation_batch_follows_the_dataset_layout():
     assert padded_validation_batch(db, pse, seqlen=20) is None
 
 
+def test_padded_validation_batch_equals_the_reference_datasets_batch():
+    """tests/golden/padded_ds_L1H64_T5.npz holds the batch the REFERENCE's validation Dataset emitted (lib/dataset/threedpw_test.py ThreeDPW_TEST on a
+    synthetic 3dpw_test_db.pt, collated by a torch DataLoader; tests/golden/make_golden.py::padded_ds_case): tepose_amd.data.padded_validation_batch on the
+    same database gives the same tensors bit for bit -- order of first appearance, the 3-frame video dropped, zero padding, float16 staging, cam = [1, 0, 0]."""
+    import os
+    import numpy as np
+    from tepose_amd.data import padded_validation_batch, synthetic_eval_db
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'padded_ds_L1H64_T5.npz'))
+    T, seed_db = int(g['meta'][2]), int(g['meta'][4])
+    db, pse = synthetic_eval_db([int(v) for v in g['db_lens']], seed=seed_db, joints=14)
+    b = padded_validation_batch(db, pse, seqlen=T)
+    assert [int(v) for v in b['vidlen_each'].view(-1).tolist()] == [int(v) for v in g['meta'][5:]] == [21, 9, 17, 12]
+    for k in ('features', 'theta', 'theta_pseu', 'kp_3d'):
+        assert b[k].dtype == torch.float32 and np.array_equal(b[k].numpy(), g[k].astype(np.float32)), k
+    assert np.array_equal(b['vidlen_each'].numpy(), g['vidlen_each']) and np.array_equal(b['index'].numpy(), g['index'])
+
+
 def test_strict_checkpoint_load_with_and_without_smplx_owned_keys():
     """evaluate.py:124 loads the generator strictly.  A reference checkpoint carries whatever the author's smplx version registered under
     `regressor.smpl.*` (faces_tensor, vertex_joint_selector.extra_joints_idxs, ...); a checkpoint written from this repo's modules, or by

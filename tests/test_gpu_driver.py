@@ -137,14 +137,16 @@ def test_live_stream_window_32_single_clip_vs_oracle_loop(smpl_np):
         assert (out['theta'][:, 75:].cpu() - ref['theta'][:, 75:]).abs().max() < 1e-4
 
 
-def test_padded_validation_batch_matches_reference_trainer_loop():
+@pytest.mark.parametrize('name', ['padded_L2H128_T5', 'padded_ds_L1H64_T5'])
+def test_padded_validation_batch_matches_reference_trainer_loop(name):
     """tepose_amd.driver.validate_padded = lib/core/trainer.py:307-357 on one batch of the validation Datasets
     (zero-padded clips, float16-staged arrays, vidlen_each): accumulators in the trainer's order against vectors from the
     reference model run through that very loop (padding windows included)."""
     import os
     from tepose_amd.driver import validate_padded
     from tepose_amd.testing import build_model
-    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'padded_L2H128_T5.npz'))
+    # (padded_ds_*: the batch is what the reference's validation Dataset + a DataLoader emitted from a database file)
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', name + '.npz'))
     L, H, T, seed_w, seed_x = [int(v) for v in g['meta'][:5]]
     lens = [int(v) for v in g['meta'][5:]]
     smpl_np = synth.synthetic_smpl(0)

@@ -274,11 +274,13 @@ def test_regressor_per_call_init_golden(name, smpl_np):
     assert np.abs(only['kp_3d'].numpy() - g['kp_3d_only_pose']).max() < 1e-5
 
 
-def test_oracle_padded_validation_batch_matches_reference_golden(smpl_np):
+@pytest.mark.parametrize('name', ['padded_L2H128_T5', 'padded_ds_L1H64_T5'])
+def test_oracle_padded_validation_batch_matches_reference_golden(name, smpl_np):
     """lib/core/trainer.py:307-357 on a padded batch (tests/golden/make_golden.py::padded_case calls the reference's unbound
-    Trainer.validate on it, padding windows included): a clip's kept rows do not depend on the padded windows the reference also
-    computes, so clip-by-clip (the oracle's run_clip) reproduces the accumulators in the trainer's order."""
-    g = np.load(os.path.join(GOLDEN, 'padded_L2H128_T5.npz'))
+    Trainer.validate on it, padding windows included; padded_ds_case takes the batch from the reference's validation Dataset + a DataLoader): a clip's
+    kept rows do not depend on the padded windows the reference also computes, so clip-by-clip (the oracle's run_clip) reproduces the accumulators in
+    the trainer's order."""
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
     L, H, T, seed_w, seed_x = [int(v) for v in g['meta'][:5]]
     lens = [int(v) for v in g['meta'][5:]]
     state = synth.synthetic_state_dict(L, H, seed_w)
