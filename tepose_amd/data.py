@@ -113,7 +113,9 @@ def synthetic_eval_db(lengths, seed=0, joints=49):
 
 def padded_validation_batch(db, pseudotheta, seqlen, joints=14):
     """The batch the reference's validation Datasets hand to trainer.validate (lib/dataset/threedpw_test.py:54-134,
-    h36m_val.py; lib/data_utils/_img_utils.py:356-376), hot-path fields only: videos in order of first appearance of their
+    h36m_val.py; lib/data_utils/_img_utils.py:356-376), hot-path fields only.  A database whose `joints3D` hold the 49 'spin' joints (Human3.6M:
+    h36m_val.py:77 `convert_kps(..., src='spin', dst='common')`) is converted to the 14 common joints first; a 14-joint database (3DPW test) is taken as is.
+    Videos in order of first appearance of their
     `vid_name`, those shorter than `seqlen` dropped, every clip zero-padded to the longest; the arrays are staged in
     float16 exactly as the Datasets do (`np.zeros(..., dtype=np.float16)` filled, then `.float()`), so features and
     thetas carry fp16 rounding; theta / theta_pseu = [1, 0, 0 | pose 72 | shape 10].
@@ -139,7 +141,11 @@ def padded_validation_batch(db, pseudotheta, seqlen, joints=14):
         feats[c, :n] = db['features'][s:e]
         theta[c, :n] = np.concatenate([cam[:n], db['pose'][s:e], db['shape'][s:e]], axis=1)
         theta_pseu[c, :n] = np.concatenate([cam[:n], pse[s:e, 3:75], pse[s:e, 75:]], axis=1)
-        kp_3d[c, :n] = np.asarray(db['joints3D'][s:e])[:, :joints]
+        j3 = np.asarray(db['joints3D'][s:e])
+        if j3.shape[1] == 49:                                    # h36m_val.py:77: spin -> common (the 14 LSP joints), then [:nj]
+            from .metrics import SPIN_TO_COMMON
+            j3 = j3[:, SPIN_TO_COMMON]
+        kp_3d[c, :n] = j3[:, :joints]
     return {'features': torch.from_numpy(feats).float(), 'theta': torch.from_numpy(theta).float(),
             'theta_pseu': torch.from_numpy(theta_pseu).float(), 'kp_3d': torch.from_numpy(kp_3d).float(),
             'vidlen_each': torch.tensor([float(e - s) for s, e in spans]).view(C, 1),

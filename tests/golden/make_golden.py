@@ -602,27 +602,33 @@ def _affine_from_3_points(src, dst):
     return np.linalg.solve(A, np.asarray(dst, dtype=np.float64)).T
 
 
-def padded_ds_case(T_mod, name, L, H, lens, T, seed_w, seed_db):
+def padded_ds_case(T_mod, name, L, H, lens, T, seed_w, seed_db, which='3dpw'):
     """The trainer's validation pass from the database FILE on: `3dpw_test_db.pt` / `3dpw_test_pseudotheta.pt` (synthetic, joblib) -> the reference's
     validation Dataset (lib/dataset/threedpw_test.py ThreeDPW_TEST: videos in order of first appearance, short ones dropped, zero padding to the longest,
-    float16 staging) -> torch DataLoader (one batch) -> the unbound Trainer.validate / Trainer.evaluate (lib/core/trainer.py:294-360, 437-503).  The
+    float16 staging; which='h36m': lib/dataset/h36m_val.py Human36M_VAL on `h36m_test_front_25fps_tight_*` with 49-joint `joints3D`, which it converts
+    spin -> common) -> torch DataLoader (one batch) -> the unbound Trainer.validate / Trainer.evaluate (lib/core/trainer.py:294-360, 437-503).  The
     fixture keeps the batch the Dataset emitted (hot-path fields) next to the accumulators, so tepose_amd.data.padded_validation_batch is pinned to the
     reference's loader and driver.validate_padded / metrics.trainer_evaluate to its loop."""
     import joblib
     import lib.core.trainer as TR
     import lib.data_utils._img_utils as IU
-    import lib.dataset.threedpw_test as DS
     from tepose_amd.data import synthetic_eval_db
-    db, pse = synthetic_eval_db(list(lens), seed=seed_db, joints=14)
+    if which == 'h36m':
+        import lib.dataset.h36m_val as DS
+        cls, stem, nj_db = DS.Human36M_VAL, 'h36m_test_front_25fps_tight', 49
+    else:
+        import lib.dataset.threedpw_test as DS
+        cls, stem, nj_db = DS.ThreeDPW_TEST, '3dpw_test', 14
+    db, pse = synthetic_eval_db(list(lens), seed=seed_db, joints=nj_db)
     n = len(db['vid_name'])
-    db = dict(db, joints2D=synth.normal('padds/j2d%d' % seed_db, (n, 14, 3), std=40.0) + 112.0, img_name=np.array(['f%06d.jpg' % i for i in range(n)]),
+    db = dict(db, joints2D=synth.normal('padds/j2d%d' % seed_db, (n, nj_db, 3), std=40.0) + 112.0, img_name=np.array(['f%06d.jpg' % i for i in range(n)]),
               bbox=np.tile(np.array([112., 112., 180., 180.], dtype=np.float32), (n, 1)), frame_id=np.arange(n))
     tmp = tempfile.mkdtemp(prefix='tepose_golden_')
-    joblib.dump(db, os.path.join(tmp, '3dpw_test_db.pt'))
-    joblib.dump(np.asarray(pse), os.path.join(tmp, '3dpw_test_pseudotheta.pt'))
+    joblib.dump(db, os.path.join(tmp, stem + '_db.pt'))
+    joblib.dump(np.asarray(pse), os.path.join(tmp, stem + '_pseudotheta.pt'))
     DS.TePose_DB_DIR = tmp
     IU.cv2.getAffineTransform = _affine_from_3_points
-    ds = DS.ThreeDPW_TEST(load_opt=None, set='test', seqlen=T, vidlen=max(lens), debug=False)
+    ds = cls(load_opt=None, set='test', seqlen=T, vidlen=max(lens), debug=False)
     # (lib/dataset/loaders.py:121-126 builds DataLoader(valid_db, batch_size, shuffle=False) with the default collate, which in the torch of the reference's
     # day zipped the per-item string lists -- instance_id, imgname: one entry per real frame -- down to the shortest; today's refuses ragged lists.  The hot
     # path reads tensors only: collate those)
@@ -657,7 +663,7 @@ def padded_ds_case(T_mod, name, L, H, lens, T, seed_w, seed_db):
     pa = TR.Trainer.evaluate(me)
     assert pa == scal['error/pa-mpjpe']
     kept_lens = [int(v) for v in batch['vidlen_each'].view(-1).tolist()]
-    save(name, meta=np.array([L, H, T, seed_w, seed_db] + kept_lens, dtype=np.int64), db_lens=np.array(list(lens), dtype=np.int64),
+    save(name, meta=np.array([L, H, T, seed_w, seed_db] + kept_lens, dtype=np.int64), db_lens=np.array(list(lens), dtype=np.int64), db_joints=np.array(nj_db),
          features=batch['features'].numpy().astype(np.float16), theta=batch['theta'].numpy().astype(np.float16),
          theta_pseu=batch['theta_pseu'].numpy().astype(np.float16), kp_3d=batch['kp_3d'].numpy().astype(np.float16),
          vidlen_each=batch['vidlen_each'].numpy(), index=batch['index'].numpy(),
@@ -806,6 +812,7 @@ def main():
         driver_case(EV, T_mod, 'driver_L1H64_N9T4', 1, 64, 9, 4, 7, 556)
         padded_case(T_mod, 'padded_L2H128_T5', 2, 128, [23, 9, 17, 5], 5, 14, 700)
         padded_ds_case(T_mod, 'padded_ds_L1H64_T5', 1, 64, [21, 9, 3, 17, 12], 5, 15, 41)
+        padded_ds_case(T_mod, 'padded_ds_h36m_L1H64_T4', 1, 64, [8, 22, 2, 11], 4, 16, 42, which='h36m')
         demo_case(DM, T_mod, 'demo_L2H128_N24T6', 2, 128, 24, 6, 16, 811)
         demo_case(DM, T_mod, 'demo_L1H64_N9T8', 1, 64, 9, 8, 17, 812)
         metrics_case(EV)

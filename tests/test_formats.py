@@ -120,18 +120,21 @@ def test_padded_validation_batch_follows_the_dataset_layout():
     assert padded_validation_batch(db, pse, seqlen=20) is None
 
 
-def test_padded_validation_batch_equals_the_reference_datasets_batch():
-    """tests/golden/padded_ds_L1H64_T5.npz holds the batch the REFERENCE's validation Dataset emitted (lib/dataset/threedpw_test.py ThreeDPW_TEST on a
-    synthetic 3dpw_test_db.pt, collated by a torch DataLoader; tests/golden/make_golden.py::padded_ds_case): tepose_amd.data.padded_validation_batch on the
-    same database gives the same tensors bit for bit -- order of first appearance, the 3-frame video dropped, zero padding, float16 staging, cam = [1, 0, 0]."""
+@pytest.mark.parametrize('name', ['padded_ds_L1H64_T5', 'padded_ds_h36m_L1H64_T4'])
+def test_padded_validation_batch_equals_the_reference_datasets_batch(name):
+    """tests/golden/padded_ds_*.npz hold the batch the REFERENCE's validation Datasets emitted (lib/dataset/threedpw_test.py ThreeDPW_TEST,
+    lib/dataset/h36m_val.py Human36M_VAL -- 49 'spin' joints converted to the 14 common ones -- on synthetic database files, collated by a torch DataLoader;
+    tests/golden/make_golden.py::padded_ds_case): tepose_amd.data.padded_validation_batch on the same database gives the same tensors bit for bit --
+    order of first appearance, videos shorter than the window dropped, zero padding, float16 staging, cam = [1, 0, 0]."""
     import os
     import numpy as np
     from tepose_amd.data import padded_validation_batch, synthetic_eval_db
-    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'padded_ds_L1H64_T5.npz'))
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', name + '.npz'))
     T, seed_db = int(g['meta'][2]), int(g['meta'][4])
-    db, pse = synthetic_eval_db([int(v) for v in g['db_lens']], seed=seed_db, joints=14)
+    db, pse = synthetic_eval_db([int(v) for v in g['db_lens']], seed=seed_db, joints=int(g['db_joints']))
     b = padded_validation_batch(db, pse, seqlen=T)
-    assert [int(v) for v in b['vidlen_each'].view(-1).tolist()] == [int(v) for v in g['meta'][5:]] == [21, 9, 17, 12]
+    assert [int(v) for v in b['vidlen_each'].view(-1).tolist()] == [int(v) for v in g['meta'][5:]]
+    assert len(g['meta'][5:]) == len(g['db_lens']) - 1                          # one video of each database is shorter than the window
     for k in ('features', 'theta', 'theta_pseu', 'kp_3d'):
         assert b[k].dtype == torch.float32 and np.array_equal(b[k].numpy(), g[k].astype(np.float32)), k
     assert np.array_equal(b['vidlen_each'].numpy(), g['vidlen_each']) and np.array_equal(b['index'].numpy(), g['index'])

@@ -47,7 +47,7 @@ def test_flow_fixtures_regenerate_bit_identically(tmp_path):
     p = subprocess.run([sys.executable, GEN, '--out', str(tmp_path), 'flows'], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     made = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.npz'))
-    assert len(made) == 14 and sum(f.startswith('eval_') for f in made) == 6 and sum(f.startswith('demo_') for f in made) == 2, made
+    assert len(made) == 15 and sum(f.startswith('eval_') for f in made) == 6 and sum(f.startswith('demo_') for f in made) == 2, made
     for f in made:
         a, b = np.load(os.path.join(str(tmp_path), f)), np.load(os.path.join(ROOT, 'tests', 'golden', f))
         assert sorted(a.files) == sorted(b.files), f

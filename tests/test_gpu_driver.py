@@ -137,7 +137,7 @@ def test_live_stream_window_32_single_clip_vs_oracle_loop(smpl_np):
         assert (out['theta'][:, 75:].cpu() - ref['theta'][:, 75:]).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize('name', ['padded_L2H128_T5', 'padded_ds_L1H64_T5'])
+@pytest.mark.parametrize('name', ['padded_L2H128_T5', 'padded_ds_L1H64_T5', 'padded_ds_h36m_L1H64_T4'])
 def test_padded_validation_batch_matches_reference_trainer_loop(name):
     """tepose_amd.driver.validate_padded = lib/core/trainer.py:307-357 on one batch of the validation Datasets
     (zero-padded clips, float16-staged arrays, vidlen_each): accumulators in the trainer's order against vectors from the

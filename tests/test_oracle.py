@@ -274,7 +274,7 @@ def test_regressor_per_call_init_golden(name, smpl_np):
     assert np.abs(only['kp_3d'].numpy() - g['kp_3d_only_pose']).max() < 1e-5
 
 
-@pytest.mark.parametrize('name', ['padded_L2H128_T5', 'padded_ds_L1H64_T5'])
+@pytest.mark.parametrize('name', ['padded_L2H128_T5', 'padded_ds_L1H64_T5', 'padded_ds_h36m_L1H64_T4'])
 def test_oracle_padded_validation_batch_matches_reference_golden(name, smpl_np):
     """lib/core/trainer.py:307-357 on a padded batch (tests/golden/make_golden.py::padded_case calls the reference's unbound
     Trainer.validate on it, padding windows included; padded_ds_case takes the batch from the reference's validation Dataset + a DataLoader): a clip's
