@@ -174,9 +174,10 @@ def test_padded_validation_batch_matches_reference_trainer_loop(name):
     ev = trainer_evaluate(model, out, target, T)
     assert abs(ev['pve'] - float(g['eval_pve'])) < 2e-4 * float(g['eval_pve']) + 2e-2, (ev['pve'], float(g['eval_pve']))
     # a clip shorter than the window contributes nothing (split_into_videos_val drops it, _img_utils.py:369-370)
-    target['vidlen_each'] = torch.tensor([lens[0], 3, lens[2], lens[3]]).float().view(-1, 1)
+    short = [3 if c == 1 else n for c, n in enumerate(lens)]
+    target['vidlen_each'] = torch.tensor(short).float().view(-1, 1)
     out2 = validate_padded(model, target, T)
-    assert out2['pred_kp_3d'].shape[0] == sum(max(n - T + 1, 0) for n in (lens[0], 0, lens[2], lens[3]))
+    assert out2['pred_kp_3d'].shape[0] == sum(max(n - T + 1, 0) for n in short)
     assert out2['pred_kp_3d'].shape[1] == 49
 
 
