@@ -727,11 +727,12 @@ def filter_cases(EV):
     _numpy1_for_transformations()
     pose = (synth.normal('flt/pose', (50, 24, 3), std=0.4) +
             0.3 * np.sin(np.arange(50, dtype=np.float32) / 6.0)[:, None, None]).astype(np.float32)
-    hat = smooth_pose(pose, np.zeros((50, 10), dtype=np.float32), min_cutoff=0.004, beta=0.7)[1]
+    betas = synth.normal('flt/betas', (50, 10), std=0.5)
+    sm_verts, hat, sm_joints = smooth_pose(pose, betas, min_cutoff=0.004, beta=0.7)     # (vertices, filtered pose, the wrapper's 49 joints) of every frame
     R = O.batch_rodrigues(torch.from_numpy(pose.reshape(-1, 3))).view(50, 24, 3, 3).numpy().astype(np.float32)
     R[7] = R[7] + synth.normal('flt/noise', (24, 3, 3), std=1e-4)          # not exactly orthonormal
     R_smooth = EV.namespace()['smooth_pose_mat'](R.copy(), ratio=0.3)
-    save('filters', pose=pose, pose_hat=hat, R=R, R_smooth=R_smooth)
+    save('filters', pose=pose, pose_hat=hat, R=R, R_smooth=R_smooth, smooth_verts_sub=sm_verts[:, ::53].astype(np.float32), smooth_joints=sm_joints.astype(np.float32))
     print('wrote filters', hat.shape, R_smooth.shape)
 
 

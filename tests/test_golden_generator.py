@@ -53,3 +53,34 @@ def test_flow_fixtures_regenerate_bit_identically(tmp_path):
         assert sorted(a.files) == sorted(b.files), f
         for k in a.files:
             assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == 'f'), (f, k)
+
+
+def test_database_names_equal_what_evaluate_py_derives():
+    """tepose_amd.config.eval_db_paths against lines 141-166 of the reference's evaluate.py, executed for every (config TITLE, --dataset, render) the script has
+    a database for -- and the combinations it has none for."""
+    import importlib.util
+    import tempfile
+    import types
+    sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location('make_golden_mod', GEN)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from tepose_amd.config import eval_db_paths, get_cfg_defaults
+    EV = mg.RefScript('evaluate.py')
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())                       # line 144 creates ./output/<dataset>_test_output
+    try:
+        for title, dataset, render in (('repr_wpw_3dpw_model', '3dpw', False), ('repr_wopw_3dpw_model', '3dpw', True),
+                                       ('repr_wpw_h36m_mpii3d_model', 'h36m', False), ('repr_wopw_h36m_model', 'h36m', False),
+                                       ('repr_wpw_h36m_mpii3d_model', 'mpii3d', False), ('repr_wopw_mpii3d_model', 'mpii3d', False)):
+            import os.path as osp
+            from pathlib import Path
+            ns = {'osp': osp, 'Path': Path, 'TePose_DB_DIR': 'data/preprocessed_data', 'cfg': types.SimpleNamespace(TITLE=title),
+                  'target_dataset': dataset, 'set': 'test', 'render': render, 'print': lambda *a, **k: None}
+            EV.run(ns, 141, 166)
+            cfg = get_cfg_defaults()
+            cfg.TITLE = title
+            assert eval_db_paths(cfg, dataset, 'data/preprocessed_data', render=render) == (ns['data_path'], ns['psetheta_file']), (title, dataset)
+            assert ns['seqlen'] == 6
+    finally:
+        os.chdir(cwd)

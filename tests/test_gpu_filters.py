@@ -38,3 +38,7 @@ def test_smooth_pose_pipeline_vs_oracle():
     v_ref, posed = O.lbs(s, torch.from_numpy(betas), R)
     assert np.abs(verts - v_ref.numpy()).max() < 1e-4
     assert np.abs(joints - O.smpl_joints49(s, v_ref, posed).numpy()).max() < 1e-4
+    # ... and against what the reference's own smooth_pose returned for this very input (lib/utils/smooth_pose.py:24-68, called by the fixture generator)
+    assert np.abs(pose_hat.reshape(50, 24, 3) - g['pose_hat']).max() < 1e-5
+    assert np.abs(verts[:, ::53] - g['smooth_verts_sub']).max() < 1e-4
+    assert np.abs(joints - g['smooth_joints']).max() < 1e-4
