@@ -183,8 +183,9 @@ def install_stubs():
         return _np_load(p, *a, **k)
 
     np.load = fake_load
-    # no GPU in the build container: the scripts' `.cuda()` calls keep the tensor / module where it is
-    torch.Tensor.cuda = lambda self, *a, **k: self
+    # no GPU in the build container: the scripts' `.cuda()` calls keep the module where it is and COPY the tensor, as a host-to-device transfer does
+    # (an identity would alias `theta_input` with the database rows it was sliced from, evaluate.py:219, and the loop's in-place shifts would edit them)
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()
     nn.Module.cuda = lambda self, *a, **k: self
 
 
@@ -373,7 +374,7 @@ def eval_valid_i(name, lens):
     return out
 
 
-def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='repr_wpw_3dpw_model', avg_filter=False):
+def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='repr_wpw_3dpw_model', avg_filter=False, seq=''):
     """evaluate.py's `__main__` body on a synthetic database.  Executed from the file: lines 64-86 (options), 109-137
     (J_regressor, TePose from cfg + checkpoint file, SMPL swap), 141-166 (data paths), 168-462 (keyed clips, VIBE
     bootstrap, window loop, conversion / valid_i / pelvis / metrics, means).  NOT executed: 88-107 (a hard-coded 2 x 1024
@@ -387,7 +388,7 @@ def run_evaluate_script(EV, T_mod, dataset, L, H, T, seed_w, db, pse, title='rep
     torch.save({'performance': 0.0, 'gen_state_dict': proto.state_dict()}, ckpt)
     cfg = CN(DEVICE='cpu', TITLE=title, MODEL=CN(TGRU=CN(NUM_LAYERS=L, HIDDEN_SIZE=H)), DATASET=CN(SEQLEN=T),
              TRAIN=CN(BATCH_SIZE=32, PRETRAINED=ckpt, PRETRAINED_REGRESSOR=''))
-    args = types.SimpleNamespace(dataset=dataset, seq='', render=False, render_plain=False, frame=0, plot=False, filter=bool(avg_filter))
+    args = types.SimpleNamespace(dataset=dataset, seq=seq, render=False, render_plain=False, frame=0, plot=False, filter=bool(avg_filter))
     if avg_filter:
         _numpy1_for_transformations()
     n = len(db['vid_name'])

@@ -84,3 +84,29 @@ def test_database_names_equal_what_evaluate_py_derives():
             assert ns['seqlen'] == 6
     finally:
         os.chdir(cwd)
+
+
+def test_clip_selection_equals_what_evaluate_py_keys():
+    """tepose_amd.data.split_db_into_clips (vid_name grouping in np.unique order, the db's `valid` column, `--seq` substring filter, camera of the
+    pseudo-theta forced to [1, 0, 0]) against `dataset_data` as lines 169-207 of the reference's evaluate.py leave it, executed on a synthetic database."""
+    import importlib.util
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location('make_golden_mod2', GEN)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.install_stubs()
+    import lib.models.tepose as T_mod
+    from tepose_amd.data import split_db_into_clips, synthetic_eval_db
+    EV = mg.RefScript('evaluate.py')
+    db, pse = synthetic_eval_db([7, 9, 8, 12], seed=77)
+    db['vid_name'] = np.concatenate([np.array([n] * l) for n, l in zip(['walk_b', 'run_a', 'walk_a', 'sit_c'], [7, 9, 8, 12])])   # not in np.unique order
+    for f in (1, 8, 20):
+        db['valid'][f] = 0
+    for seq in ('', 'walk', 'run_a', 'nothing'):
+        ns, per_clip, _ = mg.run_evaluate_script(EV, T_mod, '3dpw', 1, 64, 6, 5, db, pse, seq=seq)
+        ours = split_db_into_clips(db, pse, target_action=seq)
+        assert list(ours) == list(ns['dataset_data'])
+        for k in ours:
+            for f in ('features', 'joints3D', 'theta_pseu', 'pose', 'shape'):
+                assert np.array_equal(np.asarray(ours[k][f], dtype=np.float64), np.asarray(ns['dataset_data'][k][f], dtype=np.float64)), (seq, k, f)
