@@ -48,6 +48,7 @@ class StreamSession:
         # more bytes or the weights are re-packed.  Two sessions on one model do not share scratch either.
         self.ws = torch.empty(eng.workspace_bytes(1, T), dtype=torch.uint8, device=dev)
         self._captured_for = None
+        self._rewatch()
         # the window as the model sees it (slot T-1 = the newest frame) and a scratch copy for the one-frame shift
         self.win = torch.zeros(1, T, 2133, device=dev)
         self.win[0, 1:, :2048] = feature_init.to(dev, torch.float32)      # after the first push's shift they sit in slots 0 .. T-2
@@ -99,6 +100,11 @@ class StreamSession:
                 self.out_host[k] = torch.empty(out[k][0].shape, dtype=torch.float32).pin_memory()
             self.out_host[k].copy_(out[k][0], non_blocking=True)
 
+    def _rewatch(self):
+        eng = self.model._engine
+        self._watch = eng._enc_tensors(self.model.encoder) + eng._reg_tensors(self.model.regressor)
+        self._watch_sig = (tuple([t._version for t in self._watch]), self._watch[0].data_ptr(), self._watch[-1].data_ptr())
+
     def _signature(self):
         eng = self.model._engine
         return (eng.packed_generation, eng.blob.data_ptr() if eng.blob is not None else 0, self.ws.data_ptr())
@@ -108,8 +114,16 @@ class StreamSession:
         using the old packed blob without a sign), grow the session's workspace if the packed model now needs more, and re-capture a graph
         whose blob / workspace are no longer the ones it was captured against.  Same for the eager (graph=False) session."""
         eng = self.model._engine
-        with torch.cuda.stream(self.stream):
-            eng.pack_model(self.model, self.dev)                       # no-op while the parameter signatures stand
+        # Per push, on the frame's critical path: the in-place version counters of the watched parameter / buffer objects and two addresses (~5 us on the
+        # host).  The engine's full signature walk (every tensor re-fetched from its module by name, ~35 us) runs when those moved, and every 32nd push as a
+        # backstop for what the cheap check cannot see (a parameter OBJECT replaced by assignment).
+        self._pushes_since_full = getattr(self, '_pushes_since_full', 0) + 1
+        cheap = (tuple([t._version for t in self._watch]), self._watch[0].data_ptr(), self._watch[-1].data_ptr())
+        if cheap != self._watch_sig or self._pushes_since_full >= 32:
+            self._pushes_since_full = 0
+            with torch.cuda.stream(self.stream):
+                eng.pack_model(self.model, self.dev)                   # no-op while the parameter signatures stand
+            self._rewatch()
         if self._signature() == self._captured_for:
             return
         need = eng.workspace_bytes(1, self.T)

@@ -208,3 +208,43 @@ def test_the_demo_flow_of_the_reference_on_the_device(name, smpl_np):
     got, ses = _stream_clip(model, w, theta_init.cpu().numpy(), T, None, keep=('theta', 'kp_3d', 'verts'))
     for k in ('theta', 'kp_3d', 'verts'):
         assert torch.equal(got[k], ref[k].cpu()), k
+
+
+@pytest.mark.parametrize('graph', [True, False])
+def test_an_in_place_weight_change_is_seen_by_the_next_push(graph, smpl_np):
+    """parameters changed IN PLACE (an optimiser step, `p.add_()`, load_state_dict) with no eager forward in between -- the replayed graph would go
+    on using the old packed blob without a sign.  push() compares the watched tensors' version counters (and re-walks the full signatures every 32nd
+    push): the next frame runs on the new weights, graph and eager sessions alike, exactly as a model built with those weights from the start."""
+    import copy
+    from tepose_amd.stream import StreamSession
+    from tepose_amd.testing import build_model
+    T, N = 5, 14
+    model, state, _ = build_model(1, 64, seed=41, device='cuda', smpl_np=smpl_np, seqlen=T)
+    w = synth.synthetic_windows(1, N, 91)[0]
+    feats, th0 = torch.from_numpy(w[:, :2048].copy()), torch.from_numpy(w[:T - 1, 2048:].copy())
+    ses = StreamSession(model, T, feats[:T - 1], th0, keep=('theta', 'kp_3d'), graph=graph)
+    for f in feats[T - 1:T + 2]:
+        ses.push(f)
+    gen0 = model._engine.packed_generation
+    with torch.no_grad():
+        model.regressor.deccam.bias.add_(0.05)                       # in place: same storage, version counter + 1
+        model.encoder.gru_fwd.weight_hh_l0.mul_(0.9)
+    got = [{k: v.clone() for k, v in ses.push(f).items()} for f in feats[T + 2:]]
+    assert model._engine.packed_generation > gen0                     # re-packed by the push that followed the change
+    # the same stream on a model that had the new weights from the start
+    state2 = {k: np.array(v, copy=True) for k, v in state.items()}
+    state2['regressor.deccam.bias'] = state2['regressor.deccam.bias'] + np.float32(0.05)
+    state2['encoder.gru_fwd.weight_hh_l0'] = state2['encoder.gru_fwd.weight_hh_l0'] * np.float32(0.9)
+    old, _, _ = build_model(1, 64, seed=41, device='cuda', smpl_np=smpl_np, seqlen=T)
+    new, _, _ = build_model(1, 64, seed=41, device='cuda', smpl_np=smpl_np, seqlen=T, state=state2)
+    ses_old = StreamSession(old, T, feats[:T - 1], th0, keep=('theta', 'kp_3d'), graph=graph)
+    for f in feats[T - 1:T + 2]:
+        ses_old.push(f)
+    # hand the history the first session had reached over to the new-weights model: its window after the three pushes
+    ses_new = StreamSession(new, T, feats[:T - 1], th0, keep=('theta', 'kp_3d'), graph=graph)
+    ses_new.win.copy_(ses_old.win)
+    want = [{k: v.clone() for k, v in ses_new.push(f).items()} for f in feats[T + 2:]]
+    stale = [{k: v.clone() for k, v in ses_old.push(f).items()} for f in feats[T + 2:]]
+    for a, b, c in zip(got, want, stale):
+        assert torch.equal(a['theta'], b['theta']) and torch.equal(a['kp_3d'], b['kp_3d'])
+        assert not torch.equal(a['theta'], c['theta'])                # ... and not what the old blob would have produced
