@@ -76,13 +76,16 @@ def partition_clips(lengths, world_size, step_ms=None, seqlen=6):
     if step_ms is None or world_size <= 1:
         return parts
     cost = lambda p: lockstep_seconds([lengths[i] for i in p], seqlen, step_ms)
+    # Clips arrive in descending length, so a new clip is the shortest of its rank: for each of its w windows every clip already there is still active,
+    # and taking it costs the rank  w x (step_ms(k + 1) - step_ms(k))  (k = clips of the rank that have windows at all).  O(clips x ranks), exact.
     mine = [[] for _ in range(world_size)]
-    secs, frames = [0.0] * world_size, [0] * world_size
+    secs, frames, active = [0.0] * world_size, [0] * world_size, [0] * world_size
     for i in order:
-        cand = [(cost(mine[r] + [i]), frames[r], r) for r in range(world_size)]
+        w = max(int(lengths[i]) - int(seqlen) + 1, 0)
+        cand = [(secs[r] + w * (step_ms(active[r] + 1) - (step_ms(active[r]) if active[r] else 0.0)) / 1e3, frames[r], r) for r in range(world_size)]
         t, _, r = min(cand)
         mine[r].append(i)
-        secs[r], frames[r] = t, frames[r] + int(lengths[i])
+        secs[r], frames[r], active[r] = t, frames[r] + int(lengths[i]), active[r] + (1 if w > 0 else 0)
     return mine if max(secs) < max(cost(p) for p in parts) else parts
 
 
