@@ -569,6 +569,9 @@ static inline int forward_begin(const tepose_model* m, const void* workspace) {
   }
   return 0;
 }
+// rows up to which the persistent kernels may run (the option, capped by what the kernels hold: 64 rows)
+static inline int seq_rows_cap(const tepose_model* m) { return m->opt.seq_max_m > 64 ? 64 : m->opt.seq_max_m; }
+static inline int reg_seq_rows_cap(const tepose_model* m) { return m->opt.reg_seq_max_n > 64 ? 64 : m->opt.reg_seq_max_n; }
 static inline void fault_collected(const tepose_model* m) {
   std::lock_guard<std::mutex> g(m->q_mu);
   ++m->collected;
@@ -623,7 +626,7 @@ KernelPlan select_kernels(const tepose_model* m, int B, int T, bool assume_ready
   k.step_skinny = k.h3 && !k.scaled && B <= m->opt.skinny_h3_max_m;
   // regressor / SMPL
   k.reg_split = reg_split_for(m, B);
-  k.reg_seq = k.reg_split && B <= (m->opt.reg_seq_max_n > 64 ? 64 : m->opt.reg_seq_max_n) && persist;
+  k.reg_seq = k.reg_split && B <= reg_seq_rows_cap(m) && persist;
   k.blend16 = blend16_for(m, B);
   return k;
 }
@@ -948,7 +951,7 @@ int tepose_debug_set_test_fault(tepose_model* m, unsigned bits) {
 int tepose_uses_persistent(const tepose_model* m, int B, int T) {
   if (!m || B < 1) return 0;
   if (!persist_on(m) || !m->split || B <= m->opt.split_min_m) return 0;
-  const int cap = (m->opt.seq_max_m > 64 ? 64 : m->opt.seq_max_m) > (m->opt.reg_seq_max_n > 64 ? 64 : m->opt.reg_seq_max_n) ? (m->opt.seq_max_m > 64 ? 64 : m->opt.seq_max_m) : (m->opt.reg_seq_max_n > 64 ? 64 : m->opt.reg_seq_max_n);
+  const int cap = seq_rows_cap(m) > reg_seq_rows_cap(m) ? seq_rows_cap(m) : reg_seq_rows_cap(m);
   (void)T;
   return B <= cap ? 1 : 0;
 }
