@@ -603,23 +603,26 @@ def _affine_from_3_points(src, dst):
     return np.linalg.solve(A, np.asarray(dst, dtype=np.float64)).T
 
 
-def padded_ds_case(T_mod, name, L, H, lens, T, seed_w, seed_db, which='3dpw'):
-    """The trainer's validation pass from the database FILE on: `3dpw_test_db.pt` / `3dpw_test_pseudotheta.pt` (synthetic, joblib) -> the reference's
-    validation Dataset (lib/dataset/threedpw_test.py ThreeDPW_TEST: videos in order of first appearance, short ones dropped, zero padding to the longest,
-    float16 staging; which='h36m': lib/dataset/h36m_val.py Human36M_VAL on `h36m_test_front_25fps_tight_*` with 49-joint `joints3D`, which it converts
-    spin -> common) -> torch DataLoader (one batch) -> the unbound Trainer.validate / Trainer.evaluate (lib/core/trainer.py:294-360, 437-503).  The
-    fixture keeps the batch the Dataset emitted (hot-path fields) next to the accumulators, so tepose_amd.data.padded_validation_batch is pinned to the
-    reference's loader and driver.validate_padded / metrics.trainer_evaluate to its loop."""
+def reference_validation_loader(which, lens, T, seed_db):
+    """(DataLoader, its one batch, joints per frame of the database) of a reference validation Dataset on a synthetic database file:
+    which = '3dpw' -> lib/dataset/threedpw_test.py ThreeDPW_TEST on 3dpw_test_*; 'h36m' -> lib/dataset/h36m_val.py Human36M_VAL on
+    h36m_test_front_25fps_tight_* (49 'spin' joints); '3dpw_val' -> lib/dataset/threedpw.py ThreeDPW(set='val') = Dataset3D (lib/dataset/dataset_3d.py), the
+    class five of the six shipped configs name as TRAIN.DATASET_EVAL (lib/dataset/loaders.py:118), on 3dpw_val_*."""
     import joblib
-    import lib.core.trainer as TR
     import lib.data_utils._img_utils as IU
     from tepose_amd.data import synthetic_eval_db
+    if not hasattr(np, 'float'):
+        np.float = float                                   # dataset_3d.py:272 still says np.float (removed in NumPy 1.24)
     if which == 'h36m':
         import lib.dataset.h36m_val as DS
-        cls, stem, nj_db = DS.Human36M_VAL, 'h36m_test_front_25fps_tight', 49
+        make, stem, nj_db = (lambda: DS.Human36M_VAL(load_opt=None, set='test', seqlen=T, vidlen=max(lens), debug=False)), 'h36m_test_front_25fps_tight', 49
+    elif which == '3dpw_val':
+        import lib.dataset.dataset_3d as DS
+        import lib.dataset.threedpw as TD
+        make, stem, nj_db = (lambda: TD.ThreeDPW(load_opt='repr_wpw_3dpw_model', set='val', seqlen=T, vidlen=max(lens), overlap=(T - 1) / float(T), debug=False)), '3dpw_val', 14
     else:
         import lib.dataset.threedpw_test as DS
-        cls, stem, nj_db = DS.ThreeDPW_TEST, '3dpw_test', 14
+        make, stem, nj_db = (lambda: DS.ThreeDPW_TEST(load_opt=None, set='test', seqlen=T, vidlen=max(lens), debug=False)), '3dpw_test', 14
     db, pse = synthetic_eval_db(list(lens), seed=seed_db, joints=nj_db)
     n = len(db['vid_name'])
     db = dict(db, joints2D=synth.normal('padds/j2d%d' % seed_db, (n, nj_db, 3), std=40.0) + 112.0, img_name=np.array(['f%06d.jpg' % i for i in range(n)]),
@@ -629,14 +632,25 @@ def padded_ds_case(T_mod, name, L, H, lens, T, seed_w, seed_db, which='3dpw'):
     joblib.dump(np.asarray(pse), os.path.join(tmp, stem + '_pseudotheta.pt'))
     DS.TePose_DB_DIR = tmp
     IU.cv2.getAffineTransform = _affine_from_3_points
-    ds = cls(load_opt=None, set='test', seqlen=T, vidlen=max(lens), debug=False)
+    ds = make()
     # (lib/dataset/loaders.py:121-126 builds DataLoader(valid_db, batch_size, shuffle=False) with the default collate, which in the torch of the reference's
     # day zipped the per-item string lists -- instance_id, imgname: one entry per real frame -- down to the shortest; today's refuses ragged lists.  The hot
     # path reads tensors only: collate those)
     from torch.utils.data.dataloader import default_collate
     tensors_only = lambda items: default_collate([{k: v for k, v in it.items() if k not in ('instance_id', 'imgname')} for it in items])
     loader = torch.utils.data.DataLoader(ds, batch_size=len(ds), shuffle=False, num_workers=0, collate_fn=tensors_only)
-    batch = next(iter(loader))
+    return loader, next(iter(loader)), nj_db
+
+
+def padded_ds_case(T_mod, name, L, H, lens, T, seed_w, seed_db, which='3dpw'):
+    """The trainer's validation pass from the database FILE on: `3dpw_test_db.pt` / `3dpw_test_pseudotheta.pt` (synthetic, joblib) -> the reference's
+    validation Dataset (lib/dataset/threedpw_test.py ThreeDPW_TEST: videos in order of first appearance, short ones dropped, zero padding to the longest,
+    float16 staging; which='h36m': lib/dataset/h36m_val.py Human36M_VAL on `h36m_test_front_25fps_tight_*` with 49-joint `joints3D`, which it converts
+    spin -> common) -> torch DataLoader (one batch) -> the unbound Trainer.validate / Trainer.evaluate (lib/core/trainer.py:294-360, 437-503).  The
+    fixture keeps the batch the Dataset emitted (hot-path fields) next to the accumulators, so tepose_amd.data.padded_validation_batch is pinned to the
+    reference's loader and driver.validate_padded / metrics.trainer_evaluate to its loop."""
+    import lib.core.trainer as TR
+    loader, batch, nj_db = reference_validation_loader(which, lens, T, seed_db)
     model = load_synth(T_mod.TePose(seqlen=T, n_layers=L, hidden_size=H, pretrained='').eval(), synth.synthetic_state_dict(L, H, seed_w))
     calls = []
     model.register_forward_hook(lambda m, i, o: calls.append({k: o[-1][k].detach().clone() for k in ('theta', 'kp_3d', 'verts')}))

@@ -110,3 +110,27 @@ def test_clip_selection_equals_what_evaluate_py_keys():
         for k in ours:
             for f in ('features', 'joints3D', 'theta_pseu', 'pose', 'shape'):
                 assert np.array_equal(np.asarray(ours[k][f], dtype=np.float64), np.asarray(ns['dataset_data'][k][f], dtype=np.float64)), (seq, k, f)
+
+
+def test_the_default_validation_dataset_class_emits_the_same_batch():
+    """Five of the six shipped configs validate with TRAIN.DATASET_EVAL = 'ThreeDPW' (lib/dataset/loaders.py:118: `ThreeDPW(set='val')`, i.e. Dataset3D in
+    lib/dataset/dataset_3d.py), the sixth with 'Human36M_VAL'.  On the same synthetic database the reference's ThreeDPW(set='val') emits the batch its
+    ThreeDPW_TEST emits -- the one tests/golden/padded_ds_L1H64_T5.npz holds and tepose_amd.data.padded_validation_batch reproduces bit for bit."""
+    import importlib.util
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location('make_golden_mod3', GEN)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.install_stubs()
+    from tepose_amd.data import padded_validation_batch, synthetic_eval_db
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'padded_ds_L1H64_T5.npz'))
+    T, seed_db, lens = int(g['meta'][2]), int(g['meta'][4]), [int(v) for v in g['db_lens']]
+    _, batch, nj = mg.reference_validation_loader('3dpw_val', lens, T, seed_db)
+    assert nj == 14
+    for k in ('features', 'theta', 'theta_pseu', 'kp_3d'):
+        assert np.array_equal(batch[k].numpy(), g[k].astype(np.float32)), k
+    assert np.array_equal(batch['vidlen_each'].numpy(), g['vidlen_each']) and np.array_equal(batch['index'].numpy(), g['index'])
+    ours = padded_validation_batch(*synthetic_eval_db(lens, seed=seed_db, joints=14), seqlen=T)
+    for k in ('features', 'theta', 'theta_pseu', 'kp_3d', 'vidlen_each', 'index'):
+        assert np.array_equal(ours[k].numpy(), batch[k].numpy()), k
