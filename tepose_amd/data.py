@@ -111,10 +111,13 @@ def synthetic_eval_db(lengths, seed=0, joints=49):
     return db, pse
 
 
-def padded_validation_batch(db, pseudotheta, seqlen, joints=14):
+def padded_validation_batch(db, pseudotheta, seqlen, joints=14, eval_class=None):
     """The batch the reference's validation Datasets hand to trainer.validate (lib/dataset/threedpw_test.py:54-134,
     h36m_val.py; lib/data_utils/_img_utils.py:356-376), hot-path fields only.  A database whose `joints3D` hold the 49 'spin' joints (Human3.6M:
     h36m_val.py:77 `convert_kps(..., src='spin', dst='common')`) is converted to the 14 common joints first; a 14-joint database (3DPW test) is taken as is.
+    eval_class (the config's TRAIN.DATASET_EVAL, lib/dataset/loaders.py:118): None / 'ThreeDPW' / 'ThreeDPW_TEST' / 'Human36M_VAL' = the above;
+    'Human36M' (Dataset3D on H3.6M, dataset_3d.py:189-194,214-219): common joints as above, but ground-truth pose and shape ZERO; 'MPII3D'
+    (dataset_3d.py:182-187,231-233): the 17 `mpii3d_test` joints, pose and shape zero.
     Videos in order of first appearance of their
     `vid_name`, those shorter than `seqlen` dropped, every clip zero-padded to the longest; the arrays are staged in
     float16 exactly as the Datasets do (`np.zeros(..., dtype=np.float16)` filled, then `.float()`), so features and
@@ -130,6 +133,11 @@ def padded_validation_batch(db, pseudotheta, seqlen, joints=14):
     if not spans:
         return None
     C, vidlen = len(spans), max(e - s for s, e in spans)
+    if eval_class not in (None, 'ThreeDPW', 'ThreeDPW_TEST', 'Human36M_VAL', 'Human36M', 'MPII3D'):
+        raise ValueError('unknown validation dataset class %r' % (eval_class,))
+    zero_gt = eval_class in ('Human36M', 'MPII3D')
+    if eval_class == 'MPII3D':
+        joints = 17
     pse = np.asarray(pseudotheta, dtype=np.float32)
     feats = np.zeros((C, vidlen, 2048), dtype=np.float16)
     theta = np.zeros((C, vidlen, 85), dtype=np.float16)
@@ -139,10 +147,14 @@ def padded_validation_batch(db, pseudotheta, seqlen, joints=14):
     for c, (s, e) in enumerate(spans):
         n = e - s
         feats[c, :n] = db['features'][s:e]
-        theta[c, :n] = np.concatenate([cam[:n], db['pose'][s:e], db['shape'][s:e]], axis=1)
+        theta[c, :n] = np.concatenate([cam[:n], np.zeros((n, 82), np.float32)], axis=1) if zero_gt else \
+            np.concatenate([cam[:n], db['pose'][s:e], db['shape'][s:e]], axis=1)
         theta_pseu[c, :n] = np.concatenate([cam[:n], pse[s:e, 3:75], pse[s:e, 75:]], axis=1)
         j3 = np.asarray(db['joints3D'][s:e])
-        if j3.shape[1] == 49:                                    # h36m_val.py:77: spin -> common (the 14 LSP joints), then [:nj]
+        if eval_class == 'MPII3D':                               # dataset_3d.py:187: spin -> mpii3d_test (17 joints)
+            from .metrics import SPIN_TO_MPII3D_TEST
+            j3 = j3[:, SPIN_TO_MPII3D_TEST]
+        elif j3.shape[1] == 49:                                  # h36m_val.py:77 / dataset_3d.py:194: spin -> common (the 14 LSP joints), then [:nj]
             from .metrics import SPIN_TO_COMMON
             j3 = j3[:, SPIN_TO_COMMON]
         kp_3d[c, :n] = j3[:, :joints]

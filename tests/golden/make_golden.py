@@ -616,6 +616,16 @@ def reference_validation_loader(which, lens, T, seed_db):
     if which == 'h36m':
         import lib.dataset.h36m_val as DS
         make, stem, nj_db = (lambda: DS.Human36M_VAL(load_opt=None, set='test', seqlen=T, vidlen=max(lens), debug=False)), 'h36m_test_front_25fps_tight', 49
+    elif which in ('h36m_ds3d', 'mpii3d_ds3d'):
+        # Dataset3D's own H3.6M / MPI-INF-3DHP validation forms (TRAIN.DATASET_EVAL = 'Human36M' / 'MPII3D': no shipped config, but the class offers them):
+        # zero ground-truth pose / shape, 14 common resp. 17 mpii3d_test joints
+        import lib.dataset.dataset_3d as DS
+        if which == 'h36m_ds3d':
+            import lib.dataset.h36m as HD
+            make, stem, nj_db = (lambda: HD.Human36M(load_opt='repr_wpw_3dpw_model', set='val', seqlen=T, vidlen=max(lens), debug=False)), 'h36m_val', 49
+        else:
+            import lib.dataset.mpii3d as MD
+            make, stem, nj_db = (lambda: MD.MPII3D(load_opt='repr_wpw_3dpw_model', set='val', seqlen=T, vidlen=max(lens), debug=False)), 'mpii3d_val_scale12', 49
     elif which == '3dpw_val':
         import lib.dataset.dataset_3d as DS
         import lib.dataset.threedpw as TD
@@ -626,7 +636,7 @@ def reference_validation_loader(which, lens, T, seed_db):
     db, pse = synthetic_eval_db(list(lens), seed=seed_db, joints=nj_db)
     n = len(db['vid_name'])
     db = dict(db, joints2D=synth.normal('padds/j2d%d' % seed_db, (n, nj_db, 3), std=40.0) + 112.0, img_name=np.array(['f%06d.jpg' % i for i in range(n)]),
-              bbox=np.tile(np.array([112., 112., 180., 180.], dtype=np.float32), (n, 1)), frame_id=np.arange(n))
+              bbox=np.tile(np.array([112., 112., 180., 180.], dtype=np.float32), (n, 1)), frame_id=np.arange(n), valid_i=np.ones((n, 1), dtype=np.float32))
     tmp = tempfile.mkdtemp(prefix='tepose_golden_')
     joblib.dump(db, os.path.join(tmp, stem + '_db.pt'))
     joblib.dump(np.asarray(pse), os.path.join(tmp, stem + '_pseudotheta.pt'))

@@ -134,3 +134,24 @@ def test_the_default_validation_dataset_class_emits_the_same_batch():
     ours = padded_validation_batch(*synthetic_eval_db(lens, seed=seed_db, joints=14), seqlen=T)
     for k in ('features', 'theta', 'theta_pseu', 'kp_3d', 'vidlen_each', 'index'):
         assert np.array_equal(ours[k].numpy(), batch[k].numpy()), k
+
+
+def test_dataset3d_validation_forms_of_h36m_and_mpii3d():
+    """Dataset3D(set='val') on H3.6M / MPI-INF-3DHP (lib/dataset/dataset_3d.py:182-194,214-233: TRAIN.DATASET_EVAL = 'Human36M' / 'MPII3D'): the 14 common resp.
+    17 mpii3d_test joints of a 49-joint database, ground-truth pose / shape zero.  tepose_amd.data.padded_validation_batch(eval_class=...) against the
+    reference classes' batch on the same synthetic database, bit for bit."""
+    import importlib.util
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location('make_golden_mod4', GEN)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.install_stubs()
+    from tepose_amd.data import padded_validation_batch, synthetic_eval_db
+    lens, T, seed_db = [11, 3, 20, 7], 5, 55
+    for which, cls, nj in (('h36m_ds3d', 'Human36M', 14), ('mpii3d_ds3d', 'MPII3D', 17)):
+        _, batch, nj_db = mg.reference_validation_loader(which, lens, T, seed_db)
+        assert nj_db == 49 and batch['kp_3d'].shape[2] == nj and not batch['theta'][:, :, 3:].any()
+        ours = padded_validation_batch(*synthetic_eval_db(lens, seed=seed_db, joints=49), seqlen=T, eval_class=cls)
+        for k in ('features', 'theta', 'theta_pseu', 'kp_3d', 'vidlen_each', 'index'):
+            assert np.array_equal(ours[k].numpy(), batch[k].numpy()), (which, k)
