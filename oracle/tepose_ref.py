@@ -16,9 +16,14 @@ eval mode.  Citations are relative to /root/reference:
   R -> aa      lib/utils/geometry.py:68-233
 
 PARITY PINNING.  Everything except LBS is pinned against the reference's own
-classes run in the build container (tests/golden/make_golden.py imports
+code run in the build container (tests/golden/make_golden.py imports
 /root/reference with stub modules and writes tests/golden/*.npz; the `-m "not
-gpu"` tests check this file against those vectors).  The LBS arithmetic itself
+gpu"` tests check this file against those vectors): the model / function vectors
+call the reference's classes and functions, the flow vectors (evaluation incl.
+--filter, clip driver, demo live path, trainer validation from the database file
+on, metrics, filters) EXECUTE the reference's own statements -- AST slices of
+evaluate.py / demo.py, the unbound Trainer.validate / .evaluate, the validation
+Dataset classes.  Axis-angle -> R is pinned to lib/utils/geometry.py:22-65.  The LBS arithmetic itself
 lives in the third-party package `smplx` (requirements.txt:7 pins 0.1.13; the
 code imports `SMPLOutput`, so a later 0.1.2x was really used), which is neither
 vendored in the reference nor installed here and whose licence-gated model files
