@@ -128,7 +128,7 @@ def test_dataset_branches_match_the_reference_flow(case):
         assert abs(float(r[3]) - float(g['pa_all'][g['pose_map']].sum())) < 2e-3 * len(g['pose_map'])
 
 
-@pytest.mark.parametrize('case,world', [('eval_mpii3d_L1H64_T5', 1), ('eval_h36m_L1H64_T5', 2)])
+@pytest.mark.parametrize('case,world', [('eval_mpii3d_L1H64_T5', 1), ('eval_h36m_L1H64_T5', 2), ('eval_3dpw_filter_L2H64_T6', 1)])
 def test_the_eval_tool_on_files_alone_reproduces_the_reference_flow(tmp_path, case, world):
     """tools/evaluate_clips.py in real-data mode: database + pseudo-theta (joblib), base data (J_regressor_h36m.npy,
     smpl_mean_params.npz, SMPL_NEUTRAL.pkl, J_regressor_extra.npy), experiment YAML and the two checkpoints all read from
@@ -149,7 +149,8 @@ def test_the_eval_tool_on_files_alone_reproduces_the_reference_flow(tmp_path, ca
     db, pse = synthetic_eval_db(lens, seed=int(g['meta'][4]), joints=fx['joints'])
     for f in g['invalid_frames']:
         db['valid'][int(f)] = 0
-    stem = 'mpii3d_val_scale12' if fx['dataset'] == 'mpii3d' else 'h36m_test_25fps_nosmpl'
+    stem = {'mpii3d': 'mpii3d_val_scale12', 'h36m': 'h36m_test_25fps_nosmpl', '3dpw': '3dpw_test'}[fx['dataset']]
+    title = 'repr_wpw_3dpw_model' if fx['dataset'] == '3dpw' else 'repr_wpw_h36m_mpii3d_model'
     if fx['dataset'] == 'mpii3d':
         db['valid_i'] = g['valid_i']
     joblib.dump(db, tmp_path / (stem + '_db.pt'))
@@ -161,17 +162,21 @@ def test_the_eval_tool_on_files_alone_reproduces_the_reference_flow(tmp_path, ca
     write_base_data(tmp_path / 'base', smpl_np, mean)
     write_checkpoint(tmp_path / 'tepose.pth.tar', state)
     write_checkpoint(tmp_path / 'vibe.pth.tar', vstate)
-    write_cfg(tmp_path / 'c.yaml', 'repr_wpw_h36m_mpii3d_model', fx['L'], fx['H'], pretrained=str(tmp_path / 'tepose.pth.tar'))
+    write_cfg(tmp_path / 'c.yaml', title, fx['L'], fx['H'], pretrained=str(tmp_path / 'tepose.pth.tar'))
     cmd = [sys.executable, 'tools/evaluate_clips.py', '--cfg', str(tmp_path / 'c.yaml'), '--dataset', fx['dataset'],
            '--db-dir', str(tmp_path), '--base-data', str(tmp_path / 'base'), '--vibe-ckpt', str(tmp_path / 'vibe.pth.tar'),
            '--vibe-layers', str(fx['L']), '--vibe-hidden', str(fx['H']), '--seqlen', str(fx['T'])]
+    if fx['avg_filter']:
+        cmd += ['--filter']                                          # evaluate.py --filter (lines 273-291)
     if world > 1:
         cmd += ['--gpus', str(world), '--backend', 'gloo', '--share-device0']
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['data'] == 'real' and line['tables'] == 'files' and line['n_gpus'] == world
+    assert line['data'] == 'real' and line['tables'] == 'files' and line['n_gpus'] == world and line['avg_filter'] == fx['avg_filter']
+    if fx['dataset'] == '3dpw':
+        assert line['vs_published']['mpjpe']['published'] == 84.6      # the published row of this config / set rides along
     assert set(line['metrics_mm']) == set(fx['final'])
     for k, v in fx['final'].items():
         assert abs(line['metrics_mm'][k] - v) < 1e-2, (k, line['metrics_mm'][k], v)
