@@ -316,4 +316,4 @@ def test_sync_mode_never_returns_nan_while_another_thread_polls_the_handle(smpl_
         stop.set()
         th.join()
     assert ref is not None
-    print('  poller collected the fault word first in %d of 12 forwards' % stolen[0])
+    print('  the poller collected the fault word %d times during the 12 forwards' % stolen[0])
