@@ -44,6 +44,7 @@ struct Options {
   int split_few_max_rows = 1024;     // TEPOSE_SPLIT_FEW_MAX_ROWS: rows up to which launch_split_rows runs one workgroup per row (222 rows 12.3 -> 5 us, 1024 rows 13 -> 8)
   int h3_tile = 0;                   // TEPOSE_H3_TILE: A/B, force a tile shape of gemm_h3_kernel (64 / 192 / 256)
   int h3_tile64 = 1;                 // TEPOSE_H3_TILE64: 0 = never pick 64-row tiles (A/B)
+  int h3_tile192 = 1;                // TEPOSE_H3_TILE192: 0 = never pick 128 x 192 tiles (A/B)
   int s16_gm = 8;                    // TEPOSE_S16_GM: row tiles per XCD group of the barrier-free projection's walk (layer-0 projection ms at 2 / 4 / 8 / 16 / 32: 10.92 / 10.82 / 10.74 / 11.37 / 12.37)
   int gru_gm = 4;                    // TEPOSE_GRU_GM: the same for the fused step (recurrent ms per forward at 1 / 2 / 4 / 8 / 16 / 32: 11.31 / 11.27 / 11.22 / 11.41 / 11.41 / 11.77)
   int seq_gran_max_m = 4;            // TEPOSE_SEQ_GRAN_MAX_M: rows up to which the persistent recurrent kernel hands its state over as tagged granules (B = 1 -14 %, 4 -5 %, 8 +20 %)

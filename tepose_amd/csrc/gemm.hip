@@ -243,7 +243,7 @@ struct OptName { const char* name; int Options::*field; };
 const OptName kOptNames[] = {
     {"SKINNY_MAX_M", &Options::skinny_max_m}, {"SKINNY_MAX_M_GEMM", &Options::skinny_max_m_gemm}, {"SPLIT_MIN_M", &Options::split_min_m},
     {"SKINNY_H3_MAX_M", &Options::skinny_h3_max_m}, {"GEMM_HALF_MAX_BLOCKS", &Options::gemm_half_max_blocks},
-    {"SPLIT_FEW_MAX_ROWS", &Options::split_few_max_rows}, {"H3_TILE", &Options::h3_tile}, {"H3_TILE64", &Options::h3_tile64}, {"S16_GM", &Options::s16_gm},
+    {"SPLIT_FEW_MAX_ROWS", &Options::split_few_max_rows}, {"H3_TILE", &Options::h3_tile}, {"H3_TILE64", &Options::h3_tile64}, {"H3_TILE192", &Options::h3_tile192}, {"S16_GM", &Options::s16_gm},
     {"GRU_GM", &Options::gru_gm}, {"SEQ_GRAN_MAX_M", &Options::seq_gran_max_m}, {"SEQ_MAX_M", &Options::seq_max_m}, {"REG_SEQ_MAX_N", &Options::reg_seq_max_n},
     {"ASSUME_CUS", &Options::assume_cus}, {"SKINNY_NARROW64", &Options::skinny_narrow64}, {"SKINNY_MT1", &Options::skinny_mt1},
     {"SKINNY_NT1_BELOW", &Options::skinny_nt1_below}, {"SKINNY_W8", &Options::skinny_w8}, {"SMPL_SMALL_MAX_N", &Options::smpl_small_max_n},

@@ -780,6 +780,17 @@ hipError_t launch_gemm_h3(const H3Batch& b, hipStream_t s, const Options& o) {
     const double w128 = (double)tm * tilesN * b.n, w64 = (double)tm64 * tilesN * b.n;
     // (more than one 64-row workgroup per CU: the first sharing costs 1.55 rounds whatever the count -- 288 workgroups 51.8 us, 384: 53.0, 504: 62.8)
     const double c128 = 47. * (double)(long)((w128 + 255.) / 256.), c64 = 33. * (w64 <= 256. ? 1. : (w64 / 256. > 1.55 ? w64 / 256. : 1.55));
+    // ... and 128 x 192 tiles (round 6) where they turn "a round and a bit" of 128 x 128 tiles into exactly one round: a tile's time follows its operand
+    // bytes, (128 + 192) against (128 + 128) rows per K-tile, measured 70 us per round at K = 2048 -- the layer-1 projections of cfg-B (two products of
+    // 1024 x 3072: 384 tiles of 128 x 128 = 1.5 rounds, 256 tiles of 128 x 192 = one round): 81.8 -> 72.4 us (profiles/r06_README.md).  Column counts
+    // that are whole 192-column tiles only (3 Hp always is): the W planes are padded to 128 rows, not to 192.
+    if (o.h3_tile192 && b.p[0].N % 192 == 0) {
+      const double w192 = (double)tm * (b.p[0].N / 192) * b.n, c192 = 70. * (double)(long)((w192 + 255.) / 256.);
+      if (c192 < 0.9 * c128 && c192 <= c64) {
+        hipLaunchKernelGGL((gemm_h3_kernel<1, 3, 3, false, false>), dim3(tm * (b.p[0].N / 192), b.n), dim3(512), 0, s, b, tm, b.p[0].N / 192);
+        return hipGetLastError();
+      }
+    }
     if (t64 && c64 < 0.9 * c128) {
       hipLaunchKernelGGL((gemm_h3_kernel<1, 2, 3, false, false, 2>), dim3(tm64 * tilesN, b.n), dim3(256), 0, s, b, tm64, tilesN);
       return hipGetLastError();

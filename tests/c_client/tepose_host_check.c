@@ -96,7 +96,7 @@ int main(void) {
 
   /* the option table: every name, with and without the prefix; per handle */
   static const char* names[] = {"SKINNY_MAX_M", "SKINNY_MAX_M_GEMM", "SPLIT_MIN_M", "SKINNY_H3_MAX_M", "GEMM_HALF_MAX_BLOCKS", "SPLIT_FEW_MAX_ROWS", "H3_TILE",
-                                "H3_TILE64", "S16_GM", "GRU_GM", "SEQ_GRAN_MAX_M", "SEQ_MAX_M", "REG_SEQ_MAX_N", "ASSUME_CUS", "SKINNY_NARROW64", "SKINNY_MT1",
+                                "H3_TILE64", "H3_TILE192", "S16_GM", "GRU_GM", "SEQ_GRAN_MAX_M", "SEQ_MAX_M", "REG_SEQ_MAX_N", "ASSUME_CUS", "SKINNY_NARROW64", "SKINNY_MT1",
                                 "SKINNY_NT1_BELOW", "SKINNY_W8", "SMPL_SMALL_MAX_N", "L1_SKINNY_MAX_ROWS", "G0_MID_MIN_ROWS", "G0_SKINNY_MAX_M", "S_MIN_B",
                                 "BLEND16_MIN_N", "GI_BLK", "SEQ_SPIN_LIMIT"};
   tepose_model *a = NULL, *b = NULL;
